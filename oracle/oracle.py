@@ -1,0 +1,373 @@
+"""TEST INFRASTRUCTURE ONLY - Python face of the CPU oracle.
+
+The typed inner loops live in ``sitator_oracle.c`` (ctypes); the numpy-level glue of the
+reference (Step 1, ``PBCCalculator.average``, the ``min_samples`` filter, both cluster
+plugins, site centres, jump iteration) is restated here with numpy, which is also what
+the reference computes it with.  Parity status: PINNED by ``tests/golden`` (see the
+header of ``sitator_oracle.c``).  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module.
+
+Citations are relative to /root/reference/sitator.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+
+
+def build(quiet=True):
+    subprocess.check_call(["make", "-C", _HERE] + (["-s"] if quiet else []))
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "_build", "libsitator_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_cutoff_round_to_zero.restype = C.c_double
+        L.orc_cutoff_round_to_zero.argtypes = [C.c_double] * 3
+        L.orc_fit_centers.restype = C.c_int64
+        L.orc_predict.restype = C.c_int64
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+class OracleError(Exception):
+    """Carries what the reference's exceptions carry (landmark/errors.py, errors.py)."""
+
+    def __init__(self, kind, **attrs):
+        super().__init__("%s %s" % (kind, attrs))
+        self.kind = kind
+        self.__dict__.update(attrs)
+
+
+# ---- PBCCalculator (util/PBCCalculator.pyx) ----------------------------------------
+
+def pbc_constants(cell):
+    """:22-35 - cell_mat = cell.T, its inverse, centroid = sum(0.5 * cell, axis 0)."""
+    cell = np.asarray(cell, dtype=np.float64)
+    cm = np.ascontiguousarray(cell.T)
+    ci = np.ascontiguousarray(np.linalg.inv(cm))
+    cen = np.sum(0.5 * cell, axis=0)
+    return cm, ci, cen
+
+
+def wrap_points(cell, pts):
+    """:341-366 (returns a wrapped copy)."""
+    cm, ci, _ = pbc_constants(cell)
+    out = np.array(pts, dtype=np.float64, order="C").reshape(-1, 3)
+    lib().orc_wrap_points(_d(cm), _d(ci), _d(out), C.c_int64(len(out)))
+    return out.reshape(np.shape(pts))
+
+
+def distances(cell, pt1, pts2):
+    """:64-103."""
+    cm, ci, cen = pbc_constants(cell)
+    pt1 = np.ascontiguousarray(pt1, dtype=np.float64)
+    pts2 = np.ascontiguousarray(pts2, dtype=np.float64).reshape(-1, 3)
+    out = np.empty(len(pts2))
+    lib().orc_distances(_d(cm), _d(ci), _d(cen), _d(pt1), _d(pts2), C.c_int64(len(pts2)), _d(out))
+    return out
+
+
+def average(cell, points, weights=None):
+    """:106-139."""
+    _, _, cen = pbc_constants(cell)
+    points = np.asarray(points, dtype=np.float64)
+    about = 0 if weights is None else int(np.argmax(weights))
+    offset = cen - points[about]
+    buf = wrap_points(cell, points + offset)
+    out = np.average(buf, weights=weights, axis=0)
+    out = out - offset
+    return wrap_points(cell, out[None, :])[0]
+
+
+# ---- LandmarkAnalysis.run Step 1 (landmark/LandmarkAnalysis.py:194-202) ---------------
+
+def site_vertex_distances(cell, centers, vertices, static_pos):
+    V = max(len(v) for v in vertices)
+    D = len(vertices)
+    verts = np.full((D, V), -1, dtype=np.int64)
+    vcd = np.full((D, V), np.nan)
+    for k, poly in enumerate(vertices):
+        poly = np.asarray(poly, dtype=np.int64)
+        verts[k, :len(poly)] = poly
+        vcd[k, :len(poly)] = distances(cell, centers[k], static_pos[poly])
+    return verts, vcd
+
+
+# ---- landmark vectors (landmark/helpers.pyx) ---------------------------------------
+
+def fill(cell, wrapped_frames, static_idx, mobile_idx, ref_static, verts, vcd,
+         cutoff_midpoint=1.5, cutoff_steepness=30, static_movement_threshold=1.0,
+         dynamic_lattice_mapping=False, relaxed_lattice_checks=False, check_for_zeros=True):
+    """helpers.pyx:12-124.  Returns (lvecs[N,D], n_all_zero); raises OracleError."""
+    cm, ci, cen = pbc_constants(cell)
+    frames = np.ascontiguousarray(wrapped_frames, dtype=np.float64)
+    F, A, _ = frames.shape
+    static_idx = np.ascontiguousarray(static_idx, dtype=np.int64)
+    mobile_idx = np.ascontiguousarray(mobile_idx, dtype=np.int64)
+    ref_static = np.ascontiguousarray(ref_static, dtype=np.float64)
+    verts = np.ascontiguousarray(verts, dtype=np.int64)
+    vcd = np.ascontiguousarray(vcd, dtype=np.float64)
+    S, M = len(static_idx), len(mobile_idx)
+    D, V = verts.shape
+    lvecs = np.zeros((F * M, D))
+    nz = C.c_int64(0)
+    dups = C.c_int64(0)
+    err = np.zeros(2, dtype=np.int64)
+    seen = np.zeros(S, dtype=np.uint8)
+    rc = lib().orc_fill(_d(cm), _d(ci), _d(cen), _d(frames), C.c_int64(F), C.c_int64(A),
+                        _i(static_idx), C.c_int64(S), _i(mobile_idx), C.c_int64(M), _d(ref_static),
+                        _i(verts), _d(vcd), C.c_int64(D), C.c_int64(V),
+                        C.c_double(cutoff_midpoint), C.c_double(cutoff_steepness),
+                        C.c_double(static_movement_threshold),
+                        C.c_int(int(dynamic_lattice_mapping)), C.c_int(int(relaxed_lattice_checks)),
+                        C.c_int(int(check_for_zeros)), _d(lvecs), C.byref(nz), _i(err),
+                        seen.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(dups))
+    if rc == 1:
+        raise OracleError("StaticLatticeError", lattice_atoms=[int(err[1])], frame=int(err[0]))
+    if rc == 2:
+        raise OracleError("StaticLatticeError", lattice_atoms=np.where(seen == 0)[0], frame=int(err[0]))
+    if rc == 3:
+        raise OracleError("ZeroLandmarkError", mobile_index=int(err[1]), frame=int(err[0]))
+    return lvecs, int(nz.value)
+
+
+# ---- DotProdClassifier (util/DotProdClassifier.pyx) -----------------------------------
+
+def fit_centers(X, threshold, max_iters=10):
+    """:199-315."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    N, D = X.shape
+    ptr = _dp()
+    iters = C.c_int64(0)
+    K = lib().orc_fit_centers(_d(X), C.c_int64(N), C.c_int64(D), C.c_double(threshold),
+                              C.c_int64(max_iters), C.byref(ptr), C.byref(iters))
+    if K < 0:
+        raise OracleError("ValueError", what="Clustering did not converge after %i iterations" % max_iters)
+    out = np.ctypeslib.as_array(ptr, shape=(K, D)).copy()
+    lib().orc_free(ptr)
+    return out
+
+
+def predict(X, centers, threshold, normed=True):
+    """:129-197.  Confidence of all-zero rows is written 0.0 (uninitialised in the reference)."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    centers = np.ascontiguousarray(centers, dtype=np.float64)
+    N, D = X.shape
+    labels = np.empty(N, dtype=np.int64)
+    confs = np.empty(N)
+    lib().orc_predict(_d(X), C.c_int64(N), C.c_int64(D), _d(centers), C.c_int64(len(centers)),
+                      C.c_double(threshold), C.c_int(int(normed)), _i(labels), _d(confs))
+    return labels, confs
+
+
+def fit_predict(X, threshold, min_samples, predict_threshold=None, predict_normed=True,
+                centers=None, max_iters=10):
+    """:68-127.  Returns labels, confs, centres, counts, kept-mask."""
+    if predict_threshold is None:
+        predict_threshold = threshold
+    if centers is None:
+        centers = fit_centers(X, threshold, max_iters)
+    labels, confs = predict(X, centers, predict_threshold, predict_normed)
+    n_assigned = int(np.sum(labels >= 0))
+    counts = np.bincount(labels[labels >= 0], minlength=len(centers))
+    if isinstance(min_samples, (int, np.integer)):
+        ms = int(min_samples)
+    else:
+        ms = int(np.floor(min_samples * n_assigned))
+    ms = max(ms, 1)
+    mask = counts >= ms
+    centers = centers[mask]
+    counts = counts[mask]
+    if len(centers) == 0:
+        raise OracleError("ValueError", what="`min_samples` too large")
+    labels, confs = predict(X, centers, predict_threshold, predict_normed)
+    return labels, confs, centers, counts, mask
+
+
+def cluster_dotprod(X, params, min_samples):
+    """landmark/cluster/dotprod.py:11-33."""
+    p = {"clustering_threshold": 0.45, "assignment_threshold": 0.8}
+    p.update(params)
+    labels, confs, centers, counts, _ = fit_predict(
+        X, p["clustering_threshold"], min_samples, predict_threshold=p["assignment_threshold"])
+    return {"cluster-size": counts, "cluster-labels": labels, "cluster-confs": confs,
+            "cluster-representative-lvecs": centers}
+
+
+def markov_clustering(tm, expansion=2, inflation=2, pruning_threshold=0.00001, iterlimit=100):
+    """util/mcl.py:3-60."""
+    n = tm.shape[0]
+    assert tm.shape == (n, n) and np.count_nonzero(tm.diagonal()) == n
+    m1 = tm / np.sum(tm, axis=0)
+    cols = np.arange(n)
+    m2 = None
+    for _ in range(iterlimit):
+        m2 = np.linalg.matrix_power(m1, expansion)
+        np.power(m2, inflation, out=m2)
+        m2 /= np.sum(m2, axis=0)
+        prune = m2 < pruning_threshold
+        prune[np.argmax(m2, axis=0), cols] = False
+        m2[prune] = 0.0
+        if np.allclose(m1, m2):
+            break
+        m1 = m2.copy()
+    else:
+        raise OracleError("ValueError", what="Markov Clustering couldn't converge")
+    found = set()
+    for a in m2.diagonal().nonzero()[0]:
+        found.add(tuple(m2[a].nonzero()[0]))
+    return list(found)        # CPython set order, as the reference
+
+
+def cluster_mcl(X, params, min_samples):
+    """landmark/cluster/mcl.py:43-131."""
+    from scipy.sparse.linalg import eigsh
+    p = {"inflation": 4, "assignment_threshold": 0.7}
+    p.update(params)
+    N, D = X.shape
+    seen = np.count_nonzero(X, axis=0)
+    cov = np.dot(X.T, X) / N
+    d = np.sqrt(cov.diagonal())
+    d[d == 0] = np.inf
+    corr = ((cov.T / d).T) / d
+    graph = np.clip(corr, 0, None)
+    for i in range(D):
+        if graph[i, i] == 0:
+            graph[i, i] = 1
+    thr = p.pop("assignment_threshold")
+    good_normed = p.pop("good_site_normed_threshold", thr)
+    good_proj = p.pop("good_site_projected_threshold", thr)
+    weighted_reps = p.get("weighted_representative_landmarks", True)
+    groups = markov_clustering(graph, **p)   # every remaining key goes to MCL, as mcl.py:67
+    groups = [list(g) for g in groups if seen[g[0]] > 0]
+    centers = np.zeros((len(groups), D))
+    good = np.zeros(len(groups), dtype=bool)
+    for i, g in enumerate(groups):
+        if len(g) == 1:
+            centers[i, g] = 1.0
+        else:
+            _, vec = eigsh(cov[g][:, g], k=1)
+            centers[i, g] = vec.T
+        proj = np.abs(np.dot(X, centers[i]))
+        best = int(np.argmax(proj))
+        bdot = np.abs(np.dot(X[best], centers[i]))
+        bnorm = bdot / np.linalg.norm(X[best])
+        good[i] = (bnorm >= good_normed) and (bdot >= good_proj)
+        centers[i] /= bdot
+    groups = [g for i, g in enumerate(groups) if good[i]]
+    centers = centers[good]
+    labels, confs, _, counts, mask = fit_predict(X, np.nan, min_samples, predict_threshold=thr,
+                                                 predict_normed=False, centers=centers)
+    groups = [g for i, g in enumerate(groups) if mask[i]]
+    reps = np.zeros((len(groups), D))
+    for s in range(len(groups)):
+        w = (labels == s).astype(np.float64)
+        if weighted_reps:
+            w = w * confs
+        reps[s] = np.average(X, weights=w, axis=0)
+    return {"cluster-size": counts, "cluster-labels": labels, "cluster-confs": confs,
+            "cluster-landmark-groupings": groups, "cluster-representative-lvecs": reps}
+
+
+# ---- SiteTrajectory pieces (SiteTrajectory.py) -----------------------------------------
+
+def check_multiple_occupancy(traj, n_sites, max_mobile_per_site=1):
+    """:205-232."""
+    traj = np.ascontiguousarray(traj, dtype=np.int64)
+    F, M = traj.shape
+    nm = C.c_int64(0)
+    avg = C.c_double(0)
+    err = np.zeros(2, dtype=np.int64)
+    rc = lib().orc_check_multiple_occupancy(_i(traj), C.c_int64(F), C.c_int64(M), C.c_int64(n_sites),
+                                            C.c_int64(max_mobile_per_site), C.byref(nm), C.byref(avg), _i(err))
+    if rc:
+        f, s = int(err[0]), int(err[1])
+        raise OracleError("MultipleOccupancyError", mobile=np.where(traj[f] == s)[0], site=s, frame=f)
+    return int(nm.value), float(avg.value)
+
+
+def jumps(traj, unknown_as_jump=False):
+    """:307-373 (_jumped_generator + jumps): list of (frame, atom, from, to)."""
+    traj = np.asarray(traj)
+    last = traj[0].copy()
+    out = []
+    for f in range(1, len(traj)):
+        known = np.ones(traj.shape[1], dtype=bool) if unknown_as_jump else (traj[f] != -1)
+        jumped = (traj[f] != last) & known
+        for a in np.nonzero(jumped)[0]:
+            out.append((f, int(a), int(last[a]), int(traj[f, a])))
+        last[known] = traj[f, known]
+    return out
+
+
+# ---- the whole operator (landmark/LandmarkAnalysis.py:148-318) -------------------------
+
+def landmark_analysis(cell, ref_positions, static_mask, mobile_mask, centers, vertices, frames,
+                      clustering_algorithm="dotprod", clustering_params=None,
+                      cutoff_midpoint=1.5, cutoff_steepness=30, minimum_site_occupancy=0.01,
+                      site_centers_method="real-weighted", check_for_zero_landmarks=True,
+                      static_movement_threshold=1.0, dynamic_lattice_mapping=False,
+                      relaxed_lattice_checks=False, max_mobile_per_site=1):
+    static_mask = np.asarray(static_mask, dtype=bool)
+    mobile_mask = np.asarray(mobile_mask, dtype=bool)
+    centers = np.asarray(centers, dtype=np.float64)
+    frames = np.asarray(frames, dtype=np.float64)
+    F = len(frames)
+    M = int(mobile_mask.sum())
+    ref_static = np.asarray(ref_positions, dtype=np.float64)[static_mask & ~mobile_mask]
+    wrapped = wrap_points(cell, frames)                                   # :182-189
+    verts, vcd = site_vertex_distances(cell, centers, vertices, ref_static)   # :194-202
+    lvecs, n_zero = fill(cell, wrapped, np.where(static_mask)[0], np.where(mobile_mask)[0],
+                         ref_static, verts, vcd, cutoff_midpoint, cutoff_steepness,
+                         static_movement_threshold, dynamic_lattice_mapping,
+                         relaxed_lattice_checks, check_for_zero_landmarks)
+    func = {"dotprod": cluster_dotprod, "mcl": cluster_mcl}[clustering_algorithm]
+    res = func(lvecs, dict(clustering_params or {}), minimum_site_occupancy / float(M))   # :241
+    counts = res["cluster-size"]
+    labels = res["cluster-labels"].reshape(F, M)
+    confs = res["cluster-confs"].reshape(F, M)
+    reps = res.get("cluster-representative-lvecs")
+    K = len(counts)
+    if K < M / max_mobile_per_site:                                          # :266-271
+        raise OracleError("InsufficientSitesError", n_sites=K, n_mobile=M)
+    sc = np.empty((K, 3))
+    mob = wrapped[:, mobile_mask]
+    if site_centers_method in ("real-weighted", "real-unweighted"):          # :278-287
+        for s in range(K):
+            m = labels == s
+            sc[s] = average(cell, mob[m], confs[m] if site_centers_method == "real-weighted" else None)
+    elif site_centers_method == "representative-landmark":                   # :288-297
+        for s in range(K):
+            nzm = reps[s] > 0
+            sc[s] = average(cell, centers[nzm], reps[s, nzm])
+    else:
+        raise ValueError(site_centers_method)
+    out = {"wrapped": wrapped, "verts_np": verts, "site_vert_dists": vcd, "lvecs": lvecs,
+           "n_all_zero_lvecs": n_zero, "counts": counts, "labels": labels, "confs": confs,
+           "rep_lvecs": reps, "site_centers": sc}
+    if "cluster-landmark-groupings" in res:                                  # :301-305
+        out["groupings"] = res["cluster-landmark-groupings"]
+        out["site_vertices"] = [sorted(set().union(*[set(vertices[l]) for l in g]))
+                                for g in res["cluster-landmark-groupings"]]
+    out["n_multiple_assignments"], out["avg_mobile_per_site"] = \
+        check_multiple_occupancy(labels, K, max_mobile_per_site)             # :311
+    return out
