@@ -1,0 +1,200 @@
+/*
+ * sitator_hip.h -- C-ABI of libsitator_hip.so: the MI355X (gfx950) landmark-analysis
+ * hot path of Linux-cpp-lisp/sitator, hand-written HIP behind plain pointers and sizes.
+ *
+ * This is the boundary a reference maintainer binds with ctypes.
+ * Each entry point cites the reference interface it replaces; paths are relative to
+ * the reference's `sitator/` package.
+ *
+ * Conventions
+ *   - every function returns an int status (SIT_OK == 0); nothing throws or aborts;
+ *   - domain errors (the reference's exceptions) are reported through `sit_error`:
+ *     the first offender in the reference's (frame, index) iteration order;
+ *   - the caller owns every host buffer; the library owns device memory inside the
+ *     opaque `sit_ctx` (one context = one GPU = one host thread at a time);
+ *   - all reals are float64 and all indices int64 at the boundary, exactly as the
+ *     reference (`ctypedef double precision`, landmark/helpers.pyx:10; np.int);
+ *   - "rows" are landmark vectors: row i*M + j is mobile ion j in frame i
+ *     (landmark/helpers.pyx:212).  They live on the device in a fixed-width sparse
+ *     layout and are never materialised densely unless asked for.
+ */
+#ifndef SITATOR_HIP_H
+#define SITATOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sit_ctx sit_ctx;
+
+enum sit_status {
+    SIT_OK = 0,
+    SIT_ERR_INVALID = 1,            /* bad argument / call order (-> ValueError)            */
+    SIT_ERR_HIP = 2,                /* HIP runtime failure, see sit_last_message()          */
+    SIT_ERR_STATIC_THRESHOLD = 3,   /* StaticLatticeError, landmark/helpers.pyx:76-80       */
+    SIT_ERR_STATIC_UNASSIGNED = 4,  /* StaticLatticeError, landmark/helpers.pyx:87-92       */
+    SIT_ERR_ZERO_LANDMARK = 5,      /* ZeroLandmarkError,  landmark/helpers.pyx:116-118     */
+    SIT_ERR_MULTIPLE_OCCUPANCY = 6, /* MultipleOccupancyError, SiteTrajectory.py:219-226    */
+    SIT_ERR_NOT_CONVERGED = 7,      /* ValueError, util/DotProdClassifier.pyx:312-313       */
+    SIT_ERR_CAPACITY = 8            /* an internal capacity was exceeded (message says which)*/
+};
+
+/* kind = one of sit_status; frame / index / aux as the matching reference exception:
+ *   STATIC_THRESHOLD  : frame, index = lattice index            (lattice_atoms=[index])
+ *   STATIC_UNASSIGNED : frame (the unseen atoms: sit_static_seen)
+ *   ZERO_LANDMARK     : frame, index = mobile index
+ *   MULTIPLE_OCCUPANCY: frame, index = site                                            */
+typedef struct sit_error {
+    int32_t kind;
+    int64_t frame;
+    int64_t index;
+    int64_t aux;
+} sit_error;
+
+/* ---- context ------------------------------------------------------------------- */
+
+int sit_device_count(int *count);
+
+/* Replaces PBCCalculator.__init__ (util/PBCCalculator.pyx:22-35).
+ * cell[9]: rows are the cell vectors (ASE convention); cell_inv[9]: inverse of cell.T,
+ * computed by the caller exactly as the reference does (numpy), row-major.            */
+int sit_create(const double *cell, const double *cell_inv, int device, sit_ctx **out);
+void sit_destroy(sit_ctx *ctx);
+const char *sit_last_message(sit_ctx *ctx);
+
+/* ---- PBCCalculator parity surface (device kernels) -------------------------------- */
+
+/* PBCCalculator.wrap_points, util/PBCCalculator.pyx:341-366 (in place, host buffer). */
+int sit_wrap_points(sit_ctx *ctx, double *pts, int64_t n);
+/* PBCCalculator.distances, util/PBCCalculator.pyx:64-103 (shift-and-wrap).           */
+int sit_distances(sit_ctx *ctx, const double *pt1, const double *pts2, int64_t n, double *out);
+/* PBCCalculator.average, util/PBCCalculator.pyx:106-139; weights may be NULL.        */
+int sit_average(sit_ctx *ctx, const double *pts, const double *weights, int64_t n, double *out3);
+
+/* ---- landmark basis and trajectory -------------------------------------------------- */
+
+/* Result of LandmarkAnalysis.run Step 1 (landmark/LandmarkAnalysis.py:194-202):
+ * ref_static[S,3] = sn.static_structure.positions, verts[D,V] padded with -1 (statics-only
+ * numbering), vert_dists[D,V] padded with NaN.  static_threshold is needed here because the
+ * result-preserving landmark pruning tables are built from it (DESIGN.md "pruning").       */
+int sit_set_basis(sit_ctx *ctx, const double *ref_static, int64_t S,
+                  const int64_t *verts, const double *vert_dists, int64_t D, int64_t V,
+                  double cutoff_midpoint, double cutoff_steepness, double static_threshold);
+
+/* frames[F,A,3] float64 C-contiguous, UNWRAPPED (Step 0, LandmarkAnalysis.py:182-189, is fused
+ * into the kernels).  static_idx[S] / mobile_idx[M] = np.where(mask)[0].  Copies to HBM.
+ * frame0 = global index of the first frame (frame sharding across ranks).               */
+int sit_set_frames(sit_ctx *ctx, const double *frames, int64_t F, int64_t A,
+                   const int64_t *static_idx, int64_t S, const int64_t *mobile_idx, int64_t M,
+                   int64_t frame0);
+/* Same, but `frames_dev` is already device memory owned by the caller (borrowed).        */
+int sit_set_frames_device(sit_ctx *ctx, const void *frames_dev, int64_t F, int64_t A,
+                          const int64_t *static_idx, int64_t S, const int64_t *mobile_idx,
+                          int64_t M, int64_t frame0);
+/* Device address of the context's frame buffer (for callers that fill it on the device). */
+int sit_frames_device_ptr(sit_ctx *ctx, void **ptr);
+
+/* ---- landmark vectors: helpers._fill_landmark_vectors (landmark/helpers.pyx:12-124) --- */
+
+typedef struct sit_fill_params {
+    int32_t dynamic_lattice_mapping;   /* helpers.pyx:60-64,83 */
+    int32_t relaxed_lattice_checks;    /* helpers.pyx:87       */
+    int32_t check_for_zeros;           /* helpers.pyx:116-120  */
+    int32_t store_rows;                /* keep the sparse rows on the device (fit / mcl)   */
+    int32_t assign;                    /* fuse DotProdClassifier.predict (needs centres)   */
+    int32_t predict_normed;            /* util/DotProdClassifier.pyx:155-161               */
+    double  predict_threshold;         /* util/DotProdClassifier.pyx:184                   */
+} sit_fill_params;
+
+/* One streaming pass over the resident frames: wrap, static-lattice check, landmark vector
+ * per (frame, ion), optional fused assignment.  n_all_zero = self.n_all_zero_lvecs.
+ * On a domain error returns its status and fills *err.                                    */
+int sit_fill(sit_ctx *ctx, const sit_fill_params *p, int64_t *n_all_zero, sit_error *err);
+
+/* Seen-flags of the static atoms of one frame under dynamic mapping (helpers.pyx:87-92). */
+int sit_static_seen(sit_ctx *ctx, int64_t local_frame, uint8_t *seen);
+
+int sit_row_width(sit_ctx *ctx, int64_t *width);
+/* Dense landmark vectors (the `landmark_vectors` property, LandmarkAnalysis.py:136-141). */
+int sit_get_rows_dense(sit_ctx *ctx, int64_t row0, int64_t nrows, double *out);
+int sit_get_rows_sparse(sit_ctx *ctx, int64_t row0, int64_t nrows,
+                        int32_t *nnz, int32_t *idx, double *val);
+
+/* Install caller-provided dense rows X[N,D] as the context's rows (DotProdClassifier used
+ * stand-alone on an ndarray, util/DotProdClassifier.pyx:68,129,199).  Sets D if no basis is set. */
+int sit_set_rows_dense(sit_ctx *ctx, const double *rows, int64_t N, int64_t D);
+
+/* ---- DotProdClassifier (util/DotProdClassifier.pyx) --------------------------------- */
+
+/* fit_centers (:199-315) is a strictly ordered stream.  The clustering state (centres,
+ * counts) lives on the device; rows are pushed through it in order.                      */
+int sit_fit_reset(sit_ctx *ctx);
+int sit_fit_set_state(sit_ctx *ctx, const double *centers, const int64_t *counts, int64_t K);
+int sit_fit_get_state(sit_ctx *ctx, double *centers, int64_t *counts, int64_t *K);
+/* Stream the context's stored rows (all weights 1; first iteration, :233-288).           */
+int sit_fit_push_stored_rows(sit_ctx *ctx, double threshold);
+/* Stream caller-provided dense rows with weights (iterations >= 2, :290-299).            */
+int sit_fit_push_dense_rows(sit_ctx *ctx, const double *rows, const int64_t *weights,
+                            int64_t nrows, double threshold);
+
+/* set_cluster_centers (:58-59): centres[K,D] used by predict / fused assign.             */
+int sit_set_centers(sit_ctx *ctx, const double *centers, int64_t K, int normed);
+/* predict (:129-197) over the stored rows.  labels / confs may be NULL (kept on device);
+ * counts[K] = np.bincount(labels[labels >= 0]) (:92).                                     */
+int sit_predict(sit_ctx *ctx, double threshold, int64_t *labels, double *confs, int64_t *counts);
+/* Labels / confidences of the last predict or fused assign, from the device.              */
+int sit_get_assignments(sit_ctx *ctx, int64_t *labels, double *confs, int64_t *counts);
+
+/* ---- mcl plugin support (landmark/cluster/mcl.py) ------------------------------------ */
+
+/* G = X^T X (un-normalised, :55), seen[d] = count_nonzero(X[:, d]) (:54).                */
+int sit_gram(sit_ctx *ctx, double *G, int64_t *seen);
+/* argmax_n |X[n] . c| with first-max tie-break (:80-83): index, the dot, and |X[n]|.     */
+int sit_best_match(sit_ctx *ctx, const double *c, int64_t *row, double *dot, double *norm);
+/* sums[k] = sum_n w_n X[n], wsum[k] = sum_n w_n, w_n = (label==k) * (conf or 1) (:117-122) */
+int sit_weighted_row_sums(sit_ctx *ctx, int weighted, int64_t K, double *sums, double *wsum);
+
+/* ---- site centres (landmark/LandmarkAnalysis.py:276-287 + PBCCalculator.average) ------ */
+
+/* Pass 1: per site the anchor = first point of maximum weight (np.argmax, :124-125).      */
+int sit_site_anchors(sit_ctx *ctx, int weighted, int64_t K,
+                     double *wmax, int64_t *first_row, double *anchor_pts);
+/* Pass 2: sums[k] = (sum w, sum w*x, sum w*y, sum w*z) of points shifted by
+ * (centroid - anchor[k]) and wrapped (:127-134).                                         */
+int sit_site_sums(sit_ctx *ctx, int weighted, int64_t K, const double *anchor_pts, double *sums);
+
+/* ---- SiteTrajectory (SiteTrajectory.py) ---------------------------------------------- */
+
+/* check_multiple_occupancy (:205-232) on the device-resident labels:
+ * n_multi = sum_frames #(counts > 1), total = sum_frames sum(counts), nsites = sum_frames
+ * #unique sites (avg_mobile_per_site = total / nsites).                                   */
+int sit_check_occupancy(sit_ctx *ctx, int64_t K, int64_t max_per_site,
+                        int64_t *n_multi, int64_t *total, int64_t *nsites, sit_error *err);
+
+/* Upload a label array (and optional confidences) as the context's assignments, for a
+ * SiteTrajectory that was not produced on this context (SiteTrajectory.__init__, :15-42).
+ * Sets F, M (and the row count) if no frames are resident.                                */
+int sit_set_assignments(sit_ctx *ctx, const int64_t *labels, const double *confs,
+                        int64_t F, int64_t M, int64_t frame0);
+
+/* Jump detection, SiteTrajectory._jumped_generator (:347-373): for every (frame >= 1, ion)
+ * from[f*M+j] = the last known site before frame f if the ion jumped at f, else INT64_MIN.
+ * last_known_in[M] (NULL = frame 0 of this context is the trajectory start) / last_known_out[M]
+ * carry the forward-filled state across frame shards.                                     */
+int sit_jump_sources(sit_ctx *ctx, int unknown_as_jump, const int64_t *last_known_in,
+                     int64_t *from, int64_t *last_known_out);
+
+/* ---- measurement --------------------------------------------------------------------- */
+
+/* Device time (ms, HIP events on the library's stream) of the last call of each stage:
+ * [0] fill (+assign)  [1] fit  [2] predict  [3] gram  [4] site centres  [5] occupancy
+ * [6] H2D of frames.                                                                      */
+int sit_timers(sit_ctx *ctx, double *ms, int n);
+int sit_synchronize(sit_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SITATOR_HIP_H */

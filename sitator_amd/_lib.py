@@ -1,0 +1,364 @@
+"""ctypes binding of ``libsitator_hip.so`` (C-ABI declared in ``include/sitator_hip.h``).
+
+There is no CPU fallback: if the library is missing, or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import errors
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsitator_hip.so")
+
+OK, E_INVALID, E_HIP, E_STATIC_THRESHOLD, E_STATIC_UNASSIGNED, E_ZERO_LANDMARK, \
+    E_MULTIPLE_OCCUPANCY, E_NOT_CONVERGED, E_CAPACITY = range(9)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+_vp = C.c_void_p
+i64 = C.c_int64
+
+
+class SitError(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("frame", C.c_int64), ("index", C.c_int64), ("aux", C.c_int64)]
+
+
+class FillParams(C.Structure):
+    _fields_ = [("dynamic_lattice_mapping", C.c_int32), ("relaxed_lattice_checks", C.c_int32),
+                ("check_for_zeros", C.c_int32), ("store_rows", C.c_int32), ("assign", C.c_int32),
+                ("predict_normed", C.c_int32), ("predict_threshold", C.c_double)]
+
+
+# every symbol include/sitator_hip.h declares: (restype, argtypes)
+SIGNATURES = {
+    "sit_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sit_create": (C.c_int, [_dp, _dp, C.c_int, C.POINTER(_vp)]),
+    "sit_destroy": (None, [_vp]),
+    "sit_last_message": (C.c_char_p, [_vp]),
+    "sit_wrap_points": (C.c_int, [_vp, _dp, i64]),
+    "sit_distances": (C.c_int, [_vp, _dp, _dp, i64, _dp]),
+    "sit_average": (C.c_int, [_vp, _dp, _dp, i64, _dp]),
+    "sit_set_basis": (C.c_int, [_vp, _dp, i64, _ip, _dp, i64, i64, C.c_double, C.c_double, C.c_double]),
+    "sit_set_frames": (C.c_int, [_vp, _dp, i64, i64, _ip, i64, _ip, i64, i64]),
+    "sit_set_frames_device": (C.c_int, [_vp, _vp, i64, i64, _ip, i64, _ip, i64, i64]),
+    "sit_frames_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "sit_fill": (C.c_int, [_vp, C.POINTER(FillParams), _ip, C.POINTER(SitError)]),
+    "sit_static_seen": (C.c_int, [_vp, i64, _u8p]),
+    "sit_row_width": (C.c_int, [_vp, _ip]),
+    "sit_get_rows_dense": (C.c_int, [_vp, i64, i64, _dp]),
+    "sit_get_rows_sparse": (C.c_int, [_vp, i64, i64, _i32p, _i32p, _dp]),
+    "sit_set_rows_dense": (C.c_int, [_vp, _dp, i64, i64]),
+    "sit_fit_reset": (C.c_int, [_vp]),
+    "sit_fit_set_state": (C.c_int, [_vp, _dp, _ip, i64]),
+    "sit_fit_get_state": (C.c_int, [_vp, _dp, _ip, _ip]),
+    "sit_fit_push_stored_rows": (C.c_int, [_vp, C.c_double]),
+    "sit_fit_push_dense_rows": (C.c_int, [_vp, _dp, _ip, i64, C.c_double]),
+    "sit_set_centers": (C.c_int, [_vp, _dp, i64, C.c_int]),
+    "sit_predict": (C.c_int, [_vp, C.c_double, _ip, _dp, _ip]),
+    "sit_get_assignments": (C.c_int, [_vp, _ip, _dp, _ip]),
+    "sit_gram": (C.c_int, [_vp, _dp, _ip]),
+    "sit_best_match": (C.c_int, [_vp, _dp, _ip, _dp, _dp]),
+    "sit_weighted_row_sums": (C.c_int, [_vp, C.c_int, i64, _dp, _dp]),
+    "sit_site_anchors": (C.c_int, [_vp, C.c_int, i64, _dp, _ip, _dp]),
+    "sit_site_sums": (C.c_int, [_vp, C.c_int, i64, _dp, _dp]),
+    "sit_check_occupancy": (C.c_int, [_vp, i64, i64, _ip, _ip, _ip, C.POINTER(SitError)]),
+    "sit_set_assignments": (C.c_int, [_vp, _ip, _dp, i64, i64, i64]),
+    "sit_jump_sources": (C.c_int, [_vp, C.c_int, _ip, _ip, _ip]),
+    "sit_timers": (C.c_int, [_vp, _dp, C.c_int]),
+    "sit_synchronize": (C.c_int, [_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no GPU needed for loading); raises if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `make -C sitator_amd/csrc` (or __graft_entry__.build()). "
+                "sitator_amd has no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def device_count():
+    n = C.c_int(0)
+    load().sit_device_count(C.byref(n))
+    return n.value
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+class HipContext(object):
+    """One GPU-resident landmark-analysis context (thin, 1:1 over the C-ABI)."""
+
+    def __init__(self, cell, device=None):
+        self.lib = load()
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        cell = _f64(cell).reshape(3, 3)
+        # util/PBCCalculator.pyx:27-34 -- the inverse is numpy's, exactly as in the reference
+        cell_inv = _f64(np.asarray(np.linalg.inv(cell.T)))
+        self.cell = cell
+        self.cell_centroid = np.sum(0.5 * cell, axis=0)
+        h = _vp()
+        rc = self.lib.sit_create(_d(cell), _d(cell_inv), int(device), C.byref(h))
+        self._h = h
+        self.device = int(device)
+        if rc != OK:
+            msg = self.message()
+            self.close()
+            raise RuntimeError("sit_create failed on device %d: %s (is a GPU visible?)" % (device, msg))
+        self.D = self.S = self.M = self.F = self.N = self.K = 0
+        self.frame0 = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.sit_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def message(self):
+        m = self.lib.sit_last_message(self._h)
+        return m.decode() if m else ""
+
+    def _check(self, rc, err=None):
+        if rc == OK:
+            return
+        if rc == E_INVALID:
+            raise ValueError(self.message())
+        if rc == E_NOT_CONVERGED:
+            raise ValueError(self.message())
+        if rc in (E_HIP, E_CAPACITY):
+            raise RuntimeError("libsitator_hip: %s" % self.message())
+        raise errors.DeviceDomainError(rc, err.frame if err else -1, err.index if err else -1)
+
+    # -- PBCCalculator surface
+    def wrap_points(self, pts):
+        pts = _f64(pts)
+        assert pts.ndim == 2 and pts.shape[1] == 3, "Points must be 3D"
+        self._check(self.lib.sit_wrap_points(self._h, _d(pts), len(pts)))
+        return pts
+
+    def distances(self, pt1, pts2):
+        pt1 = _f64(pt1)
+        pts2 = _f64(pts2)
+        out = np.empty(len(pts2))
+        self._check(self.lib.sit_distances(self._h, _d(pt1), _d(pts2), len(pts2), _d(out)))
+        return out
+
+    def average(self, pts, weights=None):
+        pts = _f64(pts)
+        w = None if weights is None else _f64(weights)
+        out = np.empty(3)
+        self._check(self.lib.sit_average(self._h, _d(pts), None if w is None else _d(w), len(pts), _d(out)))
+        return out
+
+    # -- residency
+    def set_basis(self, ref_static, verts, vert_dists, midpoint, steepness, static_threshold):
+        ref_static = _f64(ref_static)
+        verts = _i64(verts)
+        vert_dists = _f64(vert_dists)
+        self.S = len(ref_static)
+        self.D, self.V = verts.shape
+        self._check(self.lib.sit_set_basis(self._h, _d(ref_static), self.S, _i(verts), _d(vert_dists),
+                                           self.D, self.V, float(midpoint), float(steepness),
+                                           float(static_threshold)))
+
+    def set_frames(self, frames, static_idx, mobile_idx, frame0=0):
+        frames = _f64(frames)
+        static_idx = _i64(static_idx)
+        mobile_idx = _i64(mobile_idx)
+        self.F, self.A = frames.shape[0], frames.shape[1]
+        self.M = len(mobile_idx)
+        self.N = self.F * self.M
+        self.frame0 = int(frame0)
+        self._check(self.lib.sit_set_frames(self._h, _d(frames), self.F, self.A, _i(static_idx), len(static_idx),
+                                            _i(mobile_idx), self.M, self.frame0))
+
+    def row_width(self):
+        w = i64(0)
+        self._check(self.lib.sit_row_width(self._h, C.byref(w)))
+        return w.value
+
+    # -- landmark vectors
+    def fill(self, dynamic_lattice_mapping=False, relaxed_lattice_checks=False, check_for_zeros=True,
+             assign=False, predict_threshold=0.0):
+        p = FillParams(int(dynamic_lattice_mapping), int(relaxed_lattice_checks), int(check_for_zeros), 1,
+                       int(assign), 1, float(predict_threshold))
+        nz = i64(0)
+        err = SitError()
+        rc = self.lib.sit_fill(self._h, C.byref(p), C.byref(nz), C.byref(err))
+        return rc, nz.value, err
+
+    def static_seen(self, local_frame):
+        seen = np.zeros(self.S, dtype=np.uint8)
+        self._check(self.lib.sit_static_seen(self._h, int(local_frame), seen.ctypes.data_as(_u8p)))
+        return seen
+
+    def rows_dense(self, row0=0, nrows=None):
+        nrows = self.N - row0 if nrows is None else nrows
+        out = np.empty((nrows, self.D))
+        self._check(self.lib.sit_get_rows_dense(self._h, int(row0), int(nrows), _d(out)))
+        return out
+
+    def rows_sparse(self, row0=0, nrows=None):
+        nrows = self.N - row0 if nrows is None else nrows
+        W = self.row_width()
+        nnz = np.empty(nrows, dtype=np.int32)
+        idx = np.empty((W, nrows), dtype=np.int32)
+        val = np.empty((W, nrows))
+        self._check(self.lib.sit_get_rows_sparse(self._h, int(row0), int(nrows), nnz.ctypes.data_as(_i32p),
+                                                 idx.ctypes.data_as(_i32p), _d(val)))
+        return nnz, idx, val
+
+    def set_rows_dense(self, X):
+        X = _f64(X)
+        assert X.ndim == 2
+        self._check(self.lib.sit_set_rows_dense(self._h, _d(X), X.shape[0], X.shape[1]))
+        self.N, self.D = X.shape
+
+    # -- DotProdClassifier
+    def fit_reset(self):
+        self._check(self.lib.sit_fit_reset(self._h))
+
+    def fit_set_state(self, centers, counts):
+        centers = _f64(centers).reshape(-1, self.D)
+        counts = _i64(counts)
+        self._check(self.lib.sit_fit_set_state(self._h, _d(centers), _i(counts), len(centers)))
+
+    def fit_get_state(self):
+        K = i64(0)
+        self._check(self.lib.sit_fit_get_state(self._h, None, None, C.byref(K)))
+        centers = np.empty((K.value, self.D))
+        counts = np.empty(K.value, dtype=np.int64)
+        if K.value:
+            self._check(self.lib.sit_fit_get_state(self._h, _d(centers), _i(counts), C.byref(K)))
+        return centers, counts
+
+    def fit_push_stored_rows(self, threshold):
+        self._check(self.lib.sit_fit_push_stored_rows(self._h, float(threshold)))
+
+    def fit_push_dense_rows(self, rows, weights, threshold):
+        rows = _f64(rows).reshape(-1, self.D)
+        weights = _i64(weights)
+        self._check(self.lib.sit_fit_push_dense_rows(self._h, _d(rows), _i(weights), len(rows), float(threshold)))
+
+    def set_centers(self, matrix, normed):
+        matrix = _f64(matrix).reshape(-1, self.D)
+        self.K = len(matrix)
+        self._check(self.lib.sit_set_centers(self._h, _d(matrix), self.K, int(bool(normed))))
+
+    def predict(self, threshold, fetch=True):
+        counts = np.zeros(self.K, dtype=np.int64)
+        if fetch:
+            labels = np.empty(self.N, dtype=np.int64)
+            confs = np.empty(self.N)
+            self._check(self.lib.sit_predict(self._h, float(threshold), _i(labels), _d(confs), _i(counts)))
+            return labels, confs, counts
+        self._check(self.lib.sit_predict(self._h, float(threshold), None, None, _i(counts)))
+        return None, None, counts
+
+    def assignments(self):
+        labels = np.empty(self.N, dtype=np.int64)
+        confs = np.empty(self.N)
+        counts = np.zeros(self.K, dtype=np.int64)
+        self._check(self.lib.sit_get_assignments(self._h, _i(labels), _d(confs), _i(counts)))
+        return labels, confs, counts
+
+    # -- mcl support
+    def gram(self):
+        G = np.empty((self.D, self.D))
+        seen = np.empty(self.D, dtype=np.int64)
+        self._check(self.lib.sit_gram(self._h, _d(G), _i(seen)))
+        return G, seen
+
+    def best_match(self, c):
+        c = _f64(c)
+        row = i64(0)
+        dot = C.c_double(0)
+        nrm = C.c_double(0)
+        self._check(self.lib.sit_best_match(self._h, _d(c), C.byref(row), C.byref(dot), C.byref(nrm)))
+        return row.value, dot.value, nrm.value
+
+    def weighted_row_sums(self, K, weighted=True):
+        sums = np.empty((K, self.D))
+        wsum = np.empty(K)
+        self._check(self.lib.sit_weighted_row_sums(self._h, int(weighted), int(K), _d(sums), _d(wsum)))
+        return sums, wsum
+
+    # -- site centres / occupancy
+    def site_anchors(self, K, weighted):
+        wmax = np.empty(K)
+        first = np.empty(K, dtype=np.int64)
+        pts = np.empty((K, 3))
+        self._check(self.lib.sit_site_anchors(self._h, int(weighted), int(K), _d(wmax), _i(first), _d(pts)))
+        return wmax, first, pts
+
+    def site_sums(self, K, weighted, anchors):
+        anchors = _f64(anchors)
+        sums = np.empty((K, 4))
+        self._check(self.lib.sit_site_sums(self._h, int(weighted), int(K), _d(anchors), _d(sums)))
+        return sums
+
+    def check_occupancy(self, K, max_per_site):
+        a, b, c = i64(0), i64(0), i64(0)
+        err = SitError()
+        rc = self.lib.sit_check_occupancy(self._h, int(K), int(max_per_site), C.byref(a), C.byref(b), C.byref(c),
+                                          C.byref(err))
+        return rc, a.value, b.value, c.value, err
+
+    def set_assignments(self, labels, confs=None, frame0=0):
+        labels = _i64(labels)
+        F, M = labels.shape
+        c = None if confs is None else _f64(confs)
+        self._check(self.lib.sit_set_assignments(self._h, _i(labels), None if c is None else _d(c), F, M, int(frame0)))
+        self.F, self.M, self.N, self.frame0 = F, M, F * M, int(frame0)
+
+    JUMP_NONE = -(1 << 63)
+
+    def jump_sources(self, unknown_as_jump=False, last_known_in=None):
+        src = np.empty((self.F, self.M), dtype=np.int64)
+        last_out = np.empty(self.M, dtype=np.int64)
+        lin = None if last_known_in is None else _i64(last_known_in)
+        self._check(self.lib.sit_jump_sources(self._h, int(unknown_as_jump), None if lin is None else _i(lin),
+                                              _i(src), _i(last_out)))
+        return src, last_out
+
+    def timers(self):
+        t = np.zeros(8)
+        self.lib.sit_timers(self._h, _d(t), 8)
+        return dict(zip(["fill", "fit", "predict", "gram", "site_centers", "occupancy", "h2d"], t))
+
+    def synchronize(self):
+        self._check(self.lib.sit_synchronize(self._h))

@@ -1,0 +1,113 @@
+"""Plugin ``"mcl"``: Markov clustering of the *landmarks* by their co-occurrence, then assignment of
+every landmark vector to the landmark groups (reference ``sitator/landmark/cluster/mcl.py:43-131``).
+
+GPU side: the Gram matrix ``X^T X`` and per-landmark hit counts (one pass over the sparse rows),
+the best-matching sample of each group (argmax reduction), both assignment passes and the
+confidence-weighted representative vectors.  Host side: the D x D correlation graph, Markov
+clustering and ``eigsh`` on the (small) per-group blocks - third-party math the reference uses too.
+
+Valid ``clustering_params``: ``assignment_threshold``, ``good_site_normed_threshold``,
+``good_site_projected_threshold``; everything else goes to ``markov_clustering``.
+"""
+import logging
+
+import numpy as np
+
+from ..dotprod_classifier import DotProdClassifier, LandmarkVectors, _as_device_rows
+from ..markov import markov_clustering
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_PARAMS = {
+    "inflation": 4,
+    "assignment_threshold": 0.7,
+}
+
+
+def cov2corr(A):
+    """Covariance -> correlation; zero-variance rows/columns correlate with nothing."""
+    d = np.sqrt(A.diagonal())
+    d[d == 0] = np.inf
+    return ((A.T / d).T) / d
+
+
+def _global_best_match(X, center):
+    """argmax_n |X[n] . center| over all ranks: (|dot|, norm of that row) (:80-87)."""
+    row, dot, nrm = X.ctx.best_match(center)
+    if X.comm.size > 1:
+        grow = row + X.ctx.frame0 * X.ctx.M
+        allv = X.comm.allgather(np.array([dot, float(grow), nrm]))
+        best = 0
+        for r in range(1, X.comm.size):          # ranks are in row order: first maximum / first NaN
+            if np.isnan(allv[best, 0]):
+                break
+            if np.isnan(allv[r, 0]) or allv[r, 0] > allv[best, 0]:
+                best = r
+        dot, nrm = allv[best, 0], allv[best, 2]
+    return dot, nrm
+
+
+def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, verbose):
+    from scipy.sparse.linalg import eigsh
+    params = dict(DEFAULT_PARAMS)
+    params.update(clustering_params)
+    X = _as_device_rows(landmark_vectors)
+    comm = X.comm
+    n_lmk = X.shape[1]
+
+    gram, seen_ntimes = X.ctx.gram()                                   # :54-55
+    n_rows = X.shape[0]
+    if comm.size > 1:
+        gram = comm.allreduce_sum(gram)
+        seen_ntimes = comm.allreduce_sum(seen_ntimes)
+        n_rows = int(comm.allreduce_sum(np.array([n_rows], dtype=np.int64))[0])
+    cov = gram / n_rows
+    graph = np.clip(cov2corr(cov), 0, None)
+    for i in range(n_lmk):
+        if graph[i, i] == 0:          # landmark never seen: needs a self loop for MCL
+            graph[i, i] = 1
+
+    predict_threshold = params.pop("assignment_threshold")
+    good_site_normed_threshold = params.pop("good_site_normed_threshold", predict_threshold)
+    good_site_project_thresh = params.pop("good_site_projected_threshold", predict_threshold)
+
+    groups = markov_clustering(graph, **params)                        # :67
+    groups = [list(g) for g in groups if seen_ntimes[g[0]] > 0]        # :69
+    centers = np.zeros((len(groups), n_lmk))
+    good = np.zeros(len(groups), dtype=bool)
+    for i, group in enumerate(groups):
+        if len(group) == 1:
+            centers[i, group] = 1.0
+        else:
+            _, vec = eigsh(cov[group][:, group], k=1)                  # :78
+            centers[i, group] = vec.T
+        best_dot, best_norm = _global_best_match(X, centers[i])
+        good[i] = (best_dot / best_norm >= good_site_normed_threshold) and (best_dot >= good_site_project_thresh)
+        centers[i] /= best_dot
+    logger.debug("Kept %i/%i landmark clusters as good sites" % (np.sum(good), len(good)))
+
+    groups = [g for i, g in enumerate(groups) if good[i]]
+    centers = centers[good]
+
+    clf = DotProdClassifier(threshold=np.nan, min_samples=min_samples)   # not fitting
+    clf.set_cluster_centers(centers)
+    labels, confs, info = clf.fit_predict(X, predict_threshold=predict_threshold, predict_normed=False,
+                                          verbose=verbose, return_info=True)
+    kept = info["kept_clusters_mask"]
+    groups = [g for i, g in enumerate(groups) if kept[i]]
+
+    # representative landmark vector of each site: confidence-weighted mean of its rows (:114-122)
+    weighted = params.get("weighted_representative_landmarks", True)
+    sums, wsum = X.ctx.weighted_row_sums(len(groups), weighted=weighted)
+    if comm.size > 1:
+        sums = comm.allreduce_sum(sums)
+        wsum = comm.allreduce_sum(wsum)
+    reps = sums / wsum[:, np.newaxis]
+
+    return {
+        "cluster-size": clf.cluster_counts,
+        "cluster-labels": labels,
+        "cluster-confs": confs,
+        "cluster-landmark-groupings": groups,
+        "cluster-representative-lvecs": reps,
+    }

@@ -1,0 +1,683 @@
+// DotProdClassifier on the device (util/DotProdClassifier.pyx) and the reductions the mcl
+// plugin needs (landmark/cluster/mcl.py), all over the sparse landmark rows.
+#include <cmath>
+#include <cstring>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "sit_internal.h"
+
+// ---- a (value, index) maximum with numpy's argmax rules: first maximum, first NaN wins ----
+struct Best {
+    double v;
+    i64 i;       // -1 = empty
+    int nan;
+};
+
+__device__ __forceinline__ Best best_empty() { Best b; b.v = 0; b.i = -1; b.nan = 0; return b; }
+
+__device__ __forceinline__ Best best_merge(const Best &a, const Best &b)
+{
+    if (a.i < 0) return b;
+    if (b.i < 0) return a;
+    if (a.nan || b.nan) {
+        if (a.nan && b.nan) return a.i < b.i ? a : b;
+        return a.nan ? a : b;
+    }
+    if (a.v > b.v) return a;
+    if (b.v > a.v) return b;
+    return a.i < b.i ? a : b;
+}
+
+__device__ __forceinline__ Best best_of(double v, i64 i)
+{
+    Best b; b.v = v; b.i = i; b.nan = isnan(v) ? 1 : 0; return b;
+}
+
+__device__ __forceinline__ Best wave_best(Best b)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.v = __shfl_down(b.v, off);
+        o.i = __shfl_down(b.i, off);
+        o.nan = __shfl_down(b.nan, off);
+        b = best_merge(b, o);
+    }
+    return b;
+}
+
+// ---- predict (util/DotProdClassifier.pyx:129-197) over sparse rows --------------------------
+//
+// One lane per row.  The dense product normed_centres . x is accumulated only over centres that
+// share a non-zero dimension with the row (all others are exactly 0): for every row entry (d, v)
+// in ascending d, the CSC column of d lists (centre, value).  Per-lane accumulators live in an
+// LDS table [TCAP][blockDim]; a row touching more than TCAP centres raises the overflow flag and
+// the launch is redone by the dense fallback.
+#define PRED_TCAP 24
+#define PRED_BLOCK 128
+
+struct PredArgs {
+    const i32 *row_nnz, *row_idx;
+    const double *row_val;
+    const i32 *col_ptr, *col_k;
+    const double *col_val;
+    const double *dense;     // [K,D] (fallback only)
+    i64 *labels;
+    double *confs;
+    u64 *counts;             // [K]
+    u64 *overflow;
+    i64 N, K, D;
+    int normed;
+    double threshold;
+};
+
+// b = numpy argmax of |normed_centres . x| (/ |x|) over the centres that overlap the row; every
+// other centre scores exactly 0, so when nothing beats 0 the dense argmax is index 0.
+__device__ __forceinline__ void finish_predict(const PredArgs &a, i64 row, Best b)
+{
+    i64 to; double conf;
+    if (b.i < 0 || (!b.nan && b.v == 0.0)) { to = 0; conf = 0.0; }
+    else { to = b.i; conf = b.v; }
+    if (conf < a.threshold) { to = -1; conf = 0.0; }                  // :184-186 (NaN: false)
+    a.labels[row] = to;
+    a.confs[row] = conf;
+    if (to >= 0) atomicAdd(&a.counts[to], 1ull);
+}
+
+__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a)
+{
+    __shared__ i32 tk[PRED_TCAP][PRED_BLOCK];
+    __shared__ double tv[PRED_TCAP][PRED_BLOCK];
+    const i64 row = (i64)blockIdx.x * PRED_BLOCK + threadIdx.x;
+    if (row >= a.N) return;
+    const int n = a.row_nnz[row];
+    if (n == 0) { a.labels[row] = -1; a.confs[row] = 0.0; return; }   // :168-172 (conf uninitialised there)
+    const int t = threadIdx.x;
+    int used = 0;
+    double x2 = 0.0;
+    bool over = false;
+    for (int e = 0; e < n; e++) {
+        const i32 d = a.row_idx[(i64)e * a.N + row];
+        const double v = a.row_val[(i64)e * a.N + row];
+        x2 += v * v;
+        const i32 lo = a.col_ptr[d], hi = a.col_ptr[d + 1];
+        for (i32 q = lo; q < hi; q++) {
+            const i32 k = a.col_k[q];
+            const double term = a.col_val[q] * v;
+            int s = 0;
+            while (s < used && tk[s][t] != k) s++;
+            if (s == used) {
+                if (used == PRED_TCAP) { over = true; break; }
+                tk[used][t] = k; tv[used][t] = term; used++;
+            } else {
+                tv[s][t] += term;
+            }
+        }
+        if (over) break;
+    }
+    if (over) { atomicAdd(a.overflow, 1ull); return; }
+    const double xn = sqrt(x2);
+    Best b = best_empty();
+    for (int s = 0; s < used; s++) {
+        double v = tv[s][t];
+        if (a.normed) v /= xn;                                         // :177-178
+        b = best_merge(b, best_of(fabs(v), tk[s][t]));                 // :179
+    }
+    finish_predict(a, row, b);
+}
+
+// Dense fallback: every centre, sparse row against the dense (normalised) centre matrix.
+__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_dense(PredArgs a)
+{
+    const i64 row = (i64)blockIdx.x * PRED_BLOCK + threadIdx.x;
+    if (row >= a.N) return;
+    const int n = a.row_nnz[row];
+    if (n == 0) { a.labels[row] = -1; a.confs[row] = 0.0; return; }
+    double x2 = 0.0;
+    for (int e = 0; e < n; e++) { const double v = a.row_val[(i64)e * a.N + row]; x2 += v * v; }
+    const double xn = sqrt(x2);
+    Best b = best_empty();
+    for (i64 k = 0; k < a.K; k++) {
+        double dot = 0.0;
+        for (int e = 0; e < n; e++)
+            dot += a.dense[k * a.D + a.row_idx[(i64)e * a.N + row]] * a.row_val[(i64)e * a.N + row];
+        if (a.normed) dot /= xn;
+        b = best_merge(b, best_of(fabs(dot), k));
+    }
+    finish_predict(a, row, b);
+}
+
+extern "C" int sit_set_centers(sit_ctx *c, const double *centers, i64 K, int normed)
+{
+    if (!c || !centers) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->D > 0 && K > 0, "sit_set_centers: basis must be set and K > 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 D = c->D;
+    std::vector<i32> ptr((size_t)D + 1, 0), ks;
+    std::vector<double> vals;
+    for (i64 d = 0; d < D; d++) {
+        ptr[(size_t)d] = (i32)ks.size();
+        for (i64 k = 0; k < K; k++) {
+            const double v = centers[k * D + d];
+            if (v != 0.0) { ks.push_back((i32)k); vals.push_back(v); }   // NaN != 0 is kept
+        }
+    }
+    ptr[(size_t)D] = (i32)ks.size();
+    if (ks.empty()) { ks.push_back(0); vals.push_back(0.0); }
+    int rc;
+    if ((rc = dev_upload(c, &c->d_col_ptr, ptr.data(), D + 1))) return rc;
+    if ((rc = dev_upload(c, &c->d_col_k, ks.data(), (i64)ks.size()))) return rc;
+    if ((rc = dev_upload(c, &c->d_col_val, vals.data(), (i64)vals.size()))) return rc;
+    c->K = K; c->centers_normed = normed;
+    if ((rc = dev_alloc(c, &c->d_counts, K))) return rc;
+    if ((rc = dev_upload(c, &c->d_cen_dense, centers, K * D))) return rc;   // dense fallback
+    c->assign_valid = false;
+    return SIT_OK;
+}
+
+static int run_predict(sit_ctx *c, double threshold)
+{
+    SIT_REQUIRE(c, c->rows_valid, "predict: no landmark rows on the device (run sit_fill with store_rows)");
+    SIT_REQUIRE(c, c->K > 0 && c->d_col_ptr, "predict: no centres set");
+    int rc;
+    if (!c->d_labels || c->assign_N != c->N) {
+        if ((rc = dev_alloc(c, &c->d_labels, c->N))) return rc;
+        if ((rc = dev_alloc(c, &c->d_confs, c->N))) return rc;
+        c->assign_N = c->N;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream));
+    if (c->N == 0) { c->assign_valid = true; return SIT_OK; }
+    PredArgs a;
+    a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx; a.row_val = c->d_row_val;
+    a.col_ptr = c->d_col_ptr; a.col_k = c->d_col_k; a.col_val = c->d_col_val; a.dense = c->d_cen_dense;
+    a.labels = c->d_labels; a.confs = c->d_confs; a.counts = (u64 *)c->d_counts; a.overflow = c->d_scal + 1;
+    a.N = c->N; a.K = c->K; a.D = c->D; a.normed = c->centers_normed; a.threshold = threshold;
+    const unsigned grid = (unsigned)((c->N + PRED_BLOCK - 1) / PRED_BLOCK);
+    StageTimer t(c, T_PREDICT);
+    k_predict_rows<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
+    HIP_TRY(c, hipGetLastError());
+    u64 over = 0;
+    HIP_TRY(c, hipMemcpyAsync(&over, c->d_scal + 1, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (over) {
+        HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
+        k_predict_rows_dense<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
+        HIP_TRY(c, hipGetLastError());
+    }
+    t.stop();
+    c->assign_valid = true;
+    return SIT_OK;
+}
+
+int sit_predict_internal(sit_ctx *c, double threshold) { return run_predict(c, threshold); }
+
+extern "C" int sit_get_assignments(sit_ctx *c, i64 *labels, double *confs, i64 *counts)
+{
+    if (!c) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->assign_valid, "no assignments on the device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (labels && c->N) HIP_TRY(c, hipMemcpyAsync(labels, c->d_labels, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (confs && c->N) HIP_TRY(c, hipMemcpyAsync(confs, c->d_confs, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (counts) HIP_TRY(c, hipMemcpyAsync(counts, c->d_counts, (size_t)c->K * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+extern "C" int sit_predict(sit_ctx *c, double threshold, i64 *labels, double *confs, i64 *counts)
+{
+    if (!c) return SIT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = run_predict(c, threshold);
+    if (rc) return rc;
+    return sit_get_assignments(c, labels, confs, counts);
+}
+
+// ---- fit_centers (util/DotProdClassifier.pyx:199-315): exact ordered stream -----------------
+//
+// One persistent workgroup owns the clustering state (dense centres [cap,D], norms, counts in
+// global memory / L2) and consumes rows strictly in order, because every decision depends on the
+// centres as updated by all earlier rows.  Per row: all lanes share the row through
+// LDS, each lane scores centres k = lane, lane+T, ... (sparse row . dense centre, in ascending
+// dimension order), a (value, index) reduction applies numpy's argmax rules, then either a new
+// centre is founded (:250-260) or the running mean is updated over all D dimensions (:283-288).
+#define FIT_T 512
+
+struct FitArgs {
+    const i32 *row_nnz, *row_idx;
+    const double *row_val;
+    const i64 *weights;      // null => 1
+    i64 stride;              // slot stride of the row arrays
+    i64 row_begin, row_end;
+    i64 D, cap;
+    double threshold;
+    double *cen, *nrm;
+    i64 *cnt, *Kp;
+    i64 *status;             // [0] = 0 ok / 1 capacity, [1] = first unprocessed row
+};
+
+__global__ __launch_bounds__(FIT_T) void k_fit_stream(FitArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *xd = (double *)smem;                       // [D] dense copy of the current row
+    double *ev = xd + a.D;                             // [D] entry values (dense rows: up to D)
+    i32 *ei = (i32 *)(ev + a.D);                       // [D] entry indices
+    __shared__ double r_v[FIT_T / 64];
+    __shared__ i64 r_i[FIT_T / 64];
+    __shared__ int r_n[FIT_T / 64];
+    __shared__ double r_s[FIT_T / 64];
+    __shared__ i64 sK;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (i64 d = t; d < a.D; d += FIT_T) xd[d] = 0.0;
+    if (t == 0) sK = *a.Kp;
+    __syncthreads();
+    i64 K = sK;
+    i64 row = a.row_begin;
+    for (; row < a.row_end; row++) {
+        const int n = a.row_nnz[row];
+        for (int e = t; e < n; e += FIT_T) {
+            const i32 d = a.row_idx[(i64)e * a.stride + row];
+            const double v = a.row_val[(i64)e * a.stride + row];
+            ei[e] = d; ev[e] = v; xd[d] = v;
+        }
+        __syncthreads();
+        const i64 w = a.weights ? a.weights[row] : 1;
+        double x2 = 0.0;
+        for (int e = 0; e < n; e++) x2 += ev[e] * ev[e];
+        const double vn = sqrt(x2);
+        i64 to = -1;
+        if (K > 0) {
+            Best b = best_empty();
+            for (i64 k = t; k < K; k += FIT_T) {
+                const double *ck = a.cen + k * a.D;
+                double dot = 0.0;
+                for (int e = 0; e < n; e++) dot += ck[ei[e]] * ev[e];
+                dot /= a.nrm[k];                                          // :239
+                dot /= vn;                                                // :240
+                b = best_merge(b, best_of(dot, k));
+            }
+            b = wave_best(b);
+            if (lane == 0) { r_v[wave] = b.v; r_i[wave] = b.i; r_n[wave] = b.nan; }
+            __syncthreads();
+            Best g = best_empty();
+            for (int q = 0; q < FIT_T / 64; q++) {
+                Best o; o.v = r_v[q]; o.i = r_i[q]; o.nan = r_n[q];
+                g = best_merge(g, o);
+            }
+            to = g.i;
+            if (g.v < a.threshold) to = -1;                               // :245-247 (NaN: false)
+        }
+        if (to < 0) {                                                     // :250-260
+            if (K == a.cap) break;                                        // uniform: K, cap are uniform
+            double *ck = a.cen + K * a.D;
+            for (i64 d = t; d < a.D; d += FIT_T) ck[d] = xd[d];
+            if (t == 0) { a.nrm[K] = vn; a.cnt[K] = w; }
+            K++;
+        } else {                                                          // :283-288
+            double *ck = a.cen + to * a.D;
+            const i64 nold = a.cnt[to];
+            const double fo = (double)nold, fn = (double)(nold + w);
+            double s = 0.0;
+            for (i64 d = t; d < a.D; d += FIT_T) {
+                double cv = ck[d];
+                cv *= fo; cv += xd[d]; cv /= fn;
+                ck[d] = cv;
+                s += cv * cv;
+            }
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+            __syncthreads();           // every lane has read cnt[to] / r_* before they are rewritten
+            if (lane == 0) r_s[wave] = s;
+            __syncthreads();
+            if (t == 0) {
+                double tot = 0.0;
+                for (int q = 0; q < FIT_T / 64; q++) tot += r_s[q];
+                a.nrm[to] = sqrt(tot);
+                a.cnt[to] = nold + w;
+            }
+        }
+        for (int e = t; e < n; e += FIT_T) xd[ei[e]] = 0.0;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (t == 0) {
+        *a.Kp = K;
+        a.status[0] = (row < a.row_end) ? 1 : 0;
+        a.status[1] = row;
+    }
+}
+
+static int fit_ensure(sit_ctx *c, i64 cap)
+{
+    if (c->fit_cap >= cap && c->d_fit_centers) return SIT_OK;
+    double *ncen = nullptr, *nnrm = nullptr;
+    i64 *ncnt = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&ncen, (size_t)(cap * c->D) * 8));
+    HIP_TRY(c, hipMalloc((void **)&nnrm, (size_t)cap * 8));
+    HIP_TRY(c, hipMalloc((void **)&ncnt, (size_t)cap * 8));
+    if (c->fit_K > 0 && c->d_fit_centers && c->fit_cap > 0) {
+        HIP_TRY(c, hipMemcpyAsync(ncen, c->d_fit_centers, (size_t)(c->fit_K * c->D) * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(nnrm, c->d_fit_nrm2, (size_t)c->fit_K * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(ncnt, c->d_fit_counts, (size_t)c->fit_K * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (c->d_fit_centers) (void)hipFree(c->d_fit_centers);
+    if (c->d_fit_nrm2) (void)hipFree(c->d_fit_nrm2);
+    if (c->d_fit_counts) (void)hipFree(c->d_fit_counts);
+    c->d_fit_centers = ncen; c->d_fit_nrm2 = nnrm; c->d_fit_counts = ncnt; c->fit_cap = cap;
+    return SIT_OK;
+}
+
+extern "C" int sit_fit_reset(sit_ctx *c)
+{
+    if (!c) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->D > 0, "sit_fit_reset: basis must be set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->fit_K = 0;
+    HIP_TRY(c, hipMemsetAsync(c->d_fit_K, 0, 8, c->stream));
+    return fit_ensure(c, 256);
+}
+
+__global__ void k_row_norms(const double *cen, i64 K, i64 D, double *nrm)
+{
+    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double s = 0.0;
+    for (i64 d = 0; d < D; d++) s += cen[k * D + d] * cen[k * D + d];
+    nrm[k] = sqrt(s);
+}
+
+extern "C" int sit_fit_set_state(sit_ctx *c, const double *centers, const i64 *counts, i64 K)
+{
+    if (!c || (K > 0 && (!centers || !counts))) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->D > 0, "sit_fit_set_state: basis must be set");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->fit_K = 0;
+    int rc = fit_ensure(c, K + 256);
+    if (rc) return rc;
+    if (K > 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_fit_centers, centers, (size_t)(K * c->D) * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_fit_counts, counts, (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
+        k_row_norms<<<dim3((unsigned)((K + 63) / 64)), dim3(64), 0, c->stream>>>(c->d_fit_centers, K, c->D, c->d_fit_nrm2);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_fit_K, &K, 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->fit_K = K;
+    return SIT_OK;
+}
+
+extern "C" int sit_fit_get_state(sit_ctx *c, double *centers, i64 *counts, i64 *K)
+{
+    if (!c || !K) return SIT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    *K = c->fit_K;
+    if (c->fit_K > 0) {
+        if (centers) HIP_TRY(c, hipMemcpyAsync(centers, c->d_fit_centers, (size_t)(c->fit_K * c->D) * 8, hipMemcpyDeviceToHost, c->stream));
+        if (counts) HIP_TRY(c, hipMemcpyAsync(counts, c->d_fit_counts, (size_t)c->fit_K * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return SIT_OK;
+}
+
+static int fit_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val, const i64 *weights,
+                      i64 stride, i64 nrows, double threshold)
+{
+    int rc;
+    if (!c->d_fit_centers && (rc = fit_ensure(c, 256))) return rc;
+    if ((rc = ensure_scratch(c, 64))) return rc;
+    const size_t lds = (size_t)c->D * 20 + 16;
+    SIT_REQUIRE(c, lds <= 150 * 1024, "fit: landmark dimension too large for the LDS-resident row");
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k_fit_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    i64 *status = (i64 *)c->d_scal + 4;
+    i64 begin = 0;
+    const i64 chunk = 1 << 20;
+    while (begin < nrows) {
+        FitArgs a;
+        a.row_nnz = nnz; a.row_idx = idx; a.row_val = val; a.weights = weights; a.stride = stride;
+        a.row_begin = begin; a.row_end = begin + chunk < nrows ? begin + chunk : nrows;
+        a.D = c->D; a.cap = c->fit_cap; a.threshold = threshold;
+        a.cen = c->d_fit_centers; a.nrm = c->d_fit_nrm2; a.cnt = c->d_fit_counts; a.Kp = c->d_fit_K; a.status = status;
+        k_fit_stream<<<dim3(1), dim3(FIT_T), lds, c->stream>>>(a);
+        HIP_TRY(c, hipGetLastError());
+        i64 h[2] = {0, 0}, hK = 0;
+        HIP_TRY(c, hipMemcpyAsync(h, status, 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&hK, c->d_fit_K, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->fit_K = hK;
+        begin = h[1];
+        if (h[0] == 1) {   // capacity reached: grow and resume at the same row
+            SIT_REQUIRE(c, c->fit_cap < (1 << 20), "fit: more than 2^20 clusters");
+            if ((rc = fit_ensure(c, c->fit_cap * 2))) return rc;
+        }
+    }
+    return SIT_OK;
+}
+
+extern "C" int sit_fit_push_stored_rows(sit_ctx *c, double threshold)
+{
+    if (!c) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->rows_valid, "sit_fit_push_stored_rows: no landmark rows on the device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    StageTimer t(c, T_FIT);
+    int rc = fit_stream(c, c->d_row_nnz, c->d_row_idx, c->d_row_val, nullptr, c->N, c->N, threshold);
+    t.stop();
+    return rc;
+}
+
+extern "C" int sit_fit_push_dense_rows(sit_ctx *c, const double *rows, const i64 *weights, i64 nrows, double threshold)
+{
+    if (!c || !rows) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->D > 0 && nrows >= 0, "sit_fit_push_dense_rows: bad arguments");
+    if (nrows == 0) return SIT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 D = c->D;
+    // sparse, slot-major with stride nrows and width D (zeros dropped: x + 0 == x)
+    std::vector<i32> nnz((size_t)nrows, 0), idx((size_t)(nrows * D), 0);
+    std::vector<double> val((size_t)(nrows * D), 0.0);
+    for (i64 r = 0; r < nrows; r++) {
+        int n = 0;
+        for (i64 d = 0; d < D; d++) {
+            const double v = rows[r * D + d];
+            if (v != 0.0) { idx[(size_t)((i64)n * nrows + r)] = (i32)d; val[(size_t)((i64)n * nrows + r)] = v; n++; }
+        }
+        nnz[(size_t)r] = n;
+    }
+    i32 *dn = nullptr, *di = nullptr; double *dv = nullptr; i64 *dw = nullptr;
+    int rc;
+    if ((rc = dev_upload(c, &dn, nnz.data(), nrows))) return rc;
+    if ((rc = dev_upload(c, &di, idx.data(), nrows * D))) return rc;
+    if ((rc = dev_upload(c, &dv, val.data(), nrows * D))) return rc;
+    if (weights && (rc = dev_upload(c, &dw, weights, nrows))) return rc;
+    StageTimer t(c, T_FIT);
+    rc = fit_stream(c, dn, di, dv, dw, nrows, nrows, threshold);
+    t.stop();
+    (void)hipFree(dn); (void)hipFree(di); (void)hipFree(dv); if (dw) (void)hipFree(dw);
+    return rc;
+}
+
+// ---- mcl plugin reductions (landmark/cluster/mcl.py:53-59, :80-83, :114-122) ----------------
+
+__global__ void k_gram(const i32 *nnz, const i32 *idx, const double *val, i64 N, i64 D, double *G, u64 *seen)
+{
+    const i64 row = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N) return;
+    const int n = nnz[row];
+    for (int e1 = 0; e1 < n; e1++) {
+        const i32 d1 = idx[(i64)e1 * N + row];
+        const double v1 = val[(i64)e1 * N + row];
+        atomicAdd(&seen[d1], 1ull);
+        for (int e2 = 0; e2 < n; e2++)
+            unsafeAtomicAdd(&G[(i64)d1 * D + idx[(i64)e2 * N + row]], v1 * val[(i64)e2 * N + row]);
+    }
+}
+
+extern "C" int sit_gram(sit_ctx *c, double *G, i64 *seen)
+{
+    if (!c || !G || !seen) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->rows_valid, "sit_gram: no landmark rows on the device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 D = c->D;
+    int rc = ensure_scratch(c, D * D * 8 + D * 8);
+    if (rc) return rc;
+    double *dG = (double *)c->d_scratch;
+    u64 *ds = (u64 *)(dG + D * D);
+    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(D * D * 8 + D * 8), c->stream));
+    StageTimer t(c, T_GRAM);
+    if (c->N > 0) {
+        k_gram<<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dG, ds);
+        HIP_TRY(c, hipGetLastError());
+    }
+    t.stop();
+    HIP_TRY(c, hipMemcpyAsync(G, dG, (size_t)(D * D) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(seen, ds, (size_t)D * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+// per block: argmax over its rows of |X[n] . cvec| with numpy's rules
+__global__ __launch_bounds__(256) void k_best_match(const i32 *nnz, const i32 *idx, const double *val, i64 N,
+                                                    const double *cvec, double *bv, i64 *bi, int *bn)
+{
+    __shared__ double r_v[4];
+    __shared__ i64 r_i[4];
+    __shared__ int r_n[4];
+    const i64 row = (i64)blockIdx.x * 256 + threadIdx.x;
+    Best b = best_empty();
+    if (row < N) {
+        const int n = nnz[row];
+        double dot = 0.0;
+        for (int e = 0; e < n; e++) dot += val[(i64)e * N + row] * cvec[idx[(i64)e * N + row]];
+        b = best_of(fabs(dot), row);
+    }
+    b = wave_best(b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { r_v[wave] = b.v; r_i[wave] = b.i; r_n[wave] = b.nan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Best g = best_empty();
+        for (int q = 0; q < 4; q++) { Best o; o.v = r_v[q]; o.i = r_i[q]; o.nan = r_n[q]; g = best_merge(g, o); }
+        bv[blockIdx.x] = g.v; bi[blockIdx.x] = g.i; bn[blockIdx.x] = g.nan;
+    }
+}
+
+__global__ void k_row_dot_norm(const i32 *nnz, const i32 *idx, const double *val, i64 N, i64 row,
+                               const double *cvec, double *out2)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const int n = nnz[row];
+    double dot = 0.0, x2 = 0.0;
+    for (int e = 0; e < n; e++) {
+        const double v = val[(i64)e * N + row];
+        dot += v * cvec[idx[(i64)e * N + row]];
+        x2 += v * v;
+    }
+    out2[0] = fabs(dot);
+    out2[1] = sqrt(x2);
+}
+
+extern "C" int sit_best_match(sit_ctx *c, const double *cvec, i64 *row_out, double *dot, double *norm)
+{
+    if (!c || !cvec || !row_out || !dot || !norm) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->rows_valid && c->N > 0, "sit_best_match: no landmark rows on the device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 nb = (c->N + 255) / 256;
+    int rc = ensure_scratch(c, c->D * 8 + nb * 24 + 64);
+    if (rc) return rc;
+    double *dc = (double *)c->d_scratch;
+    double *bv = dc + c->D;
+    i64 *bi = (i64 *)(bv + nb);
+    int *bn = (int *)(bi + nb);
+    double *out2 = (double *)(bn + nb + (nb & 1));
+    HIP_TRY(c, hipMemcpyAsync(dc, cvec, (size_t)c->D * 8, hipMemcpyHostToDevice, c->stream));
+    k_best_match<<<dim3((unsigned)nb), dim3(256), 0, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, dc, bv, bi, bn);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<double> hv((size_t)nb);
+    std::vector<i64> hi((size_t)nb);
+    std::vector<int> hn((size_t)nb);
+    HIP_TRY(c, hipMemcpyAsync(hv.data(), bv, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hi.data(), bi, (size_t)nb * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hn.data(), bn, (size_t)nb * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    i64 best = -1;
+    for (i64 b = 0; b < nb; b++) {       // blocks are in row order: first maximum / first NaN
+        if (hi[(size_t)b] < 0) continue;
+        if (best < 0) { best = b; continue; }
+        if (hn[(size_t)best]) break;
+        if (hn[(size_t)b]) { best = b; break; }
+        if (hv[(size_t)b] > hv[(size_t)best]) best = b;
+    }
+    *row_out = hi[(size_t)best];
+    k_row_dot_norm<<<dim3(1), dim3(64), 0, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, *row_out, dc, out2);
+    HIP_TRY(c, hipGetLastError());
+    double h2[2];
+    HIP_TRY(c, hipMemcpyAsync(h2, out2, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *dot = h2[0]; *norm = h2[1];
+    return SIT_OK;
+}
+
+__global__ void k_weighted_row_sums(const i32 *nnz, const i32 *idx, const double *val, const i64 *labels,
+                                    const double *confs, i64 N, i64 D, i64 K, int weighted, double *sums, double *wsum)
+{
+    const i64 row = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N) return;
+    const i64 l = labels[row];
+    if (l < 0 || l >= K) return;
+    const double w = weighted ? confs[row] : 1.0;
+    unsafeAtomicAdd(&wsum[l], w);
+    const int n = nnz[row];
+    for (int e = 0; e < n; e++)
+        unsafeAtomicAdd(&sums[l * D + idx[(i64)e * N + row]], w * val[(i64)e * N + row]);
+}
+
+extern "C" int sit_weighted_row_sums(sit_ctx *c, int weighted, i64 K, double *sums, double *wsum)
+{
+    if (!c || !sums || !wsum) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->rows_valid && c->assign_valid && K > 0, "sit_weighted_row_sums: rows and assignments needed");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 D = c->D;
+    int rc = ensure_scratch(c, (K * D + K) * 8);
+    if (rc) return rc;
+    double *ds = (double *)c->d_scratch, *dw = ds + K * D;
+    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)((K * D + K) * 8), c->stream));
+    if (c->N > 0) {
+        k_weighted_row_sums<<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(
+            c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs, c->N, D, K, weighted, ds, dw);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipMemcpyAsync(sums, ds, (size_t)(K * D) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(wsum, dw, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+// ---- caller-provided dense rows (stand-alone DotProdClassifier) ---------------------------------
+extern "C" int sit_set_rows_dense(sit_ctx *c, const double *rows, i64 N, i64 D)
+{
+    if (!c || (!rows && N > 0)) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, N >= 0 && D > 0 && (c->D == 0 || c->D == D), "sit_set_rows_dense: bad shape");
+    HIP_TRY(c, hipSetDevice(c->device));
+    i64 W = 1;
+    std::vector<i32> nnz((size_t)(N > 0 ? N : 1), 0);
+    for (i64 r = 0; r < N; r++) {
+        int n = 0;
+        for (i64 d = 0; d < D; d++) n += rows[r * D + d] != 0.0;
+        nnz[(size_t)r] = n;
+        if (n > W) W = n;
+    }
+    std::vector<i32> idx((size_t)(N * W > 0 ? N * W : 1), 0);
+    std::vector<double> val((size_t)(N * W > 0 ? N * W : 1), 0.0);
+    for (i64 r = 0; r < N; r++) {
+        i64 e = 0;
+        for (i64 d = 0; d < D; d++) {
+            const double v = rows[r * D + d];
+            if (v != 0.0) { idx[(size_t)(e * N + r)] = (i32)d; val[(size_t)(e * N + r)] = v; e++; }
+        }
+    }
+    int rc;
+    if ((rc = dev_upload(c, &c->d_row_nnz, nnz.data(), N))) return rc;
+    if ((rc = dev_upload(c, &c->d_row_idx, idx.data(), N * W))) return rc;
+    if ((rc = dev_upload(c, &c->d_row_val, val.data(), N * W))) return rc;
+    c->D = D; c->N = N; c->rows_W = W; c->rows_N = N;
+    c->rows_valid = true; c->assign_valid = false;
+    return SIT_OK;
+}

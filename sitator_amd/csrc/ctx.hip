@@ -1,0 +1,267 @@
+// Context, basis / trajectory residency, and the PBCCalculator parity surface.
+#include <cmath>
+#include <cstring>
+
+#include "sit_internal.h"
+
+extern "C" int sit_device_count(int *count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (count) *count = (e == hipSuccess) ? n : 0;
+    return e == hipSuccess ? SIT_OK : SIT_ERR_HIP;
+}
+
+extern "C" int sit_create(const double *cell, const double *cell_inv, int device, sit_ctx **out)
+{
+    if (!cell || !cell_inv || !out) return SIT_ERR_INVALID;
+    sit_ctx *c = new sit_ctx();
+    c->device = device;
+    // util/PBCCalculator.pyx:27-35: cell_mat = cell.T; centroid = sum(0.5 * cell, axis 0)
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) c->pbc.cm[3 * i + j] = cell[3 * j + i];
+    for (int i = 0; i < 9; i++) c->pbc.ci[i] = cell_inv[i];
+    for (int j = 0; j < 3; j++)
+        c->pbc.cen[j] = (0.5 * cell[0 + j] + 0.5 * cell[3 + j]) + 0.5 * cell[6 + j];
+    *out = c;
+    if (hipSetDevice(device) != hipSuccess) { c->msg = "hipSetDevice failed"; return SIT_ERR_HIP; }
+    HIP_TRY(c, hipStreamCreate(&c->stream));
+    HIP_TRY(c, hipEventCreate(&c->ev0));
+    HIP_TRY(c, hipEventCreate(&c->ev1));
+    HIP_TRY(c, hipMalloc((void **)&c->d_err, sizeof(u64)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_scal, sizeof(u64) * 16));
+    HIP_TRY(c, hipMalloc((void **)&c->d_fit_K, sizeof(i64)));
+    return SIT_OK;
+}
+
+extern "C" void sit_destroy(sit_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void *ptrs[] = {c->d_ref_static, c->d_verts, c->d_vcd, c->d_bin_off, c->d_bin_list,
+                    c->frames_owned ? c->d_frames : nullptr, c->d_static_idx, c->d_mobile_idx,
+                    c->d_lattice_map, c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs,
+                    c->d_counts, c->d_col_ptr, c->d_col_k, c->d_col_val, c->d_cen_dense, c->d_fit_centers,
+                    c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scal, c->d_scratch};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char *sit_last_message(sit_ctx *c) { return c ? c->msg.c_str() : "null context"; }
+
+extern "C" int sit_timers(sit_ctx *c, double *ms, int n)
+{
+    if (!c || !ms) return SIT_ERR_INVALID;
+    for (int i = 0; i < n; i++) ms[i] = i < T_N ? c->timers[i] : 0.0;
+    return SIT_OK;
+}
+
+extern "C" int sit_synchronize(sit_ctx *c)
+{
+    if (!c) return SIT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+// ---- PBCCalculator surface ---------------------------------------------------------------
+
+__global__ void k_wrap_points(Pbc P, double *pts, i64 n)
+{
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    wrap3(P, x, y, z);
+    pts[3 * i] = x; pts[3 * i + 1] = y; pts[3 * i + 2] = z;
+}
+
+__global__ void k_distances(Pbc P, double ax, double ay, double az, const double *pts, i64 n, double *out)
+{
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = dist_sw(P, ax, ay, az, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+}
+
+extern "C" int sit_wrap_points(sit_ctx *c, double *pts, i64 n)
+{
+    if (!c || (!pts && n > 0)) return SIT_ERR_INVALID;
+    if (n <= 0) return SIT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, n * 24);
+    if (rc) return rc;
+    double *d = (double *)c->d_scratch;
+    HIP_TRY(c, hipMemcpyAsync(d, pts, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    k_wrap_points<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(c->pbc, d, n);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(pts, d, (size_t)n * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+extern "C" int sit_distances(sit_ctx *c, const double *pt1, const double *pts2, i64 n, double *out)
+{
+    if (!c || !pt1 || ((!pts2 || !out) && n > 0)) return SIT_ERR_INVALID;
+    if (n <= 0) return SIT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, n * 32);
+    if (rc) return rc;
+    double *d = (double *)c->d_scratch, *o = d + 3 * n;
+    HIP_TRY(c, hipMemcpyAsync(d, pts2, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    k_distances<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(c->pbc, pt1[0], pt1[1], pt1[2], d, n, o);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, o, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+// util/PBCCalculator.pyx:106-139.  One block; a fixed-shape tree reduction keeps the result
+// independent of scheduling.  part[] = (sum w, sum w*x, sum w*y, sum w*z) of wrap(p + offset).
+__global__ __launch_bounds__(256) void k_average(Pbc P, const double *pts, const double *w, i64 n,
+                                                 double ox, double oy, double oz, double *out4)
+{
+    __shared__ double red[4][256];
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (i64 i = threadIdx.x; i < n; i += 256) {
+        double x = pts[3 * i] + ox, y = pts[3 * i + 1] + oy, z = pts[3 * i + 2] + oz;
+        wrap3(P, x, y, z);
+        double wi = w ? w[i] : 1.0;
+        s0 += wi; s1 += wi * x; s2 += wi * y; s3 += wi * z;
+    }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2; red[3][threadIdx.x] = s3;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int q = 0; q < 4; q++) red[q][threadIdx.x] += red[q][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) out4[threadIdx.x] = red[threadIdx.x][0];
+}
+
+extern "C" int sit_average(sit_ctx *c, const double *pts, const double *weights, i64 n, double *out3)
+{
+    if (!c || !pts || !out3 || n <= 0) return SIT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // center_about = argmax(weights) (first maximum; NaN first), index 0 when unweighted (:121-123)
+    i64 about = 0;
+    if (weights) {
+        for (i64 i = 0; i < n; i++) {
+            if (std::isnan(weights[i])) { about = i; break; }
+            if (weights[i] > weights[about]) about = i;
+        }
+    }
+    const double off[3] = {c->pbc.cen[0] - pts[3 * about], c->pbc.cen[1] - pts[3 * about + 1],
+                           c->pbc.cen[2] - pts[3 * about + 2]};
+    int rc = ensure_scratch(c, n * 32 + 64);
+    if (rc) return rc;
+    double *dp = (double *)c->d_scratch, *dw = dp + 3 * n, *dout = dw + n;
+    HIP_TRY(c, hipMemcpyAsync(dp, pts, (size_t)n * 24, hipMemcpyHostToDevice, c->stream));
+    if (weights) HIP_TRY(c, hipMemcpyAsync(dw, weights, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    k_average<<<dim3(1), dim3(256), 0, c->stream>>>(c->pbc, dp, weights ? dw : nullptr, n, off[0], off[1], off[2], dout);
+    HIP_TRY(c, hipGetLastError());
+    double h[4];
+    HIP_TRY(c, hipMemcpyAsync(h, dout, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double r[3] = {h[1] / h[0] - off[0], h[2] / h[0] - off[1], h[3] / h[0] - off[2]};
+    return sit_wrap_points(c, r, 1) ? SIT_ERR_HIP : (out3[0] = r[0], out3[1] = r[1], out3[2] = r[2], SIT_OK);
+}
+
+// ---- basis ----------------------------------------------------------------------------------
+
+extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const i64 *verts,
+                             const double *vcd, i64 D, i64 V, double midpoint, double steepness,
+                             double static_thr)
+{
+    if (!c) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, ref_static && verts && vcd && S > 0 && D > 0 && V > 0, "sit_set_basis: bad arguments");
+    SIT_REQUIRE(c, S < (1LL << 30) && D < (1LL << 30), "sit_set_basis: sizes too large");
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (i64 k = 0; k < D * V; k++)
+        SIT_REQUIRE(c, verts[k] >= -1 && verts[k] < S, "sit_set_basis: vertex index out of range");
+    c->S = S; c->D = D; c->V = V;
+    c->midpoint = midpoint; c->steepness = steepness; c->static_thr = static_thr;
+    // landmark/helpers.pyx:127-131 with threshold 0.0001 (:42-44)
+    c->rz = midpoint + log((1 / 0.0001) - 1.) / steepness;
+    std::vector<i32> v32((size_t)(D * V));
+    for (i64 k = 0; k < D * V; k++) v32[(size_t)k] = (i32)verts[k];
+    int rc;
+    if ((rc = dev_upload(c, &c->d_ref_static, ref_static, S * 3))) return rc;
+    if ((rc = dev_upload(c, &c->d_verts, v32.data(), D * V))) return rc;
+    if ((rc = dev_upload(c, &c->d_vcd, vcd, D * V))) return rc;
+    std::vector<i32> off, list;
+    if ((rc = sit_build_candidates(c, ref_static, verts, vcd, off, list))) return rc;
+    if ((rc = dev_upload(c, &c->d_bin_off, off.data(), (i64)off.size()))) return rc;
+    if ((rc = dev_upload(c, &c->d_bin_list, list.data(), (i64)list.size()))) return rc;
+    c->rows_valid = false; c->assign_valid = false; c->map_valid = false;
+    return SIT_OK;
+}
+
+// ---- trajectory -------------------------------------------------------------------------------
+
+static int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S, const i64 *mobile_idx,
+                          i64 M, i64 frame0)
+{
+    SIT_REQUIRE(c, c->S > 0, "sit_set_frames: call sit_set_basis first");
+    SIT_REQUIRE(c, F >= 0 && A > 0 && M > 0 && S == c->S && static_idx && mobile_idx,
+                "sit_set_frames: bad arguments (S must match the basis)");
+    SIT_REQUIRE(c, F * M < (1LL << 40), "sit_set_frames: too many rows");
+    std::vector<i32> s32((size_t)S), m32((size_t)M);
+    for (i64 i = 0; i < S; i++) {
+        SIT_REQUIRE(c, static_idx[i] >= 0 && static_idx[i] < A, "static index out of range");
+        s32[(size_t)i] = (i32)static_idx[i];
+    }
+    for (i64 i = 0; i < M; i++) {
+        SIT_REQUIRE(c, mobile_idx[i] >= 0 && mobile_idx[i] < A, "mobile index out of range");
+        m32[(size_t)i] = (i32)mobile_idx[i];
+    }
+    int rc;
+    if ((rc = dev_upload(c, &c->d_static_idx, s32.data(), S))) return rc;
+    if ((rc = dev_upload(c, &c->d_mobile_idx, m32.data(), M))) return rc;
+    c->F = F; c->A = A; c->M = M; c->frame0 = frame0; c->N = F * M;
+    c->rows_valid = false; c->assign_valid = false; c->map_valid = false;
+    return SIT_OK;
+}
+
+extern "C" int sit_set_frames(sit_ctx *c, const double *frames, i64 F, i64 A, const i64 *static_idx, i64 S,
+                              const i64 *mobile_idx, i64 M, i64 frame0)
+{
+    if (!c) return SIT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = set_frame_meta(c, F, A, static_idx, S, mobile_idx, M, frame0);
+    if (rc) return rc;
+    const i64 bytes = F * A * 24;
+    if (!c->frames_owned || c->frames_cap_bytes < bytes) {
+        if (c->frames_owned && c->d_frames) (void)hipFree(c->d_frames);
+        c->d_frames = nullptr; c->frames_owned = true; c->frames_cap_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_frames, (size_t)(bytes > 0 ? bytes : 8)));
+        c->frames_cap_bytes = bytes;
+    }
+    if (frames && bytes > 0) {
+        StageTimer t(c, T_H2D);
+        HIP_TRY(c, hipMemcpyAsync(c->d_frames, frames, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+        t.stop();
+    }
+    return SIT_OK;
+}
+
+extern "C" int sit_set_frames_device(sit_ctx *c, const void *frames_dev, i64 F, i64 A, const i64 *static_idx,
+                                     i64 S, const i64 *mobile_idx, i64 M, i64 frame0)
+{
+    if (!c || !frames_dev) return SIT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = set_frame_meta(c, F, A, static_idx, S, mobile_idx, M, frame0);
+    if (rc) return rc;
+    if (c->frames_owned && c->d_frames) (void)hipFree(c->d_frames);
+    c->d_frames = (double *)frames_dev;
+    c->frames_owned = false; c->frames_cap_bytes = 0;
+    return SIT_OK;
+}
+
+extern "C" int sit_frames_device_ptr(sit_ctx *c, void **ptr)
+{
+    if (!c || !ptr) return SIT_ERR_INVALID;
+    *ptr = c->d_frames;
+    return SIT_OK;
+}

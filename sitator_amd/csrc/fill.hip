@@ -1,0 +1,342 @@
+// Landmark-vector fill: helpers._fill_landmark_vectors + fill_landmark_vec
+// (landmark/helpers.pyx:12-212) with Step 0 (wrap, LandmarkAnalysis.py:182-189) fused in.
+//
+// v1 layout: one workgroup handles `fpb` consecutive frames.  Phase 1 streams the frames'
+// atoms from HBM, wraps them and parks statics + mobiles in LDS (SoA), running the
+// static-lattice check on the way.  Phase 2 gives every (frame, ion) to one lane, which walks
+// the candidate landmarks of the ion's bin (candidates.cpp) in ascending order and evaluates
+// them with the reference's arithmetic, vertex by vertex with the reference's early exit.
+// Rows go to HBM slot-major (idx[e*N+row]) so that the stores of a wave coalesce.
+#include <cmath>
+
+#include "sit_internal.h"
+
+struct FillArgs {
+    Pbc P;
+    const double *frames;      // [F,A,3]
+    const i32 *static_idx, *mobile_idx;
+    const double *ref_static;  // [S,3]
+    const i32 *verts;          // [D,V]
+    const double *vcd;         // [D,V]
+    const i32 *bin_off, *bin_list;
+    const i32 *lattice_map;    // [F,S] or null
+    i32 *row_nnz, *row_idx;
+    double *row_val;
+    u64 *err, *zero_count;
+    i64 F, A, S, M, D, V, N, W, frame0;
+    int G0, G1, G2;
+    int fpb;
+    int check_zeros;
+    double midpoint, steepness, rz, static_thr;
+};
+
+__device__ __forceinline__ u64 err_key(i64 frame, i64 S, i64 M, i64 slot)
+{
+    return (u64)frame * (u64)(S + 1 + M) + (u64)slot;
+}
+
+template <bool DYN>
+__global__ __launch_bounds__(256) void k_fill_rows(FillArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const i64 S = a.S, M = a.M;
+    double *sx = (double *)smem;
+    double *sy = sx + (i64)a.fpb * S;
+    double *sz = sy + (i64)a.fpb * S;
+    double *mx = sz + (i64)a.fpb * S;
+    double *my = mx + (i64)a.fpb * M;
+    double *mz = my + (i64)a.fpb * M;
+    const Pbc &P = a.P;
+    const i64 f0 = (i64)blockIdx.x * a.fpb;
+    const int nf = (int)((a.F - f0) < a.fpb ? (a.F - f0) : a.fpb);
+    const i64 SM = S + M;
+
+    // ---- phase 1: load, wrap (Step 0), static-lattice check (helpers.pyx:57-80) ----
+    for (i64 t = threadIdx.x; t < (i64)nf * SM; t += blockDim.x) {
+        const int fl = (int)(t / SM);
+        const i64 r = t - (i64)fl * SM;
+        const i64 atom = r < S ? a.static_idx[r] : a.mobile_idx[r - S];
+        const double *p = a.frames + ((f0 + fl) * a.A + atom) * 3;
+        double x = p[0], y = p[1], z = p[2];
+        wrap3(P, x, y, z);
+        if (r < S) {
+            sx[fl * S + r] = x; sy[fl * S + r] = y; sz[fl * S + r] = z;
+            if (!DYN) {
+                const double *rp = a.ref_static + 3 * r;
+                const double d = dist_sw(P, rp[0], rp[1], rp[2], x, y, z);
+                if (d > a.static_thr) atomicMin(a.err, err_key(a.frame0 + f0 + fl, S, M, r));
+            }
+        } else {
+            mx[fl * M + (r - S)] = x; my[fl * M + (r - S)] = y; mz[fl * M + (r - S)] = z;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: one lane per (frame, ion) (helpers.pyx:95-122, :134-212) ----
+    for (i64 t = threadIdx.x; t < (i64)nf * M; t += blockDim.x) {
+        const int fl = (int)(t / M);
+        const i64 j = t - (i64)fl * M;
+        const double px = mx[fl * M + j], py = my[fl * M + j], pz = mz[fl * M + j];
+        const double ox = P.cen[0] - px, oy = P.cen[1] - py, oz = P.cen[2] - pz;   // helpers.pyx:100
+        // bin of the (wrapped) ion in fractional coordinates
+        double fb0 = (P.ci[0] * px + P.ci[1] * py + P.ci[2] * pz); fb0 -= floor(fb0);
+        double fb1 = (P.ci[3] * px + P.ci[4] * py + P.ci[5] * pz); fb1 -= floor(fb1);
+        double fb2 = (P.ci[6] * px + P.ci[7] * py + P.ci[8] * pz); fb2 -= floor(fb2);
+        int b0 = (int)(fb0 * a.G0), b1 = (int)(fb1 * a.G1), b2 = (int)(fb2 * a.G2);
+        b0 = b0 < 0 ? 0 : (b0 >= a.G0 ? a.G0 - 1 : b0);
+        b1 = b1 < 0 ? 0 : (b1 >= a.G1 ? a.G1 - 1 : b1);
+        b2 = b2 < 0 ? 0 : (b2 >= a.G2 ? a.G2 - 1 : b2);
+        const i64 bin = ((i64)b0 * a.G1 + b1) * a.G2 + b2;
+        const i32 lo = a.bin_off[bin], hi = a.bin_off[bin + 1];
+        const double *fsx = sx + fl * S, *fsy = sy + fl * S, *fsz = sz + fl * S;
+        const i32 *lmap = DYN ? a.lattice_map + (f0 + fl) * S : nullptr;
+        const i64 row = (f0 + fl) * M + j;
+        int nnz = 0;
+        for (i32 c = lo; c < hi; c++) {
+            const i32 k = a.bin_list[c];
+            const i32 *vk = a.verts + (i64)k * a.V;
+            const double *dk = a.vcd + (i64)k * a.V;
+            double acc = 1.0;
+            int nv = 0;
+            for (int h = 0; h < (int)a.V; h++) {
+                i32 v = vk[h];
+                if (v < 0) break;
+                nv++;
+                if (DYN) v = lmap[v];
+                double qx = fsx[v] + ox, qy = fsy[v] + oy, qz = fsz[v] + oz;
+                wrap3(P, qx, qy, qz);                                             // helpers.pyx:103
+                const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
+                const double dist = sqrt((dx * dx + dy * dy) + dz * dz);          // :176
+                double tt = dist / dk[h];                                         // :197
+                if (tt > a.rz) { acc = 0.0; break; }                              // :199-203
+                tt = 1.0 / (1.0 + exp(a.steepness * (tt - a.midpoint)));          // :205
+                acc *= tt;
+            }
+            if (acc != 0.0) {
+                const double val = pow(acc, 1.0 / nv);                            // :212
+                if (val != 0.0) {
+                    a.row_idx[(i64)nnz * a.N + row] = k;
+                    a.row_val[(i64)nnz * a.N + row] = val;
+                    nnz++;
+                }
+            }
+        }
+        a.row_nnz[row] = nnz;
+        if (nnz == 0) {                                                           // :116-120
+            if (a.check_zeros) atomicMin(a.err, err_key(a.frame0 + f0 + fl, S, M, S + 1 + j));
+            else atomicAdd(a.zero_count, 1ull);
+        }
+    }
+}
+
+// Dynamic lattice mapping (helpers.pyx:60-64,83) + its checks, one workgroup per frame.
+// map[f, li] = first-minimum argmin over the frame's static atoms of the shift-and-wrap distance
+// to lattice position li; seen flags; threshold / unassigned errors in the reference's order.
+struct MapArgs {
+    Pbc P;
+    const double *frames;
+    const i32 *static_idx;
+    const double *ref_static;
+    i32 *lattice_map;
+    u64 *err;
+    unsigned char *seen_out;   // optional [S] for one frame (sit_static_seen)
+    i64 F, A, S, M, frame0, only_frame;
+    int relaxed;
+    double static_thr;
+};
+
+__global__ __launch_bounds__(256) void k_lattice_map(MapArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const i64 S = a.S;
+    double *sx = (double *)smem, *sy = sx + S, *sz = sy + S;
+    int *seen = (int *)(sz + S);
+    const i64 f = a.only_frame >= 0 ? a.only_frame : (i64)blockIdx.x;
+    const Pbc &P = a.P;
+    for (i64 s = threadIdx.x; s < S; s += blockDim.x) {
+        const double *p = a.frames + (f * a.A + a.static_idx[s]) * 3;
+        double x = p[0], y = p[1], z = p[2];
+        wrap3(P, x, y, z);
+        sx[s] = x; sy[s] = y; sz[s] = z; seen[s] = 0;
+    }
+    __syncthreads();
+    for (i64 li = threadIdx.x; li < S; li += blockDim.x) {
+        const double *rp = a.ref_static + 3 * li;
+        double best = dist_sw(P, rp[0], rp[1], rp[2], sx[0], sy[0], sz[0]);
+        i32 arg = 0;
+        for (i64 s = 1; s < S; s++) {
+            const double d = dist_sw(P, rp[0], rp[1], rp[2], sx[s], sy[s], sz[s]);
+            if (d < best) { best = d; arg = (i32)s; }      // np.argmin: first minimum
+        }
+        if (a.lattice_map) a.lattice_map[f * S + li] = arg;
+        atomicOr(&seen[arg], 1);
+        if (best > a.static_thr) atomicMin(a.err, err_key(a.frame0 + f, S, a.M, li));
+    }
+    __syncthreads();
+    for (i64 s = threadIdx.x; s < S; s += blockDim.x) {
+        if (a.seen_out) a.seen_out[s] = (unsigned char)seen[s];
+        if (!a.relaxed && !seen[s]) atomicMin(a.err, err_key(a.frame0 + f, S, a.M, S));
+    }
+}
+
+static int decode_error(sit_ctx *c, u64 key, sit_error *err)
+{
+    if (key == SIT_NO_ERROR_KEY) return SIT_OK;
+    const u64 Wd = (u64)(c->S + 1 + c->M);
+    const i64 frame = (i64)(key / Wd), slot = (i64)(key % Wd);
+    int kind;
+    i64 index;
+    if (slot < c->S) { kind = SIT_ERR_STATIC_THRESHOLD; index = slot; }
+    else if (slot == c->S) { kind = SIT_ERR_STATIC_UNASSIGNED; index = -1; }
+    else { kind = SIT_ERR_ZERO_LANDMARK; index = slot - c->S - 1; }
+    if (err) { err->kind = kind; err->frame = frame; err->index = index; err->aux = 0; }
+    return kind;
+}
+
+extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, sit_error *err)
+{
+    if (!c || !p) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->D > 0 && c->d_frames && c->M > 0, "sit_fill: basis and frames must be set first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
+    const i64 S = c->S, M = c->M, N = c->N, W = c->W;
+    int rc;
+    if (c->rows_W != W || c->rows_N != N || !c->d_row_nnz) {
+        c->rows_valid = false;
+        if ((rc = dev_alloc(c, &c->d_row_nnz, N))) return rc;
+        if ((rc = dev_alloc(c, &c->d_row_idx, N * W))) return rc;
+        if ((rc = dev_alloc(c, &c->d_row_val, N * W))) return rc;
+        c->rows_W = W; c->rows_N = N;
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_err, 0xFF, sizeof(u64), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream));
+    if (c->F == 0) { if (n_all_zero) *n_all_zero = 0; c->rows_valid = true; return SIT_OK; }
+
+    StageTimer timer(c, T_FILL);
+    if (p->dynamic_lattice_mapping) {
+        if ((rc = dev_alloc(c, &c->d_lattice_map, c->F * S))) return rc;
+        MapArgs m;
+        m.P = c->pbc; m.frames = c->d_frames; m.static_idx = c->d_static_idx; m.ref_static = c->d_ref_static;
+        m.lattice_map = c->d_lattice_map; m.err = c->d_err; m.seen_out = nullptr;
+        m.F = c->F; m.A = c->A; m.S = S; m.M = M; m.frame0 = c->frame0; m.only_frame = -1;
+        m.relaxed = p->relaxed_lattice_checks; m.static_thr = c->static_thr;
+        const size_t lds = (size_t)S * 28 + 16;
+        SIT_REQUIRE(c, lds <= 160 * 1024, "sit_fill: too many static atoms for the LDS-resident lattice map");
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_lattice_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_lattice_map<<<dim3((unsigned)c->F), dim3(256), lds, c->stream>>>(m);
+        HIP_TRY(c, hipGetLastError());
+        c->map_valid = true;
+    }
+    FillArgs a;
+    a.P = c->pbc; a.frames = c->d_frames; a.static_idx = c->d_static_idx; a.mobile_idx = c->d_mobile_idx;
+    a.ref_static = c->d_ref_static; a.verts = c->d_verts; a.vcd = c->d_vcd;
+    a.bin_off = c->d_bin_off; a.bin_list = c->d_bin_list;
+    a.lattice_map = p->dynamic_lattice_mapping ? c->d_lattice_map : nullptr;
+    a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx; a.row_val = c->d_row_val;
+    a.err = c->d_err; a.zero_count = c->d_scal;
+    a.F = c->F; a.A = c->A; a.S = S; a.M = M; a.D = c->D; a.V = c->V; a.N = N; a.W = W; a.frame0 = c->frame0;
+    a.G0 = c->G[0]; a.G1 = c->G[1]; a.G2 = c->G[2];
+    a.check_zeros = p->check_for_zeros;
+    a.midpoint = c->midpoint; a.steepness = c->steepness; a.rz = c->rz; a.static_thr = c->static_thr;
+    // frames per workgroup: aim at ~256 ions per workgroup within the LDS budget
+    const i64 per_frame = (S + M) * 24;
+    SIT_REQUIRE(c, per_frame <= 150 * 1024, "sit_fill: one frame's atoms do not fit in LDS");
+    i64 fpb = 256 / M; if (fpb < 1) fpb = 1; if (fpb > 16) fpb = 16;
+    while (fpb > 1 && fpb * per_frame > 64 * 1024) fpb--;
+    a.fpb = (int)fpb;
+    const size_t lds = (size_t)(fpb * per_frame);
+    const unsigned grid = (unsigned)((c->F + fpb - 1) / fpb);
+    if (p->dynamic_lattice_mapping) {
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_fill_rows<true><<<dim3(grid), dim3(256), lds, c->stream>>>(a);
+    } else {
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_fill_rows<false><<<dim3(grid), dim3(256), lds, c->stream>>>(a);
+    }
+    HIP_TRY(c, hipGetLastError());
+    timer.stop();
+    u64 hkey = 0, hzero = 0;
+    HIP_TRY(c, hipMemcpyAsync(&hkey, c->d_err, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&hzero, c->d_scal, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n_all_zero) *n_all_zero = (i64)hzero;
+    c->rows_valid = true;
+    c->assign_valid = false;
+    const int kind = decode_error(c, hkey, err);
+    if (kind == SIT_OK && p->assign) return sit_predict_internal(c, p->predict_threshold);
+    return kind;
+}
+
+extern "C" int sit_static_seen(sit_ctx *c, i64 local_frame, uint8_t *seen)
+{
+    if (!c || !seen) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->d_frames && local_frame >= 0 && local_frame < c->F, "sit_static_seen: bad frame");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, c->S + 64);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_err, 0xFF, sizeof(u64), c->stream));
+    MapArgs m;
+    m.P = c->pbc; m.frames = c->d_frames; m.static_idx = c->d_static_idx; m.ref_static = c->d_ref_static;
+    m.lattice_map = nullptr; m.err = c->d_err; m.seen_out = (unsigned char *)c->d_scratch;
+    m.F = c->F; m.A = c->A; m.S = c->S; m.M = c->M; m.frame0 = c->frame0; m.only_frame = local_frame;
+    m.relaxed = 1; m.static_thr = c->static_thr;
+    const size_t lds = (size_t)c->S * 28 + 16;
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k_lattice_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_lattice_map<<<dim3(1), dim3(256), lds, c->stream>>>(m);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(seen, c->d_scratch, (size_t)c->S, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+// ---- row read-back (the `landmark_vectors` property, LandmarkAnalysis.py:136-141) ----------
+
+__global__ void k_rows_dense(const i32 *nnz, const i32 *idx, const double *val, i64 N, i64 D, i64 row0,
+                             i64 nrows, double *out)
+{
+    i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const i64 row = row0 + r;
+    const int n = nnz[row];
+    for (int e = 0; e < n; e++) out[r * D + idx[(i64)e * N + row]] = val[(i64)e * N + row];
+}
+
+extern "C" int sit_row_width(sit_ctx *c, i64 *w)
+{
+    if (!c || !w) return SIT_ERR_INVALID;
+    *w = c->rows_valid ? c->rows_W : c->W;
+    return SIT_OK;
+}
+
+extern "C" int sit_get_rows_dense(sit_ctx *c, i64 row0, i64 nrows, double *out)
+{
+    if (!c || !out) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->rows_valid && row0 >= 0 && nrows >= 0 && row0 + nrows <= c->N, "sit_get_rows_dense: bad range or no rows");
+    if (nrows == 0) return SIT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, nrows * c->D * 8);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(nrows * c->D * 8), c->stream));
+    k_rows_dense<<<dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, c->stream>>>(
+        c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, c->D, row0, nrows, (double *)c->d_scratch);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, (size_t)(nrows * c->D * 8), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+extern "C" int sit_get_rows_sparse(sit_ctx *c, i64 row0, i64 nrows, i32 *nnz, i32 *idx, double *val)
+{
+    if (!c || !nnz || !idx || !val) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->rows_valid && row0 >= 0 && nrows >= 0 && row0 + nrows <= c->N, "sit_get_rows_sparse: bad range or no rows");
+    if (nrows == 0) return SIT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    // output is slot-major over the requested window: idx[e*nrows + r]
+    HIP_TRY(c, hipMemcpyAsync(nnz, c->d_row_nnz + row0, (size_t)nrows * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(idx, (size_t)nrows * 4, c->d_row_idx + row0, (size_t)c->N * 4, (size_t)nrows * 4,
+                                (size_t)c->rows_W, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(val, (size_t)nrows * 8, c->d_row_val + row0, (size_t)c->N * 8, (size_t)nrows * 8,
+                                (size_t)c->rows_W, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}

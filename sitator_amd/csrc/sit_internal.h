@@ -1,0 +1,177 @@
+// Internal definitions shared by the translation units of libsitator_hip.so.
+// Not part of the boundary (that is include/sitator_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "sitator_hip.h"
+
+typedef int64_t i64;
+typedef int32_t i32;
+typedef unsigned long long u64;
+
+// Periodic-cell constants, passed to kernels by value (lands in SGPRs / constant loads).
+// cm = cell.T (columns are the cell vectors), ci = inverse(cm), cen = cell centroid
+// (util/PBCCalculator.pyx:22-35).
+struct Pbc {
+    double cm[9];
+    double ci[9];
+    double cen[3];
+};
+
+enum { T_FILL = 0, T_FIT = 1, T_PREDICT = 2, T_GRAM = 3, T_CENTERS = 4, T_OCC = 5, T_H2D = 6, T_N = 8 };
+
+#define SIT_NO_ERROR_KEY 0xFFFFFFFFFFFFFFFFull
+
+struct sit_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string msg;
+    double timers[T_N] = {0};
+    Pbc pbc;
+
+    // basis (sit_set_basis)
+    i64 S = 0, D = 0, V = 0;
+    double midpoint = 1.5, steepness = 30, rz = 0, static_thr = 1.0;
+    double *d_ref_static = nullptr;   // [S,3]
+    i32 *d_verts = nullptr;           // [D,V], -1 padded
+    double *d_vcd = nullptr;          // [D,V]
+    // result-preserving landmark pruning: fractional-coordinate bins -> candidate landmarks
+    int G[3] = {1, 1, 1};
+    i32 *d_bin_off = nullptr;         // [nbins+1]
+    i32 *d_bin_list = nullptr;
+    i64 W = 0;                        // row width = longest candidate list
+    double mean_candidates = 0;
+
+    // trajectory (sit_set_frames)
+    i64 F = 0, A = 0, M = 0, frame0 = 0;
+    double *d_frames = nullptr;
+    bool frames_owned = false;
+    i64 frames_cap_bytes = 0;
+    i32 *d_static_idx = nullptr, *d_mobile_idx = nullptr;
+    i32 *d_lattice_map = nullptr;     // [F,S] when dynamic mapping ran
+    bool map_valid = false;
+
+    // sparse rows, slot-major: idx[e*N + row], val[e*N + row]
+    i64 N = 0, rows_W = 0, rows_N = 0;
+    i32 *d_row_nnz = nullptr, *d_row_idx = nullptr;
+    double *d_row_val = nullptr;
+    bool rows_valid = false;
+
+    // assignment
+    i64 *d_labels = nullptr;
+    double *d_confs = nullptr;
+    i64 *d_counts = nullptr;          // [K]
+    i64 assign_N = 0;
+    bool assign_valid = false;
+
+    // predict centres, CSC over landmark dimension: for dim d entries col_ptr[d]..col_ptr[d+1]
+    i64 K = 0;
+    int centers_normed = 1;
+    i32 *d_col_ptr = nullptr, *d_col_k = nullptr;
+    double *d_col_val = nullptr;
+    double *d_cen_dense = nullptr;    // [K,D] the same matrix, dense (fallback predict)
+
+    // fit state (dense centres on device)
+    i64 fit_cap = 0, fit_K = 0;
+    double *d_fit_centers = nullptr;  // [fit_cap, D]
+    double *d_fit_nrm2 = nullptr;    // [fit_cap]
+    i64 *d_fit_counts = nullptr;      // [fit_cap]
+    i64 *d_fit_K = nullptr;           // device scalar
+
+    // scalars on device
+    u64 *d_err = nullptr;             // packed first-offender key (atomicMin)
+    u64 *d_scal = nullptr;            // [16] general purpose counters
+    void *d_scratch = nullptr;
+    i64 scratch_bytes = 0;
+};
+
+#define HIP_TRY(ctx, expr)                                                              \
+    do {                                                                                \
+        hipError_t e__ = (expr);                                                        \
+        if (e__ != hipSuccess) {                                                        \
+            (ctx)->msg = std::string(#expr) + ": " + hipGetErrorString(e__);            \
+            return SIT_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define SIT_REQUIRE(ctx, cond, text)                                                    \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            (ctx)->msg = (text);                                                        \
+            return SIT_ERR_INVALID;                                                     \
+        }                                                                               \
+    } while (0)
+
+template <typename T>
+static inline int dev_alloc(sit_ctx *c, T **p, i64 n)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (n <= 0) n = 1;
+    HIP_TRY(c, hipMalloc((void **)p, sizeof(T) * (size_t)n));
+    return SIT_OK;
+}
+
+template <typename T>
+static inline int dev_upload(sit_ctx *c, T **p, const T *h, i64 n)
+{
+    int rc = dev_alloc(c, p, n);
+    if (rc) return rc;
+    if (n > 0) HIP_TRY(c, hipMemcpyAsync(*p, h, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+static inline int ensure_scratch(sit_ctx *c, i64 bytes)
+{
+    if (bytes <= c->scratch_bytes) return SIT_OK;
+    if (c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = nullptr; c->scratch_bytes = 0; }
+    HIP_TRY(c, hipMalloc(&c->d_scratch, (size_t)bytes));
+    c->scratch_bytes = bytes;
+    return SIT_OK;
+}
+
+struct StageTimer {
+    sit_ctx *c; int slot;
+    StageTimer(sit_ctx *c_, int s) : c(c_), slot(s) { (void)hipEventRecord(c->ev0, c->stream); }
+    void stop()
+    {
+        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventSynchronize(c->ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        c->timers[slot] = ms;
+    }
+};
+
+// ---- device helpers shared by kernels ---------------------------------------------------
+
+// util/PBCCalculator.pyx:341-366: f = ci.p; f -= floor(f); p = cm.f, rows summed left to right.
+__device__ __forceinline__ void wrap3(const Pbc &P, double &x, double &y, double &z)
+{
+    double b0 = (P.ci[0] * x + P.ci[1] * y + P.ci[2] * z); b0 -= floor(b0);
+    double b1 = (P.ci[3] * x + P.ci[4] * y + P.ci[5] * z); b1 -= floor(b1);
+    double b2 = (P.ci[6] * x + P.ci[7] * y + P.ci[8] * z); b2 -= floor(b2);
+    x = (P.cm[0] * b0 + P.cm[1] * b1 + P.cm[2] * b2);
+    y = (P.cm[3] * b0 + P.cm[4] * b1 + P.cm[5] * b2);
+    z = (P.cm[6] * b0 + P.cm[7] * b1 + P.cm[8] * b2);
+}
+
+// util/PBCCalculator.pyx:64-103 for one point: |centroid - wrap(p2 + (centroid - p1))|
+__device__ __forceinline__ double dist_sw(const Pbc &P, double ax, double ay, double az,
+                                          double bx, double by, double bz)
+{
+    double qx = bx + (P.cen[0] - ax), qy = by + (P.cen[1] - ay), qz = bz + (P.cen[2] - az);
+    wrap3(P, qx, qy, qz);
+    double dx = -qx + P.cen[0], dy = -qy + P.cen[1], dz = -qz + P.cen[2];
+    return sqrt((dx * dx + dy * dy) + dz * dz);
+}
+
+// host-side pieces implemented in other translation units
+int sit_predict_internal(sit_ctx *c, double threshold);
+int sit_build_candidates(sit_ctx *c, const double *ref_static, const i64 *verts, const double *vcd,
+                         std::vector<i32> &bin_off, std::vector<i32> &bin_list);

@@ -1,0 +1,291 @@
+// Site centres (landmark/LandmarkAnalysis.py:276-287 + PBCCalculator.average,
+// util/PBCCalculator.pyx:106-139) and SiteTrajectory.check_multiple_occupancy
+// (SiteTrajectory.py:205-232) on the device-resident labels / confidences.
+#include <cmath>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "sit_internal.h"
+
+// Pass 1a: per site the largest weight (weights are confidences >= 0, so their IEEE bit
+// patterns order like the values; unweighted: every weight is 1).
+__global__ void k_site_wmax(const i64 *labels, const double *confs, i64 N, i64 K, int weighted, u64 *wmax_bits)
+{
+    const i64 row = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N) return;
+    const i64 l = labels[row];
+    if (l < 0 || l >= K) return;
+    const double w = weighted ? confs[row] : 1.0;
+    atomicMax(&wmax_bits[l], (u64)__double_as_longlong(w));
+}
+
+// Pass 1b: first row (np.argmax: first maximum) holding that weight.
+__global__ void k_site_first(const i64 *labels, const double *confs, i64 N, i64 K, int weighted,
+                             const u64 *wmax_bits, u64 *first_row, i64 row_offset)
+{
+    const i64 row = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N) return;
+    const i64 l = labels[row];
+    if (l < 0 || l >= K) return;
+    const double w = weighted ? confs[row] : 1.0;
+    if ((u64)__double_as_longlong(w) == wmax_bits[l]) atomicMin(&first_row[l], (u64)(row + row_offset));
+}
+
+// wrapped (Step 0) position of the mobile ion of a row
+__device__ __forceinline__ void ion_position(const Pbc &P, const double *frames, const i32 *mobile_idx,
+                                             i64 A, i64 M, i64 row, double &x, double &y, double &z)
+{
+    const i64 f = row / M, j = row - f * M;
+    const double *p = frames + (f * A + mobile_idx[j]) * 3;
+    x = p[0]; y = p[1]; z = p[2];
+    wrap3(P, x, y, z);
+}
+
+__global__ void k_site_anchor_pts(Pbc P, const double *frames, const i32 *mobile_idx, i64 A, i64 M, i64 K,
+                                  const u64 *first_row, i64 row_offset, i64 N, double *pts)
+{
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const u64 r = first_row[k];
+    double x = NAN, y = NAN, z = NAN;
+    if (r != SIT_NO_ERROR_KEY) {
+        const i64 local = (i64)r - row_offset;
+        if (local >= 0 && local < N) ion_position(P, frames, mobile_idx, A, M, local, x, y, z);
+    }
+    pts[3 * k] = x; pts[3 * k + 1] = y; pts[3 * k + 2] = z;
+}
+
+// Pass 2: per site (sum w, sum w*q) with q = wrap(p + (centroid - anchor)) (:127-134).
+// Workgroup-private partial sums in LDS (ds_add_f64), then one global atomic per site and block.
+__global__ __launch_bounds__(256) void k_site_sums(Pbc P, const double *frames, const i32 *mobile_idx, i64 A,
+                                                   i64 M, const i64 *labels, const double *confs, i64 N, i64 K,
+                                                   int weighted, const double *anchors, double *sums,
+                                                   i64 rows_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *part = (double *)smem;     // [K,4]
+    for (i64 q = threadIdx.x; q < K * 4; q += blockDim.x) part[q] = 0.0;
+    __syncthreads();
+    const i64 r0 = (i64)blockIdx.x * rows_per_block;
+    const i64 r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+    for (i64 row = r0 + threadIdx.x; row < r1; row += blockDim.x) {
+        const i64 l = labels[row];
+        if (l < 0 || l >= K) continue;
+        const double w = weighted ? confs[row] : 1.0;
+        double x, y, z;
+        ion_position(P, frames, mobile_idx, A, M, row, x, y, z);
+        x += (P.cen[0] - anchors[3 * l]); y += (P.cen[1] - anchors[3 * l + 1]); z += (P.cen[2] - anchors[3 * l + 2]);
+        wrap3(P, x, y, z);
+        unsafeAtomicAdd(&part[4 * l + 0], w);
+        unsafeAtomicAdd(&part[4 * l + 1], w * x);
+        unsafeAtomicAdd(&part[4 * l + 2], w * y);
+        unsafeAtomicAdd(&part[4 * l + 3], w * z);
+    }
+    __syncthreads();
+    for (i64 q = threadIdx.x; q < K * 4; q += blockDim.x)
+        if (part[q] != 0.0) unsafeAtomicAdd(&sums[q], part[q]);
+}
+
+extern "C" int sit_site_anchors(sit_ctx *c, int weighted, i64 K, double *wmax, i64 *first_row, double *anchor_pts)
+{
+    if (!c || !wmax || !first_row || !anchor_pts) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->assign_valid && c->d_frames && K > 0, "sit_site_anchors: assignments and frames needed");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, K * (8 + 8 + 24));
+    if (rc) return rc;
+    u64 *dw = (u64 *)c->d_scratch, *df = dw + K;
+    double *dp = (double *)(df + K);
+    const i64 row_offset = c->frame0 * c->M;
+    HIP_TRY(c, hipMemsetAsync(dw, 0, (size_t)K * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(df, 0xFF, (size_t)K * 8, c->stream));
+    StageTimer t(c, T_CENTERS);
+    if (c->N > 0) {
+        const unsigned grid = (unsigned)((c->N + 255) / 256);
+        k_site_wmax<<<dim3(grid), dim3(256), 0, c->stream>>>(c->d_labels, c->d_confs, c->N, K, weighted, dw);
+        k_site_first<<<dim3(grid), dim3(256), 0, c->stream>>>(c->d_labels, c->d_confs, c->N, K, weighted, dw, df, row_offset);
+    }
+    k_site_anchor_pts<<<dim3((unsigned)((K + 63) / 64)), dim3(64), 0, c->stream>>>(
+        c->pbc, c->d_frames, c->d_mobile_idx, c->A, c->M, K, df, row_offset, c->N, dp);
+    HIP_TRY(c, hipGetLastError());
+    t.stop();
+    HIP_TRY(c, hipMemcpyAsync(wmax, dw, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(first_row, df, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(anchor_pts, dp, (size_t)K * 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (i64 k = 0; k < K; k++)
+        if ((u64)first_row[k] == SIT_NO_ERROR_KEY) { first_row[k] = -1; wmax[k] = -1.0; }
+    return SIT_OK;
+}
+
+extern "C" int sit_site_sums(sit_ctx *c, int weighted, i64 K, const double *anchor_pts, double *sums)
+{
+    if (!c || !anchor_pts || !sums) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->assign_valid && c->d_frames && K > 0, "sit_site_sums: assignments and frames needed");
+    SIT_REQUIRE(c, K * 32 <= 150 * 1024, "sit_site_sums: too many sites for the LDS-private partial sums");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, K * (24 + 32));
+    if (rc) return rc;
+    double *da = (double *)c->d_scratch, *ds = da + 3 * K;
+    HIP_TRY(c, hipMemcpyAsync(da, anchor_pts, (size_t)K * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ds, 0, (size_t)K * 32, c->stream));
+    StageTimer t(c, T_CENTERS);
+    if (c->N > 0) {
+        const i64 rpb = 4096;
+        const size_t lds = (size_t)K * 32;
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_site_sums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_site_sums<<<dim3((unsigned)((c->N + rpb - 1) / rpb)), dim3(256), lds, c->stream>>>(
+            c->pbc, c->d_frames, c->d_mobile_idx, c->A, c->M, c->d_labels, c->d_confs, c->N, K, weighted, da, ds, rpb);
+        HIP_TRY(c, hipGetLastError());
+    }
+    t.stop();
+    HIP_TRY(c, hipMemcpyAsync(sums, ds, (size_t)K * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+// ---- check_multiple_occupancy (SiteTrajectory.py:205-232) ------------------------------------
+// One workgroup walks frames; an LDS histogram over sites counts the ions per site of one frame.
+// stats[0] += #(sites with count > 1), stats[1] += sum(counts), stats[2] += #occupied sites.
+__global__ __launch_bounds__(256) void k_occupancy(const i64 *labels, i64 F, i64 M, i64 K, i64 max_per_site,
+                                                   i64 frame0, u64 *err, u64 *stats, i64 frames_per_block)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *hist = (int *)smem;           // [K]
+    for (i64 q = threadIdx.x; q < K; q += blockDim.x) hist[q] = 0;
+    __syncthreads();
+    const i64 f0 = (i64)blockIdx.x * frames_per_block;
+    const i64 f1 = f0 + frames_per_block < F ? f0 + frames_per_block : F;
+    u64 more = 0, total = 0, nsites = 0;
+    for (i64 f = f0; f < f1; f++) {
+        const i64 *rowp = labels + f * M;
+        for (i64 j = threadIdx.x; j < M; j += blockDim.x) {
+            const i64 l = rowp[j];
+            if (l >= 0 && l < K) atomicAdd(&hist[l], 1);
+        }
+        __syncthreads();
+        for (i64 j = threadIdx.x; j < M; j += blockDim.x) {
+            const i64 l = rowp[j];
+            if (l < 0 || l >= K) continue;
+            const int cnt = hist[l];
+            if (cnt > max_per_site) atomicMin(err, (u64)(frame0 + f) * (u64)K + (u64)l);
+            // the lowest-indexed ion of a site accounts for it
+            bool rep = true;
+            if (cnt > 1) for (i64 q = 0; q < j; q++) if (rowp[q] == l) { rep = false; break; }
+            if (rep) { nsites++; total += (u64)cnt; if (cnt > 1) more++; }
+        }
+        __syncthreads();
+        for (i64 j = threadIdx.x; j < M; j += blockDim.x) {
+            const i64 l = rowp[j];
+            if (l >= 0 && l < K) hist[l] = 0;
+        }
+        __syncthreads();
+    }
+    if (more) atomicAdd(&stats[0], more);
+    if (total) atomicAdd(&stats[1], total);
+    if (nsites) atomicAdd(&stats[2], nsites);
+}
+
+extern "C" int sit_check_occupancy(sit_ctx *c, i64 K, i64 max_per_site, i64 *n_multi, i64 *total, i64 *nsites,
+                                   sit_error *err)
+{
+    if (!c || !n_multi || !total || !nsites) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->assign_valid && K > 0, "sit_check_occupancy: assignments needed");
+    SIT_REQUIRE(c, K * 4 <= 150 * 1024, "sit_check_occupancy: too many sites for the LDS histogram");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
+    HIP_TRY(c, hipMemsetAsync(c->d_err, 0xFF, sizeof(u64), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream));
+    StageTimer t(c, T_OCC);
+    if (c->F > 0) {
+        const i64 fpb = 64;
+        const size_t lds = (size_t)K * 4 + 16;
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_occupancy, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_occupancy<<<dim3((unsigned)((c->F + fpb - 1) / fpb)), dim3(256), lds, c->stream>>>(
+            c->d_labels, c->F, c->M, K, max_per_site, c->frame0, c->d_err, c->d_scal + 8, fpb);
+        HIP_TRY(c, hipGetLastError());
+    }
+    t.stop();
+    u64 key = 0, st[3] = {0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(&key, c->d_err, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(st, c->d_scal + 8, 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_multi = (i64)st[0]; *total = (i64)st[1]; *nsites = (i64)st[2];
+    if (key != SIT_NO_ERROR_KEY) {
+        if (err) { err->kind = SIT_ERR_MULTIPLE_OCCUPANCY; err->frame = (i64)(key / (u64)K); err->index = (i64)(key % (u64)K); }
+        return SIT_ERR_MULTIPLE_OCCUPANCY;
+    }
+    return SIT_OK;
+}
+
+// ---- assignments upload + jump detection (SiteTrajectory.py:15-42, :347-373) -----------------
+
+extern "C" int sit_set_assignments(sit_ctx *c, const i64 *labels, const double *confs, i64 F, i64 M, i64 frame0)
+{
+    if (!c || !labels) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, F >= 0 && M > 0, "sit_set_assignments: bad shape");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->d_frames) SIT_REQUIRE(c, F == c->F && M == c->M, "sit_set_assignments: shape differs from the resident frames");
+    c->F = F; c->M = M; c->N = F * M; c->frame0 = frame0;
+    int rc;
+    if (!c->d_labels || c->assign_N != c->N) {
+        if ((rc = dev_alloc(c, &c->d_labels, c->N))) return rc;
+        if ((rc = dev_alloc(c, &c->d_confs, c->N))) return rc;
+        c->assign_N = c->N;
+    }
+    if (c->N > 0) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_labels, labels, (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream));
+        if (confs) HIP_TRY(c, hipMemcpyAsync(c->d_confs, confs, (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream));
+        else HIP_TRY(c, hipMemsetAsync(c->d_confs, 0, (size_t)c->N * 8, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->assign_valid = true;
+    return SIT_OK;
+}
+
+#define JUMP_NONE ((i64)0x8000000000000000ull)
+
+// One lane per ion walks the frames in order (the forward fill is a running state); loads are
+// issued eight frames ahead of the dependent logic so that HBM latency overlaps.
+__global__ void k_jump_sources(const i64 *labels, i64 F, i64 M, int unknown_as_jump, const i64 *last_in,
+                               i64 *from, i64 *last_out)
+{
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    i64 last;
+    i64 f = 0;
+    if (last_in) last = last_in[j];
+    else { last = F > 0 ? labels[j] : -1; if (F > 0) from[j] = JUMP_NONE; f = 1; }
+    for (; f < F; f += 8) {
+        i64 cur[8];
+        const int nb = (int)((F - f) < 8 ? (F - f) : 8);
+#pragma unroll
+        for (int q = 0; q < 8; q++) cur[q] = q < nb ? labels[(f + q) * M + j] : -1;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (q >= nb) break;
+            const bool known = unknown_as_jump ? true : (cur[q] != -1);
+            const bool jumped = (cur[q] != last) && known;
+            from[(f + q) * M + j] = jumped ? last : JUMP_NONE;
+            if (known) last = cur[q];
+        }
+    }
+    if (last_out) last_out[j] = last;
+}
+
+extern "C" int sit_jump_sources(sit_ctx *c, int unknown_as_jump, const i64 *last_known_in, i64 *from, i64 *last_known_out)
+{
+    if (!c || !from) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->assign_valid, "sit_jump_sources: assignments needed");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 N = c->N, M = c->M;
+    int rc = ensure_scratch(c, (N + 2 * M) * 8);
+    if (rc) return rc;
+    i64 *dfrom = (i64 *)c->d_scratch, *din = dfrom + N, *dout = din + M;
+    if (last_known_in) HIP_TRY(c, hipMemcpyAsync(din, last_known_in, (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
+    k_jump_sources<<<dim3((unsigned)((M + 63) / 64)), dim3(64), 0, c->stream>>>(
+        c->d_labels, c->F, M, unknown_as_jump, last_known_in ? din : nullptr, dfrom, dout);
+    HIP_TRY(c, hipGetLastError());
+    if (N > 0) HIP_TRY(c, hipMemcpyAsync(from, dfrom, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (last_known_out) HIP_TRY(c, hipMemcpyAsync(last_known_out, dout, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}

@@ -1,0 +1,258 @@
+"""``LandmarkAnalysis``: the operator surface of the reference's landmark analysis
+(``sitator/landmark/LandmarkAnalysis.py:29-318``) over the MI355X-native hot path.
+
+Same constructor keywords, same ``run(sn, frames) -> SiteTrajectory``, same post-run attributes
+and the same exceptions; the work happens in hand-written HIP kernels behind the C-ABI of
+``include/sitator_hip.h``:
+
+    frames (HBM)  --fill-->  sparse landmark rows  --cluster plugin-->  labels / confidences
+                  (wrap + static-lattice check fused)     (fit / predict / Gram on device)
+    --> site centres (two reductions) --> occupancy check --> SiteTrajectory
+
+Extra, reference-preserving keywords: ``comm`` (frame sharding across GPUs, see ``sharding.py``)
+and ``device``.
+"""
+import importlib
+import logging
+
+import numpy as np
+
+from . import _lib, errors
+from .dotprod_classifier import LandmarkVectors
+from .pbc import PBCCalculator
+from .sharding import Comm
+from .site_network import SiteNetwork
+from .site_trajectory import SiteTrajectory
+
+logger = logging.getLogger(__name__)
+
+_I64MAX = np.iinfo(np.int64).max
+
+
+class LandmarkAnalysis(object):
+    """Site analysis of mobile atoms in a static lattice with landmark analysis.
+
+    Keyword arguments and defaults are those of the reference (``LandmarkAnalysis.py:95-108``):
+    ``clustering_algorithm`` ('dotprod' | 'mcl' | any module in ``sitator_amd.cluster``),
+    ``clustering_params``, ``cutoff_midpoint``, ``cutoff_steepness``, ``minimum_site_occupancy``,
+    ``site_centers_method``, ``check_for_zero_landmarks``, ``static_movement_threshold``,
+    ``dynamic_lattice_mapping``, ``relaxed_lattice_checks``, ``max_mobile_per_site``,
+    ``force_no_memmap`` (accepted, meaningless here: rows stay sparse in HBM), ``verbose``.
+    """
+
+    SITE_CENTERS_REAL_UNWEIGHTED = "real-unweighted"
+    SITE_CENTERS_REAL_WEIGHTED = "real-weighted"
+    SITE_CENTERS_REPRESENTATIVE_LANDMARK = "representative-landmark"
+
+    CLUSTERING_CLUSTER_SIZE = "cluster-size"
+    CLUSTERING_LABELS = "cluster-labels"
+    CLUSTERING_CONFIDENCES = "cluster-confs"
+    CLUSTERING_LANDMARK_GROUPINGS = "cluster-landmark-groupings"
+    CLUSTERING_REPRESENTATIVE_LANDMARKS = "cluster-representative-lvecs"
+
+    def __init__(self, clustering_algorithm="dotprod", clustering_params={}, cutoff_midpoint=1.5,
+                 cutoff_steepness=30, minimum_site_occupancy=0.01,
+                 site_centers_method=SITE_CENTERS_REAL_WEIGHTED, check_for_zero_landmarks=True,
+                 static_movement_threshold=1.0, dynamic_lattice_mapping=False,
+                 relaxed_lattice_checks=False, max_mobile_per_site=1, force_no_memmap=False,
+                 verbose=True, comm=None, device=None):
+        self._cutoff_midpoint = cutoff_midpoint
+        self._cutoff_steepness = cutoff_steepness
+        self._minimum_site_occupancy = minimum_site_occupancy
+        self._cluster_algo = clustering_algorithm
+        self._clustering_params = clustering_params
+        self.verbose = verbose
+        self.check_for_zero_landmarks = check_for_zero_landmarks
+        self.site_centers_method = site_centers_method
+        self.dynamic_lattice_mapping = dynamic_lattice_mapping
+        self.relaxed_lattice_checks = relaxed_lattice_checks
+        self.static_movement_threshold = static_movement_threshold
+        self.max_mobile_per_site = max_mobile_per_site
+        self.force_no_memmap = force_no_memmap
+        self._comm = comm if comm is not None else Comm()
+        self._device = device
+        self._landmark_vectors = None
+        self._landmark_dimension = None
+        self._ctx = None
+        self._has_run = False
+        self.timings = {}
+
+    # -- results (ValueError before run(), as the reference's `analysis_result`, :20-27) ------
+    def _need_run(self):
+        if not self._has_run:
+            raise ValueError("This LandmarkAnalysis hasn't been run yet.")
+
+    @property
+    def landmark_vectors(self):
+        """Dense (n_frames * n_mobile, landmark_dimension) landmark vectors of this rank, read-only."""
+        self._need_run()
+        dense = np.asarray(self._landmark_vectors)
+        dense.flags.writeable = False
+        return dense
+
+    @property
+    def landmark_dimension(self):
+        self._need_run()
+        return self._landmark_dimension
+
+    # -- the operator ----------------------------------------------------------------------------
+    def run(self, sn, frames):
+        """Landmark analysis of ``frames`` (n_frames x n_atoms x 3, may be unwrapped; not modified)
+        against the landmark basis ``sn`` (centres + vertices).  Returns a ``SiteTrajectory``."""
+        assert isinstance(sn, SiteNetwork) or all(hasattr(sn, a) for a in ("static_mask", "mobile_mask", "centers", "vertices"))
+        if self._has_run:
+            raise ValueError("Cannot rerun LandmarkAnalysis!")
+        if frames.shape[1:] != (sn.n_total, 3):
+            raise ValueError("Wrong shape %s for frames." % (frames.shape,))
+        if sn.vertices is None:
+            raise ValueError("Input SiteNetwork must have vertices")
+        if frames.dtype != np.float64:
+            raise ValueError("Buffer dtype mismatch, expected 'double' but got '%s'" % frames.dtype)
+        comm = self._comm
+        n_frames = len(frames)
+        logger.info("--- Running Landmark Analysis ---")
+
+        ctx = _lib.HipContext(np.asarray(sn.structure.cell, dtype=np.float64), device=self._device)
+        self._ctx = ctx
+        self._pbcc = PBCCalculator(np.asarray(sn.structure.cell, dtype=np.float64), _ctx=ctx)
+
+        # Step 1: landmark centre -> vertex distances in the reference structure (:194-202)
+        self._landmark_dimension = sn.n_sites
+        ref_static = np.asarray(sn.static_structure.get_positions(), dtype=np.float64)
+        widest = max(len(v) for v in sn.vertices)
+        verts_np = np.full((sn.n_sites, widest), -1, dtype=np.int64)
+        site_vert_dists = np.full(verts_np.shape, np.nan)
+        for i, polyhedron in enumerate(sn.vertices):
+            polyhedron = np.asarray(polyhedron, dtype=np.int64)
+            verts_np[i, :len(polyhedron)] = polyhedron
+            site_vert_dists[i, :len(polyhedron)] = self._pbcc.distances(sn.centers[i], ref_static[polyhedron])
+        ctx.set_basis(ref_static, verts_np, site_vert_dists, self._cutoff_midpoint, self._cutoff_steepness,
+                      self.static_movement_threshold)
+
+        # Steps 0 + 2: frames to HBM; wrap, static-lattice check and landmark vectors in one pass
+        frame0 = 0
+        if comm.size > 1:
+            counts = comm.allgather(np.array([n_frames], dtype=np.int64))[:, 0]
+            frame0 = int(np.sum(counts[:comm.rank]))
+        static_idx = np.where(sn.static_mask)[0]
+        mobile_idx = np.where(sn.mobile_mask)[0]
+        ctx.set_frames(frames, static_idx, mobile_idx, frame0=frame0)
+        logger.info("  - computing landmark vectors -")
+        rc, n_zero, err = ctx.fill(self.dynamic_lattice_mapping, self.relaxed_lattice_checks,
+                                   self.check_for_zero_landmarks)
+        self._raise_fill_error(ctx, comm, rc, err)
+        self.n_all_zero_lvecs = int(comm.allreduce_sum(np.array([n_zero], dtype=np.int64))[0]) \
+            if comm.size > 1 else n_zero
+        if not self.check_for_zero_landmarks and self.n_all_zero_lvecs > 0:
+            logger.warning("     Had %i all-zero landmark vectors; no error because `check_for_zero_landmarks = False`."
+                           % self.n_all_zero_lvecs)
+        self._landmark_vectors = LandmarkVectors(ctx, comm)
+
+        # Step 3: cluster (plugin located by name, :234-242)
+        logger.info("  - clustering landmark vectors -")
+        clustermod = importlib.import_module(".cluster." + self._cluster_algo, package=__package__)
+        clustering = clustermod.do_landmark_clustering(
+            self._landmark_vectors, clustering_params=self._clustering_params,
+            min_samples=self._minimum_site_occupancy / float(sn.n_mobile), verbose=self.verbose)
+
+        cluster_counts = clustering[self.CLUSTERING_CLUSTER_SIZE]
+        lmk_lbls = clustering[self.CLUSTERING_LABELS]
+        lmk_confs = clustering[self.CLUSTERING_CONFIDENCES]
+        landmark_clusters = clustering.get(self.CLUSTERING_LANDMARK_GROUPINGS)
+        if landmark_clusters is not None:
+            assert len(cluster_counts) == len(landmark_clusters)
+        rep_lvecs = clustering.get(self.CLUSTERING_REPRESENTATIVE_LANDMARKS)
+        if rep_lvecs is not None:
+            rep_lvecs = np.asarray(rep_lvecs)
+            assert rep_lvecs.shape == (len(cluster_counts), self._landmark_dimension)
+        self.cluster_centers_ = rep_lvecs          # site centres in landmark space (extra attribute)
+        if len(lmk_lbls):
+            logger.info("    Failed to assign %i%% of mobile particle positions to sites."
+                        % (100.0 * np.sum(lmk_lbls < 0) / float(len(lmk_lbls))))
+        lmk_lbls = lmk_lbls.reshape(n_frames, sn.n_mobile)
+        lmk_confs = lmk_confs.reshape(n_frames, sn.n_mobile)
+
+        n_sites = len(cluster_counts)
+        if n_sites < (sn.n_mobile / self.max_mobile_per_site):
+            raise errors.InsufficientSitesError(verb="Landmark analysis", n_sites=n_sites, n_mobile=sn.n_mobile)
+        logger.info("    Identified %i sites with assignment counts %s" % (n_sites, cluster_counts))
+
+        # Output network: site centres (:276-299)
+        out_sn = sn.copy()
+        out_sn.centers = self._site_centers(ctx, comm, sn, n_sites, rep_lvecs)
+        if landmark_clusters is not None:                                  # :301-305
+            out_sn.vertices = [set.union(*[set(sn.vertices[l]) for l in lclust]) for lclust in landmark_clusters]
+
+        out_st = SiteTrajectory(out_sn, lmk_lbls, lmk_confs, _ctx=ctx, _comm=comm)
+        self.n_multiple_assignments, self.avg_mobile_per_site = out_st.check_multiple_occupancy(
+            max_mobile_per_site=self.max_mobile_per_site)
+        out_st.set_real_traj(frames)
+        self.timings = ctx.timers()
+        self._has_run = True
+        return out_st
+
+    # -- helpers -----------------------------------------------------------------------------------
+    def _raise_fill_error(self, ctx, comm, rc, err):
+        """Map the first offender (in the reference's frame/index order, across ranks) to the
+        reference's exceptions (``landmark/helpers.pyx:76-92,116-118``)."""
+        if rc in (_lib.E_INVALID, _lib.E_HIP, _lib.E_CAPACITY):
+            ctx._check(rc)
+        kind, frame, index = (rc, err.frame, err.index) if rc != _lib.OK else (0, _I64MAX, 0)
+        owner = comm.rank
+        if comm.size > 1:
+            allk = comm.allgather(np.array([frame, kind, index], dtype=np.int64))
+            owner = int(np.argmin(allk[:, 0]))        # frames are disjoint across ranks
+            frame, kind, index = (int(v) for v in allk[owner])
+        if kind == 0:
+            return
+        if kind == _lib.E_STATIC_THRESHOLD:
+            raise errors.StaticLatticeError(
+                "No static atom position within %f A threshold of static lattice position %i"
+                % (self.static_movement_threshold, index), lattice_atoms=[int(index)], frame=int(frame),
+                try_recentering=True)
+        if kind == _lib.E_STATIC_UNASSIGNED:
+            missing = np.zeros(0, dtype=np.int64)
+            if owner == comm.rank:
+                missing = np.where(ctx.static_seen(frame - ctx.frame0) == 0)[0]
+            if comm.size > 1:
+                missing = comm.bcast(missing, root=owner)
+            raise errors.StaticLatticeError(
+                "At frame %i, static positions of atoms %s not assigned to lattice positions" % (frame, missing),
+                lattice_atoms=missing, frame=int(frame), try_recentering=True)
+        if kind == _lib.E_ZERO_LANDMARK:
+            raise errors.ZeroLandmarkError(mobile_index=int(index), frame=int(frame))
+        raise RuntimeError("unexpected device status %d" % kind)
+
+    def _site_centers(self, ctx, comm, sn, n_sites, rep_lvecs):
+        method = self.site_centers_method
+        if method in (self.SITE_CENTERS_REAL_WEIGHTED, self.SITE_CENTERS_REAL_UNWEIGHTED):
+            # PBCCalculator.average per site as two device reductions (util/PBCCalculator.pyx:106-139):
+            # anchor = first point of maximal weight, then weighted sums of points wrapped about it.
+            weighted = method == self.SITE_CENTERS_REAL_WEIGHTED
+            wmax, first, anchors = ctx.site_anchors(n_sites, weighted)
+            if comm.size > 1:
+                allw = comm.allgather(wmax)
+                allf = comm.allgather(first)
+                alla = comm.allgather(anchors)
+                allf = np.where(allf < 0, _I64MAX, allf)
+                top = allw.max(axis=0)
+                cand = np.where(allw == top[None, :], allf, _I64MAX)
+                owner = np.argmin(cand, axis=0)
+                anchors = alla[owner, np.arange(n_sites)]
+            sums = ctx.site_sums(n_sites, weighted, anchors)
+            if comm.size > 1:
+                sums = comm.allreduce_sum(sums)
+            offset = ctx.cell_centroid[None, :] - anchors
+            centers = sums[:, 1:] / sums[:, :1] - offset
+            self._pbcc.wrap_points(centers)
+            return centers
+        if method == self.SITE_CENTERS_REPRESENTATIVE_LANDMARK:
+            if rep_lvecs is None:
+                raise ValueError("Chosen clustering method (with current parameters) didn't return representative "
+                                 "landmark vectors; can't use SITE_CENTERS_REPRESENTATIVE_LANDMARK.")
+            centers = np.empty((n_sites, 3))
+            for site in range(n_sites):
+                nonzero = rep_lvecs[site] > 0
+                centers[site] = self._pbcc.average(np.asarray(sn.centers)[nonzero], weights=rep_lvecs[site, nonzero])
+            return centers
+        raise ValueError("Invalid site centers method '%s'" % method)

@@ -1,0 +1,201 @@
+"""``SiteTrajectory``: the output type of ``LandmarkAnalysis.run`` (reference:
+``sitator/SiteTrajectory.py``).  The parts on the landmark path are provided - constructor
+(:15-42), occupancy check (:205-232), real-trajectory association (:120-137), per-particle /
+per-site accessors (:140-184) and the jump iterators (:307-373) - with the occupancy check and
+the jump forward-fill evaluated by HIP kernels on the (device-resident) label array.
+Plotting hooks are out of scope.
+"""
+import numpy as np
+
+from . import _lib, errors
+
+
+class SiteTrajectory(object):
+    """Site assignment of every mobile particle in every frame."""
+
+    SITE_UNKNOWN = -1
+
+    def __init__(self, site_network, particle_assignments, confidences=None, _ctx=None, _comm=None):
+        particle_assignments = np.asarray(particle_assignments)
+        if particle_assignments.ndim != 2:
+            raise ValueError("particle_assignments must be 2D")
+        if particle_assignments.shape[1] != site_network.n_mobile:
+            raise ValueError("particle_assignments has wrong shape %s" % (particle_assignments.shape,))
+        if confidences is not None and confidences.shape != particle_assignments.shape:
+            raise ValueError("confidences has wrong shape %s; should be %s" % (confidences.shape, particle_assignments.shape))
+        self._sn = site_network
+        self._traj = particle_assignments.copy()
+        self._confs = confidences
+        self._real_traj = None
+        # device context whose resident assignments equal self._traj (set by LandmarkAnalysis)
+        self._ctx = _ctx
+        self._comm = _comm
+
+    # -- container protocol ---------------------------------------------------------------
+    def __len__(self):
+        return self.n_frames
+
+    def __getitem__(self, key):
+        st = type(self)(self._sn, self._traj[key], confidences=None if self._confs is None else self._confs[key])
+        if self._real_traj is not None:
+            st.set_real_traj(self._real_traj[key])
+        return st
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_real_traj"] = None          # trajectories are not pickled (reference :55-63)
+        state["_ctx"] = None
+        state["_comm"] = None
+        return state
+
+    # -- plain accessors --------------------------------------------------------------------
+    @property
+    def traj(self):
+        return self._traj
+
+    @property
+    def confidences(self):
+        return self._confs
+
+    @property
+    def n_frames(self):
+        return len(self._traj)
+
+    @property
+    def n_unassigned(self):
+        return int(np.sum(self._traj < 0))
+
+    @property
+    def n_assigned(self):
+        return self._sn.n_mobile * self.n_frames - self.n_unassigned
+
+    @property
+    def percent_unassigned(self):
+        return float(self.n_unassigned) / (self._sn.n_mobile * self.n_frames)
+
+    @property
+    def site_network(self):
+        return self._sn
+
+    @site_network.setter
+    def site_network(self, value):
+        assert np.all(value.mobile_mask == self._sn.mobile_mask)
+        assert np.all(value.static_mask == self._sn.static_mask)
+        self._sn = value
+
+    @property
+    def real_trajectory(self):
+        return self._real_traj
+
+    def copy(self):
+        st = self[:]
+        st.site_network = st.site_network.copy()
+        return st
+
+    def set_real_traj(self, real_traj):
+        """Associate (without copying) the real-space trajectory, shape (n_frames, n_total, 3)."""
+        expected = (self.n_frames, self._sn.n_total, 3)
+        if real_traj.shape != expected:
+            raise ValueError("real_traj of shape %s does not have expected shape %s" % (real_traj.shape, expected))
+        self._real_traj = real_traj
+
+    def remove_real_traj(self):
+        self._real_traj = None
+
+    def trajectory_for_particle(self, i, return_confidences=False):
+        if return_confidences and self._confs is None:
+            raise ValueError("This SiteTrajectory has no confidences")
+        if return_confidences:
+            return self._traj[:, i], self._confs[:, i]
+        return self._traj[:, i]
+
+    def real_positions_for_site(self, site, return_confidences=False):
+        if self._real_traj is None:
+            raise ValueError("This SiteTrajectory has no real trajectory")
+        if return_confidences and self._confs is None:
+            raise ValueError("This SiteTrajectory has no confidences")
+        assert site < self._sn.n_sites
+        sel = self._traj == site
+        pts = self._real_traj[:, self._sn.mobile_mask][sel]
+        if return_confidences:
+            return pts, self._confs[sel].flatten()
+        return pts
+
+    def compute_site_occupancies(self):
+        """Fraction of frames each site is occupied (can exceed 1 under multiple occupancy)."""
+        return np.true_divide(np.bincount(self._traj[self._traj >= 0], minlength=self._sn.n_sites), self.n_frames)
+
+    # -- device-backed pieces ----------------------------------------------------------------
+    def _device(self):
+        """A context holding this trajectory's labels (uploads them if it has none)."""
+        if self._ctx is None:
+            cell = self._sn.structure.cell
+            self._ctx = _lib.HipContext(np.asarray(cell, dtype=np.float64))
+            self._ctx.set_assignments(self._traj, self._confs)
+        return self._ctx
+
+    def _invalidate_device(self):
+        self._ctx = None
+
+    def check_multiple_occupancy(self, max_mobile_per_site=1):
+        """Count frames x sites holding more than one mobile atom; raise past the allowed maximum.
+
+        Returns ``(n_multiple_assignments, avg_mobile_per_site)`` as the reference (:205-232)."""
+        ctx = self._device()
+        K = max(int(self._sn.n_sites), 1)
+        rc, n_multi, total, nsites, err = ctx.check_occupancy(K, max_mobile_per_site)
+        comm = self._comm
+        if comm is not None and comm.size > 1:
+            key = np.array([err.frame if rc == _lib.E_MULTIPLE_OCCUPANCY else np.iinfo(np.int64).max,
+                            err.index if rc == _lib.E_MULTIPLE_OCCUPANCY else 0], dtype=np.int64)
+            keys = comm.allgather(key)
+            first = int(np.argmin(keys[:, 0]))
+            if keys[first, 0] != np.iinfo(np.int64).max:
+                frame, site = int(keys[first, 0]), int(keys[first, 1])
+                local = frame - ctx.frame0
+                mob = np.where(self._traj[local] == site)[0] if 0 <= local < self.n_frames else np.array([], dtype=int)
+                raise errors.MultipleOccupancyError(mobile=mob, site=site, frame=frame)
+            tot = comm.allreduce_sum(np.array([n_multi, total, nsites], dtype=np.int64))
+            n_multi, total, nsites = (int(v) for v in tot)
+        elif rc == _lib.E_MULTIPLE_OCCUPANCY:
+            local = err.frame - ctx.frame0
+            raise errors.MultipleOccupancyError(mobile=np.where(self._traj[local] == err.index)[0],
+                                                site=int(err.index), frame=int(err.frame))
+        elif rc != _lib.OK:
+            ctx._check(rc)
+        return n_multi, total / nsites
+
+    def _jump_arrays(self, unknown_as_jump=False):
+        """(frames, atoms, from_sites, to_sites) of every jump, frame-major, from the device scan."""
+        ctx = self._device()
+        last_in = None
+        comm = self._comm
+        if comm is not None and comm.size > 1:
+            # forward-filled state flows from shard to shard in frame order
+            last_in = None
+            for r in range(comm.size):
+                if comm.rank == r:
+                    src, last_out = ctx.jump_sources(unknown_as_jump, last_in)
+                else:
+                    last_out = np.zeros(self._sn.n_mobile, dtype=np.int64)
+                last_out = comm.bcast(last_out, root=r)
+                if comm.rank == r + 1:
+                    last_in = last_out
+        else:
+            src, _ = ctx.jump_sources(unknown_as_jump, None)
+        f, a = np.nonzero(src != ctx.JUMP_NONE)
+        return f, a, src[f, a], self._traj[f, a]
+
+    def jumps(self, **kwargs):
+        """Yield ``(frame, mobile_atom, from_site, to_site)`` for every jump (reference :307-329)."""
+        f, a, fr, to = self._jump_arrays(**kwargs)
+        for i in range(len(f)):
+            yield int(f[i]), int(a[i]), int(fr[i]), int(to[i])
+
+    def jumps_by_frame(self, **kwargs):
+        """Yield ``(frame, atoms_that_jumped, from_sites, to_sites)`` for frames 1.. (reference :331-345)."""
+        f, a, fr, to = self._jump_arrays(**kwargs)
+        bounds = np.searchsorted(f, np.arange(1, self.n_frames + 1))
+        for frame in range(1, self.n_frames):
+            lo, hi = bounds[frame - 1], bounds[frame]
+            yield frame, a[lo:hi], fr[lo:hi], to[lo:hi]

@@ -1,0 +1,181 @@
+"""GPU parity tests: the HIP path (through the C-ABI / the Python operator surface) against
+(1) the golden vectors of the TRUE reference and (2) the CPU oracle on fresh seeded inputs.
+
+Bars (BASELINE.json north_star): integer site indices, counts, error attributes: bit-exact;
+landmark vectors / confidences / site centres: 1e-6 relative (observed ~1e-14).
+"""
+import json
+
+import numpy as np
+import pytest
+
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+def make_sn(c):
+    from sitator_amd import SiteNetwork, Structure
+    sn = SiteNetwork(Structure(c.ref_positions, c.cell), c.static_mask, c.mobile_mask)
+    sn.centers = c.centers
+    sn.vertices = c.vertices
+    return sn
+
+
+_cases = {}
+
+
+def case(name):
+    if name not in _cases:
+        _cases[name] = G.Case(name)
+    return _cases[name]
+
+
+def assert_lvecs(mine, ref):
+    assert mine.shape == ref.shape
+    assert np.array_equal(mine != 0, ref != 0), "sparsity pattern of the landmark vectors differs"
+    np.testing.assert_allclose(mine, ref, rtol=RTOL, atol=0)
+
+
+def test_pbc_surface_against_reference():
+    from sitator_amd import PBCCalculator
+    z = G.load("pbc_known_answers")
+    for name in ("ortho", "hex", "tri"):
+        pb = PBCCalculator(z[name + "/cell"])
+        assert np.array_equal(pb.cell_centroid, z[name + "/centroid"])
+        pts = z[name + "/pts"].copy()
+        pb.wrap_points(pts)
+        np.testing.assert_allclose(pts, z[name + "/wrapped"], rtol=1e-12, atol=1e-12)
+        d = pb.distances(z[name + "/pt1"], z[name + "/pts2"])
+        np.testing.assert_allclose(d, z[name + "/dists"], rtol=1e-12)
+        np.testing.assert_allclose(pb.average(z[name + "/cloud"]), z[name + "/avg"], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(pb.average(z[name + "/cloud"], z[name + "/weights"]),
+                                   z[name + "/avg_weighted"], rtol=0, atol=1e-10)
+
+
+def test_dotprod_classifier_against_reference():
+    from sitator_amd import DotProdClassifier
+    z = G.load("dotprod_known_answers")
+    X = z["X"]
+    for tag, thr in (("t045", 0.45), ("t090", 0.9)):
+        clf = DotProdClassifier(threshold=thr, min_samples=1)
+        clf.fit_centers(X[z[tag + "/fit_input_rows"]])
+        assert clf.cluster_centers.shape == z[tag + "/centers"].shape
+        np.testing.assert_allclose(clf.cluster_centers, z[tag + "/centers"], rtol=1e-9, atol=1e-14)
+    for tag in ("fp_int", "fp_float", "fp_raw"):
+        p = json.loads(str(z[tag + "/params"]))
+        clf = DotProdClassifier(threshold=p["threshold"], min_samples=p["min_samples"])
+        lab, conf, info = clf.fit_predict(X, predict_threshold=p["predict_threshold"], predict_normed=p["normed"],
+                                          return_info=True, verbose=False)
+        assert np.array_equal(lab, z[tag + "/labels"])
+        assert np.array_equal(clf.cluster_counts, z[tag + "/counts"])
+        assert np.array_equal(info["kept_clusters_mask"], z[tag + "/mask"])
+        m = lab >= 0
+        np.testing.assert_allclose(conf[m], z[tag + "/confs"][m], rtol=RTOL)
+        np.testing.assert_allclose(clf.cluster_centers, z[tag + "/centers"], rtol=1e-9, atol=1e-14)
+    clf = DotProdClassifier(threshold=0.45, min_samples=1)
+    clf.fit_centers(z["quirk/X"])          # zero vectors fold into cluster 0 (NaN argmax)
+    assert clf.cluster_centers.shape == z["quirk/centers"].shape
+    np.testing.assert_allclose(clf.cluster_centers, z["quirk/centers"], rtol=1e-9, atol=1e-14)
+
+
+@pytest.mark.parametrize("name,tag", G.all_runs())
+def test_operator_against_reference_golden(name, tag):
+    from sitator_amd import LandmarkAnalysis, errors
+    c = case(name)
+    exp = c.out(tag)
+    la = LandmarkAnalysis(verbose=False, **c.kwargs(tag))
+    frames_before = c.frames.copy()
+    if "error_type" in exp:
+        et = str(exp["error_type"])
+        cls = {"StaticLatticeError": errors.StaticLatticeError, "ZeroLandmarkError": errors.ZeroLandmarkError,
+               "MultipleOccupancyError": errors.MultipleOccupancyError,
+               "NameError": errors.InsufficientSitesError}[et]     # reference bug: missing import
+        with pytest.raises(cls) as ei:
+            la.run(make_sn(c), c.frames)
+        e = ei.value
+        if "error_frame" in exp:
+            assert e.frame == int(exp["error_frame"])
+        if "error_lattice_atoms" in exp:
+            assert list(np.atleast_1d(e.lattice_atoms)) == list(np.atleast_1d(exp["error_lattice_atoms"]))
+        if "error_mobile_index" in exp:
+            assert e.mobile_index == int(exp["error_mobile_index"])
+        if "error_site" in exp:
+            assert e.site == int(exp["error_site"])
+            assert list(e.mobile_particles) == list(exp["error_mobile_particles"])
+        return
+    st = la.run(make_sn(c), c.frames)
+    assert np.array_equal(c.frames, frames_before), "input frames must not be modified"
+    assert st.real_trajectory is c.frames
+    assert_lvecs(la.landmark_vectors, exp["lvecs"])
+    assert la.n_all_zero_lvecs == int(exp["n_all_zero_lvecs"])
+    assert st.traj.dtype == np.int64
+    assert np.array_equal(st.traj, exp["labels"]), "site indices must be bit-identical"
+    assert np.array_equal(np.bincount(st.traj[st.traj >= 0], minlength=st.site_network.n_sites), exp["counts"])
+    m = exp["labels"] >= 0
+    np.testing.assert_allclose(st.confidences[m], exp["confs"][m], rtol=RTOL)
+    np.testing.assert_allclose(st.site_network.centers, exp["site_centers"], rtol=RTOL, atol=1e-8)
+    assert la.n_multiple_assignments == int(exp["n_multiple_assignments"])
+    assert la.avg_mobile_per_site == pytest.approx(float(exp["avg_mobile_per_site"]), rel=1e-12)
+    assert list(st.jumps()) == [tuple(r) for r in exp["jumps"]]
+    assert list(st.jumps(unknown_as_jump=True)) == [tuple(r) for r in exp["jumps_unknown"]]
+    if "site_vertices" in exp:
+        assert [sorted(v) for v in st.site_network.vertices] == G.vertices_of(exp["site_vertices"])
+    with pytest.raises(ValueError):
+        la.run(make_sn(c), c.frames)          # one-shot, as the reference
+
+
+def test_step1_and_wrap_against_reference():
+    from sitator_amd import PBCCalculator
+    for name in ("c1_hex_scgrid", "c1b_tri_bcctet", "c5_cut_fcc_ragged"):
+        c = case(name)
+        pb = PBCCalculator(c.cell)
+        head = c.frames[:8].reshape(-1, 3).copy()
+        pb.wrap_points(head)
+        np.testing.assert_allclose(head.reshape(c.wrapped_head.shape), c.wrapped_head, rtol=1e-12, atol=1e-12)
+        rs = c.ref_positions[c.static_mask]
+        for k in (0, len(c.vertices) // 2, len(c.vertices) - 1):
+            d = pb.distances(c.centers[k], rs[c.vertices[k]])
+            np.testing.assert_allclose(d, c.site_vert_dists[k, :len(d)], rtol=1e-12)
+
+
+def _oracle_vs_gpu(oracle, host, M, F, seed, algo="dotprod", **kw):
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth
+    frames, sm, mm, ref = synth.make_trajectory(host, M, F, seed=seed)
+    sn = SiteNetwork(Structure(ref, host.cell), sm, mm)
+    sn.centers = host.centers
+    sn.vertices = host.vertices
+    la = LandmarkAnalysis(clustering_algorithm=algo, verbose=False, **kw)
+    st = la.run(sn, frames)
+    exp = oracle.landmark_analysis(host.cell, ref, sm, mm, host.centers, host.vertices, frames,
+                                   clustering_algorithm=algo, **kw)
+    assert_lvecs(la.landmark_vectors, exp["lvecs"])
+    assert np.array_equal(st.traj, exp["labels"])
+    m = exp["labels"] >= 0
+    np.testing.assert_allclose(st.confidences[m], exp["confs"][m], rtol=RTOL)
+    np.testing.assert_allclose(st.site_network.centers, exp["site_centers"], rtol=RTOL, atol=1e-8)
+    assert (la.n_multiple_assignments, la.avg_mobile_per_site) == \
+        (exp["n_multiple_assignments"], pytest.approx(exp["avg_mobile_per_site"], rel=1e-12))
+    return la, st
+
+
+def test_c2_cut_against_oracle(oracle):
+    from sitator_amd import synth
+    _oracle_vs_gpu(oracle, synth.config_host("C2"), 64, 300, seed=202)
+
+
+def test_c4_shaped_cut_against_oracle(oracle):
+    from sitator_amd import synth
+    _oracle_vs_gpu(oracle, synth.config_host("C4"), 256, 12, seed=404)
+
+
+def test_c3_shaped_cut_against_oracle(oracle):
+    from sitator_amd import synth
+    _oracle_vs_gpu(oracle, synth.config_host("C3"), 448, 10, seed=303)
+
+
+def test_triclinic_mcl_against_oracle(oracle):
+    from sitator_amd import synth
+    _oracle_vs_gpu(oracle, synth.config_host("C1b"), 4, 1500, seed=505, algo="mcl")
