@@ -36,9 +36,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=100000, help="frames per GPU")
     ap.add_argument("--config", default="C2")
-    ap.add_argument("--fit-frames", type=int, default=1500)
+    ap.add_argument("--fit-frames", type=int, default=3000)
     ap.add_argument("--cpu-frames", type=int, default=600, help="frames of the CPU-baseline cut (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run() timing on a cut")
+    ap.add_argument("--compare-v1", action="store_true",
+                    help="also time the first-generation kernels (fill + predict), interleaved in this process")
     return ap.parse_args()
 
 
@@ -71,10 +73,12 @@ def main():
     sn.vertices = host.vertices
 
     # --- site centres: the product's own fit on a leading cut (outside the timed region) ---
+    # (a strided sample of the whole trajectory, so that the centres cover every visited site)
     cut = min(F, args.fit_frames)
+    fit_sample = np.ascontiguousarray(frames[::max(1, F // cut)][:cut])
     t0 = time.time()
     la = LandmarkAnalysis(verbose=False, device=local)
-    st_cut = la.run(sn, frames[:cut])
+    st_cut = la.run(sn, fit_sample)
     t_e2e_cut = time.time() - t0
     e2e = {"frames": cut, "seconds": round(t_e2e_cut, 4), "lvec_per_s": round(cut * M / t_e2e_cut, 1),
            "stage_ms": {k: round(v, 3) for k, v in la.timings.items()}, "sites": int(st_cut.site_network.n_sites)}
@@ -98,7 +102,7 @@ def main():
     ctx.set_centers(normed, True)
 
     def step():
-        rc, nz, err = ctx.fill(False, False, True, assign=True, predict_threshold=0.8)
+        rc, nz, err = ctx.fill(False, False, True, assign=True, predict_threshold=0.8, store_rows=False)
         if rc != 0:
             raise RuntimeError("fill failed rc=%d frame=%d index=%d: %s" % (rc, err.frame, err.index, ctx.message()))
 
@@ -126,6 +130,28 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    ab = None
+    if args.compare_v1:
+        os.environ["SITATOR_FILL_KERNEL"] = "1"
+        ctx1 = _lib.HipContext(host.cell, device=local)
+        ctx1.set_basis(ref_static, verts, vcd, 1.5, 30, 1.0)
+        os.environ.pop("SITATOR_FILL_KERNEL")
+        ctx1.set_frames(frames, np.where(gen.static_mask)[0], np.where(gen.mobile_mask)[0], frame0=rank * F)
+        ctx1.set_centers(normed, True)
+        t_v1, t_v2 = [], []
+        for _ in range(max(3, args.steps)):
+            ctx1.fill(False, False, True, assign=True, predict_threshold=0.8)
+            tm = ctx1.timers()
+            t_v1.append(tm["fill"] + tm["predict"])
+            step()
+            t_v2.append(ctx.timers()["fill"])
+        l1, c1, n1 = ctx1.assignments()
+        l2, c2, n2 = ctx.assignments()
+        ab = {"v1_fill_plus_predict_ms": {"median": float(np.median(t_v1)), "min": float(np.min(t_v1))},
+              "v2_fused_ms": {"median": float(np.median(t_v2)), "min": float(np.min(t_v2))},
+              "labels_identical": bool(np.array_equal(l1, l2)), "confs_identical": bool(np.array_equal(c1, c2))}
+        ctx1.close()
 
     labels, confs, counts = ctx.assignments()
     checks = {"unassigned_frac": float(np.mean(labels < 0)), "sites": int(len(counts)),
@@ -162,6 +188,8 @@ def main():
             "end_to_end_cut": e2e,
             "checks": checks,
         }
+        if ab is not None:
+            out["ab_kernels"] = ab
         if args.cpu_frames > 0:
             out["cpu_baseline"] = cpu_baseline(host, gen, frames[:min(F, args.cpu_frames)], ref, fit_ctx_centers, M)
         print(json.dumps(out))

@@ -192,6 +192,11 @@ int sit_jump_sources(sit_ctx *ctx, int unknown_as_jump, const int64_t *last_know
  * [0] fill (+assign)  [1] fit  [2] predict  [3] gram  [4] site centres  [5] occupancy
  * [6] H2D of frames.                                                                      */
 int sit_timers(sit_ctx *ctx, double *ms, int n);
+/* Diagnostics of the pruning tables and the last fill: [0] row width (loose table), [1] mean
+ * candidates per bin (loose), [2] longest tight list, [3] mean candidates per bin (tight),
+ * [4] delta (sampled static displacement bound, A), [5] frames of the last fill that exceeded
+ * delta, [6..8] loose grid, [9..11] tight grid, [12] frames per workgroup of the last fill.   */
+int sit_info(sit_ctx *ctx, double *out, int n);
 int sit_synchronize(sit_ctx *ctx);
 
 #ifdef __cplusplus

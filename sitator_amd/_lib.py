@@ -69,6 +69,7 @@ SIGNATURES = {
     "sit_set_assignments": (C.c_int, [_vp, _ip, _dp, i64, i64, i64]),
     "sit_jump_sources": (C.c_int, [_vp, C.c_int, _ip, _ip, _ip]),
     "sit_timers": (C.c_int, [_vp, _dp, C.c_int]),
+    "sit_info": (C.c_int, [_vp, _dp, C.c_int]),
     "sit_synchronize": (C.c_int, [_vp]),
 }
 
@@ -213,9 +214,9 @@ class HipContext(object):
 
     # -- landmark vectors
     def fill(self, dynamic_lattice_mapping=False, relaxed_lattice_checks=False, check_for_zeros=True,
-             assign=False, predict_threshold=0.0):
-        p = FillParams(int(dynamic_lattice_mapping), int(relaxed_lattice_checks), int(check_for_zeros), 1,
-                       int(assign), 1, float(predict_threshold))
+             assign=False, predict_threshold=0.0, store_rows=True):
+        p = FillParams(int(dynamic_lattice_mapping), int(relaxed_lattice_checks), int(check_for_zeros),
+                       int(store_rows), int(assign), 1, float(predict_threshold))
         nz = i64(0)
         err = SitError()
         rc = self.lib.sit_fill(self._h, C.byref(p), C.byref(nz), C.byref(err))
@@ -359,6 +360,17 @@ class HipContext(object):
         t = np.zeros(8)
         self.lib.sit_timers(self._h, _d(t), 8)
         return dict(zip(["fill", "fit", "predict", "gram", "site_centers", "occupancy", "h2d"], t))
+
+    def info(self):
+        v = np.zeros(13)
+        self.lib.sit_info(self._h, _d(v), 13)
+        keys = ["row_width", "mean_candidates_loose", "tight_width", "mean_candidates_tight", "delta",
+                "fallback_frames"]
+        out = dict(zip(keys, v[:6]))
+        out["grid_loose"] = [int(x) for x in v[6:9]]
+        out["grid_tight"] = [int(x) for x in v[9:12]]
+        out["frames_per_workgroup"] = int(v[12])
+        return out
 
     def synchronize(self):
         self._check(self.lib.sit_synchronize(self._h))

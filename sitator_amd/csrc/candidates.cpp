@@ -54,8 +54,9 @@ bool within_periodic(const Cell &c, const double *d, double T)
 }  // namespace
 
 int sit_build_candidates(sit_ctx *c, const double *ref_static, const i64 *verts, const double *vcd,
-                         std::vector<i32> &bin_off, std::vector<i32> &bin_list)
+                         double displacement, double bin_target, CandidateTable &out)
 {
+    std::vector<i32> &bin_off = out.off, &bin_list = out.list;
     Cell cell;
     for (int i = 0; i < 9; i++) { cell.cm[i] = c->pbc.cm[i]; cell.ci[i] = c->pbc.ci[i]; }
     double len[3];
@@ -66,17 +67,16 @@ int sit_build_candidates(sit_ctx *c, const double *ref_static, const i64 *verts,
         len[i] = std::sqrt(cell.cm[i] * cell.cm[i] + cell.cm[3 + i] * cell.cm[3 + i] + cell.cm[6 + i] * cell.cm[6 + i]);
     }
     const i64 D = c->D, V = c->V;
-    const double bin_target = 1.0;   // Angstrom; DESIGN.md "pruning"
     int G[3];
     for (int i = 0; i < 3; i++) {
         G[i] = (int)std::lround(len[i] / bin_target);
         G[i] = std::max(1, std::min(G[i], 192));
     }
-    while ((i64)G[0] * G[1] * G[2] > 4000000) {
+    while ((i64)G[0] * G[1] * G[2] > 1500000) {
         int m = (G[0] >= G[1] && G[0] >= G[2]) ? 0 : (G[1] >= G[2] ? 1 : 2);
         G[m] = G[m] * 3 / 4;
     }
-    for (int i = 0; i < 3; i++) c->G[i] = G[i];
+    for (int i = 0; i < 3; i++) out.G[i] = G[i];
     // covering radius of a bin: half its longest body diagonal
     double rb = 0;
     for (int sa = -1; sa <= 1; sa += 2)
@@ -95,7 +95,7 @@ int sit_build_candidates(sit_ctx *c, const double *ref_static, const i64 *verts,
         int best = -1;
         for (i64 h = 0; h < V; h++) {
             if (verts[k * V + h] < 0) break;
-            T[h] = c->rz * vcd[k * V + h] * (1.0 + 1e-9) + c->static_thr + rb + 1e-9;
+            T[h] = c->rz * vcd[k * V + h] * (1.0 + 1e-9) + displacement * (1.0 + 1e-9) + rb + 1e-9;
             if (best < 0 || T[h] < T[best]) best = (int)h;
             nv++;
         }
@@ -147,7 +147,7 @@ int sit_build_candidates(sit_ctx *c, const double *ref_static, const i64 *verts,
     bin_list.resize((size_t)std::max<i64>(total, 1));
     for (i64 b = 0; b < nb; b++)
         std::copy(lists[(size_t)b].begin(), lists[(size_t)b].end(), bin_list.begin() + bin_off[(size_t)b]);
-    c->W = W;
-    c->mean_candidates = (double)total / (double)nb;
+    out.W = W;
+    out.mean = (double)total / (double)nb;
     return SIT_OK;
 }

@@ -6,33 +6,6 @@
 
 #include "sit_internal.h"
 
-// ---- a (value, index) maximum with numpy's argmax rules: first maximum, first NaN wins ----
-struct Best {
-    double v;
-    i64 i;       // -1 = empty
-    int nan;
-};
-
-__device__ __forceinline__ Best best_empty() { Best b; b.v = 0; b.i = -1; b.nan = 0; return b; }
-
-__device__ __forceinline__ Best best_merge(const Best &a, const Best &b)
-{
-    if (a.i < 0) return b;
-    if (b.i < 0) return a;
-    if (a.nan || b.nan) {
-        if (a.nan && b.nan) return a.i < b.i ? a : b;
-        return a.nan ? a : b;
-    }
-    if (a.v > b.v) return a;
-    if (b.v > a.v) return b;
-    return a.i < b.i ? a : b;
-}
-
-__device__ __forceinline__ Best best_of(double v, i64 i)
-{
-    Best b; b.v = v; b.i = i; b.nan = isnan(v) ? 1 : 0; return b;
-}
-
 __device__ __forceinline__ Best wave_best(Best b)
 {
     for (int off = 32; off > 0; off >>= 1) {

@@ -1,6 +1,7 @@
 // Context, basis / trajectory residency, and the PBCCalculator parity surface.
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 #include "sit_internal.h"
 
@@ -38,9 +39,9 @@ extern "C" void sit_destroy(sit_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->d_ref_static, c->d_verts, c->d_vcd, c->d_bin_off, c->d_bin_list,
+    void *ptrs[] = {c->d_ref_static, c->d_verts, c->d_vcd, c->d_hi2, c->d_bin_off, c->d_bin_list,
                     c->frames_owned ? c->d_frames : nullptr, c->d_static_idx, c->d_mobile_idx,
-                    c->d_lattice_map, c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs,
+                    c->d_lattice_map, c->d_tbin_off, c->d_tbin_list, c->d_frame_dmax, c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs,
                     c->d_counts, c->d_col_ptr, c->d_col_k, c->d_col_val, c->d_cen_dense, c->d_fit_centers,
                     c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scal, c->d_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -56,6 +57,16 @@ extern "C" int sit_timers(sit_ctx *c, double *ms, int n)
 {
     if (!c || !ms) return SIT_ERR_INVALID;
     for (int i = 0; i < n; i++) ms[i] = i < T_N ? c->timers[i] : 0.0;
+    return SIT_OK;
+}
+
+extern "C" int sit_info(sit_ctx *c, double *out, int n)
+{
+    if (!c || !out) return SIT_ERR_INVALID;
+    const double v[13] = {(double)c->W, c->mean_candidates, (double)c->W_tight, c->tight_mean_candidates,
+                          c->tight_delta, (double)c->fallback_frames, (double)c->G[0], (double)c->G[1],
+                          (double)c->G[2], (double)c->tG[0], (double)c->tG[1], (double)c->tG[2], (double)c->last_fpb};
+    for (int i = 0; i < n; i++) out[i] = i < 13 ? v[i] : 0.0;
     return SIT_OK;
 }
 
@@ -190,10 +201,30 @@ extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const 
     if ((rc = dev_upload(c, &c->d_ref_static, ref_static, S * 3))) return rc;
     if ((rc = dev_upload(c, &c->d_verts, v32.data(), D * V))) return rc;
     if ((rc = dev_upload(c, &c->d_vcd, vcd, D * V))) return rc;
-    std::vector<i32> off, list;
-    if ((rc = sit_build_candidates(c, ref_static, verts, vcd, off, list))) return rc;
-    if ((rc = dev_upload(c, &c->d_bin_off, off.data(), (i64)off.size()))) return rc;
-    if ((rc = dev_upload(c, &c->d_bin_list, list.data(), (i64)list.size()))) return rc;
+    {   // d^2 > hi2  =>  fl(fl(sqrt(d^2)) / vcd) > rz  (three roundings of 2^-53 each << 1e-14)
+        std::vector<double> hi2((size_t)(D * V));
+        for (i64 k = 0; k < D * V; k++) {
+            const double r = c->rz * vcd[k];
+            hi2[(size_t)k] = (vcd[k] == vcd[k]) ? r * r * (1.0 + 1e-14) : 0.0;
+        }
+        if ((rc = dev_upload(c, &c->d_hi2, hi2.data(), D * V))) return rc;
+    }
+    CandidateTable tab;
+    if ((rc = sit_build_candidates(c, ref_static, verts, vcd, static_thr, 1.0, tab))) return rc;
+    if ((rc = dev_upload(c, &c->d_bin_off, tab.off.data(), (i64)tab.off.size()))) return rc;
+    if ((rc = dev_upload(c, &c->d_bin_list, tab.list.data(), (i64)tab.list.size()))) return rc;
+    for (int i = 0; i < 3; i++) c->G[i] = tab.G[i];
+    c->W = tab.W; c->mean_candidates = tab.mean;
+    c->h_ref_static.assign(ref_static, ref_static + 3 * S);
+    c->h_verts.assign(verts, verts + D * V);
+    c->h_vcd.assign(vcd, vcd + D * V);
+    c->cell_diagonal = true;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            if (i != j && (c->pbc.cm[3 * i + j] != 0.0 || c->pbc.ci[3 * i + j] != 0.0)) c->cell_diagonal = false;
+    const char *fk = getenv("SITATOR_FILL_KERNEL");
+    c->fill_kernel = (fk && fk[0] == '1') ? 1 : 2;
+    c->tight_valid = false;
     c->rows_valid = false; c->assign_valid = false; c->map_valid = false;
     return SIT_OK;
 }
@@ -220,7 +251,7 @@ static int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S
     if ((rc = dev_upload(c, &c->d_static_idx, s32.data(), S))) return rc;
     if ((rc = dev_upload(c, &c->d_mobile_idx, m32.data(), M))) return rc;
     c->F = F; c->A = A; c->M = M; c->frame0 = frame0; c->N = F * M;
-    c->rows_valid = false; c->assign_valid = false; c->map_valid = false;
+    c->rows_valid = false; c->assign_valid = false; c->map_valid = false; c->tight_valid = false;
     return SIT_OK;
 }
 

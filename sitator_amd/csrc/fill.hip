@@ -140,6 +140,7 @@ struct MapArgs {
     i32 *lattice_map;
     u64 *err;
     unsigned char *seen_out;   // optional [S] for one frame (sit_static_seen)
+    u64 *frame_dmax_bits;      // optional [F]: max over lattice sites of the matched distance
     i64 F, A, S, M, frame0, only_frame;
     int relaxed;
     double static_thr;
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256) void k_lattice_map(MapArgs a)
         }
         if (a.lattice_map) a.lattice_map[f * S + li] = arg;
         atomicOr(&seen[arg], 1);
+        if (a.frame_dmax_bits) atomicMax(&a.frame_dmax_bits[f], (u64)__double_as_longlong(best));
         if (best > a.static_thr) atomicMin(a.err, err_key(a.frame0 + f, S, a.M, li));
     }
     __syncthreads();
@@ -193,40 +195,31 @@ static int decode_error(sit_ctx *c, u64 key, sit_error *err)
     return kind;
 }
 
-extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, sit_error *err)
+static int launch_lattice_map(sit_ctx *c, const sit_fill_params *p)
 {
-    if (!c || !p) return SIT_ERR_INVALID;
-    SIT_REQUIRE(c, c->D > 0 && c->d_frames && c->M > 0, "sit_fill: basis and frames must be set first");
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
-    const i64 S = c->S, M = c->M, N = c->N, W = c->W;
+    const i64 S = c->S;
     int rc;
-    if (c->rows_W != W || c->rows_N != N || !c->d_row_nnz) {
-        c->rows_valid = false;
-        if ((rc = dev_alloc(c, &c->d_row_nnz, N))) return rc;
-        if ((rc = dev_alloc(c, &c->d_row_idx, N * W))) return rc;
-        if ((rc = dev_alloc(c, &c->d_row_val, N * W))) return rc;
-        c->rows_W = W; c->rows_N = N;
-    }
-    HIP_TRY(c, hipMemsetAsync(c->d_err, 0xFF, sizeof(u64), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream));
-    if (c->F == 0) { if (n_all_zero) *n_all_zero = 0; c->rows_valid = true; return SIT_OK; }
+    if ((rc = dev_alloc(c, &c->d_lattice_map, c->F * S))) return rc;
+    if ((rc = dev_alloc(c, &c->d_frame_dmax, c->F))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_frame_dmax, 0, (size_t)c->F * 8, c->stream));
+    MapArgs m;
+    m.P = c->pbc; m.frames = c->d_frames; m.static_idx = c->d_static_idx; m.ref_static = c->d_ref_static;
+    m.lattice_map = c->d_lattice_map; m.err = c->d_err; m.seen_out = nullptr;
+    m.frame_dmax_bits = (u64 *)c->d_frame_dmax;
+    m.F = c->F; m.A = c->A; m.S = S; m.M = c->M; m.frame0 = c->frame0; m.only_frame = -1;
+    m.relaxed = p->relaxed_lattice_checks; m.static_thr = c->static_thr;
+    const size_t lds = (size_t)S * 28 + 16;
+    SIT_REQUIRE(c, lds <= 160 * 1024, "sit_fill: too many static atoms for the LDS-resident lattice map");
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k_lattice_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_lattice_map<<<dim3((unsigned)c->F), dim3(256), lds, c->stream>>>(m);
+    HIP_TRY(c, hipGetLastError());
+    c->map_valid = true;
+    return SIT_OK;
+}
 
-    StageTimer timer(c, T_FILL);
-    if (p->dynamic_lattice_mapping) {
-        if ((rc = dev_alloc(c, &c->d_lattice_map, c->F * S))) return rc;
-        MapArgs m;
-        m.P = c->pbc; m.frames = c->d_frames; m.static_idx = c->d_static_idx; m.ref_static = c->d_ref_static;
-        m.lattice_map = c->d_lattice_map; m.err = c->d_err; m.seen_out = nullptr;
-        m.F = c->F; m.A = c->A; m.S = S; m.M = M; m.frame0 = c->frame0; m.only_frame = -1;
-        m.relaxed = p->relaxed_lattice_checks; m.static_thr = c->static_thr;
-        const size_t lds = (size_t)S * 28 + 16;
-        SIT_REQUIRE(c, lds <= 160 * 1024, "sit_fill: too many static atoms for the LDS-resident lattice map");
-        HIP_TRY(c, hipFuncSetAttribute((const void *)k_lattice_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_lattice_map<<<dim3((unsigned)c->F), dim3(256), lds, c->stream>>>(m);
-        HIP_TRY(c, hipGetLastError());
-        c->map_valid = true;
-    }
+static int launch_fill_v1(sit_ctx *c, const sit_fill_params *p)
+{
+    const i64 S = c->S, M = c->M;
     FillArgs a;
     a.P = c->pbc; a.frames = c->d_frames; a.static_idx = c->d_static_idx; a.mobile_idx = c->d_mobile_idx;
     a.ref_static = c->d_ref_static; a.verts = c->d_verts; a.vcd = c->d_vcd;
@@ -234,7 +227,7 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
     a.lattice_map = p->dynamic_lattice_mapping ? c->d_lattice_map : nullptr;
     a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx; a.row_val = c->d_row_val;
     a.err = c->d_err; a.zero_count = c->d_scal;
-    a.F = c->F; a.A = c->A; a.S = S; a.M = M; a.D = c->D; a.V = c->V; a.N = N; a.W = W; a.frame0 = c->frame0;
+    a.F = c->F; a.A = c->A; a.S = S; a.M = M; a.D = c->D; a.V = c->V; a.N = c->N; a.W = c->rows_W; a.frame0 = c->frame0;
     a.G0 = c->G[0]; a.G1 = c->G[1]; a.G2 = c->G[2];
     a.check_zeros = p->check_for_zeros;
     a.midpoint = c->midpoint; a.steepness = c->steepness; a.rz = c->rz; a.static_thr = c->static_thr;
@@ -254,17 +247,118 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         k_fill_rows<false><<<dim3(grid), dim3(256), lds, c->stream>>>(a);
     }
     HIP_TRY(c, hipGetLastError());
-    timer.stop();
-    u64 hkey = 0, hzero = 0;
-    HIP_TRY(c, hipMemcpyAsync(&hkey, c->d_err, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&hzero, c->d_scal, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (n_all_zero) *n_all_zero = (i64)hzero;
-    c->rows_valid = true;
-    c->assign_valid = false;
-    const int kind = decode_error(c, hkey, err);
-    if (kind == SIT_OK && p->assign) return sit_predict_internal(c, p->predict_threshold);
-    return kind;
+    return SIT_OK;
+}
+
+// The tight pruning table: candidates for the static displacement actually present.  delta is
+// estimated from a strided sample of frames; every frame's true maximum is measured again inside
+// the fill kernel, and a frame above delta takes the loose table, so delta only steers speed.
+static int ensure_tight_table(sit_ctx *c)
+{
+    if (c->tight_valid) return SIT_OK;
+    std::vector<double> sample;
+    int rc = fill2_sample_dmax(c, sample);
+    if (rc) return rc;
+    double mx = 0.0;
+    for (double d : sample) if (d == d && d <= c->static_thr && d > mx) mx = d;
+    double delta = mx * 1.15 + 0.02;
+    if (delta > c->static_thr) delta = c->static_thr;
+    CandidateTable tab;
+    if ((rc = sit_build_candidates(c, c->h_ref_static.data(), c->h_verts.data(), c->h_vcd.data(), delta, 0.5, tab))) return rc;
+    if (tab.W > 256) {       // F2_WTASK: an ion's tasks must fit one wave batch -> loose table for everything
+        delta = -1.0;
+    }
+    if ((rc = dev_upload(c, &c->d_tbin_off, tab.off.data(), (i64)tab.off.size()))) return rc;
+    if ((rc = dev_upload(c, &c->d_tbin_list, tab.list.data(), (i64)tab.list.size()))) return rc;
+    for (int i = 0; i < 3; i++) c->tG[i] = tab.G[i];
+    c->W_tight = tab.W; c->tight_mean_candidates = tab.mean; c->tight_delta = delta;
+    c->tight_valid = true;
+    return SIT_OK;
+}
+
+__global__ __launch_bounds__(256) void k_label_hist(const i64 *labels, i64 N, i64 K, u64 *counts)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned int *h = (unsigned int *)smem;
+    for (i64 q = threadIdx.x; q < K; q += 256) h[q] = 0;
+    __syncthreads();
+    const i64 per = 8192;
+    const i64 r0 = (i64)blockIdx.x * per, r1 = r0 + per < N ? r0 + per : N;
+    for (i64 r = r0 + threadIdx.x; r < r1; r += 256) {
+        const i64 l = labels[r];
+        if (l >= 0 && l < K) atomicAdd(&h[l], 1u);
+    }
+    __syncthreads();
+    for (i64 q = threadIdx.x; q < K; q += 256) if (h[q]) atomicAdd(&counts[q], (u64)h[q]);
+}
+
+int sit_label_counts(sit_ctx *c)
+{
+    HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
+    if (c->N == 0) return SIT_OK;
+    SIT_REQUIRE(c, c->K * 4 <= 150 * 1024, "too many sites for the LDS label histogram");
+    const size_t lds = (size_t)c->K * 4 + 16;
+    HIP_TRY(c, hipFuncSetAttribute((const void *)k_label_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_label_hist<<<dim3((unsigned)((c->N + 8191) / 8192)), dim3(256), lds, c->stream>>>(c->d_labels, c->N, c->K, (u64 *)c->d_counts);
+    HIP_TRY(c, hipGetLastError());
+    return SIT_OK;
+}
+
+extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, sit_error *err)
+{
+    if (!c || !p) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->D > 0 && c->d_frames && c->M > 0, "sit_fill: basis and frames must be set first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
+    const i64 N = c->N, W = c->W;
+    const bool v2 = c->fill_kernel == 2 && c->W <= 256;   // F2_WTASK
+    bool assign = p->assign != 0;
+    bool store = true;   // rows feed the predict kernel (wave-level fusion: see DESIGN.md)
+    if (assign) SIT_REQUIRE(c, c->K > 0 && c->d_col_ptr, "sit_fill: assign requested but no centres set");
+    int rc;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (store && (c->rows_W != W || c->rows_N != N || !c->d_row_nnz)) {
+            c->rows_valid = false;
+            if ((rc = dev_alloc(c, &c->d_row_nnz, N))) return rc;
+            if ((rc = dev_alloc(c, &c->d_row_idx, N * W))) return rc;
+            if ((rc = dev_alloc(c, &c->d_row_val, N * W))) return rc;
+            c->rows_W = W; c->rows_N = N;
+        }
+        if (assign && (!c->d_labels || c->assign_N != N)) {
+            if ((rc = dev_alloc(c, &c->d_labels, N))) return rc;
+            if ((rc = dev_alloc(c, &c->d_confs, N))) return rc;
+            c->assign_N = N;
+        }
+        if (v2 && c->F > 0 && (rc = ensure_tight_table(c))) return rc;
+        HIP_TRY(c, hipMemsetAsync(c->d_err, 0xFF, sizeof(u64), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream));
+        if (c->F == 0) {
+            if (n_all_zero) *n_all_zero = 0;
+            c->rows_valid = store; c->assign_valid = assign;
+            if (assign) HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
+            return SIT_OK;
+        }
+        StageTimer timer(c, T_FILL);
+        if (p->dynamic_lattice_mapping && (rc = launch_lattice_map(c, p))) return rc;
+        if (v2) rc = fill2_launch(c, p, store, assign, p->predict_threshold);
+        else rc = launch_fill_v1(c, p);
+        if (rc) return rc;
+        timer.stop();
+        u64 hkey = 0, hs[4] = {0, 0, 0, 0};
+        HIP_TRY(c, hipMemcpyAsync(&hkey, c->d_err, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(hs, c->d_scal, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (n_all_zero) *n_all_zero = (i64)hs[0];
+        c->fallback_frames = (i64)hs[2];
+        c->rows_valid = store;
+        c->assign_valid = false;
+        const int kind = decode_error(c, hkey, err);
+        if (kind != SIT_OK) return kind;
+        if (v2 && hs[3]) { c->msg = "landmark row wider than the pruning bound (internal error)"; return SIT_ERR_CAPACITY; }
+        if (!assign) return SIT_OK;
+        return sit_predict_internal(c, p->predict_threshold);
+    }
+    return SIT_ERR_CAPACITY;
 }
 
 extern "C" int sit_static_seen(sit_ctx *c, i64 local_frame, uint8_t *seen)
@@ -278,6 +372,7 @@ extern "C" int sit_static_seen(sit_ctx *c, i64 local_frame, uint8_t *seen)
     MapArgs m;
     m.P = c->pbc; m.frames = c->d_frames; m.static_idx = c->d_static_idx; m.ref_static = c->d_ref_static;
     m.lattice_map = nullptr; m.err = c->d_err; m.seen_out = (unsigned char *)c->d_scratch;
+    m.frame_dmax_bits = nullptr;
     m.F = c->F; m.A = c->A; m.S = c->S; m.M = c->M; m.frame0 = c->frame0; m.only_frame = local_frame;
     m.relaxed = 1; m.static_thr = c->static_thr;
     const size_t lds = (size_t)c->S * 28 + 16;

@@ -1,0 +1,416 @@
+// Landmark-vector fill, second generation (the one `sit_fill` launches by default).
+//
+// Same arithmetic as fill.hip (reference order, FP64, no contraction); what changes is how the
+// work is laid out on the machine:
+//   * a workgroup parks the wrapped statics of `fpb` frames in LDS (phase 1, one barrier) and then
+//     its four waves work on their own 32-ion chunks WITHOUT any further workgroup barrier;
+//   * lanes are (ion, candidate-landmark) TASKS, not ions: a wave flattens the candidate lists of its
+//     ions into a wave-private LDS task list (wave scan), SCREENS every task with squared distances
+//     against (rz*vcd)^2 (any vertex provably beyond the cut-off => component exactly 0), compacts the
+//     survivors with a ballot, and only then runs the full reference evaluation (sqrt, two divisions,
+//     exp, n-th root) one lane per surviving landmark, so those lanes stay converged;
+//   * candidates come from a TIGHT pruning table built for the static displacement actually present
+//     (delta, sampled on the device, see sit_fill) instead of static_movement_threshold; the
+//     per-frame displacement is measured in phase 1 anyway (it is the static-lattice check), and a
+//     frame that exceeds delta takes the loose table, so the result is exact for every frame the
+//     reference accepts;
+//   * diagonal cells skip the exactly-zero terms of the 3x3 products (x*a + y*0 + z*0 == x*a).
+#include <cmath>
+
+#include "sit_internal.h"
+
+#define F2_THREADS 256
+#define F2_IW 32           // ions per wave chunk
+#define F2_WTASK 256       // tasks per wave batch
+
+struct Fill2Args {
+    Pbc P;
+    const double *frames;
+    const i32 *static_idx, *mobile_idx;
+    const double *ref_static;
+    const i32 *verts;
+    const double *vcd;
+    const double *hi2;                // [D,V] squared screening bound: d^2 > hi2 => dist/vcd > rz
+    const i32 *t_off, *t_list;        // tight table
+    const i32 *l_off, *l_list;        // loose table (static_movement_threshold)
+    const i32 *lattice_map;           // [F,S] or null
+    const double *frame_dmax;         // [F] (dynamic mapping only)
+    i32 *row_nnz, *row_idx;
+    double *row_val;                  // null when rows are not stored
+    i64 *labels;
+    double *confs;                    // null when not assigning
+    const i32 *col_ptr, *col_k;
+    const double *col_val;
+    u64 *err, *scal;                  // scal[0] zero rows, [1] predict overflow, [2] fallback frames, [3] row overflow
+    i64 F, A, N, frame0;
+    int S, M, D, V, W;
+    int tG0, tG1, tG2, lG0, lG1, lG2;
+    int fpb;
+    int check_zeros, normed;
+    double midpoint, steepness, rz, delta2, thr2_lo, thr2_hi, static_thr, threshold;
+};
+
+template <int CELL>
+__device__ __forceinline__ void wrapc(const Pbc &P, double &x, double &y, double &z)
+{
+    if (CELL == 1) {        // diagonal cell: the off-diagonal terms are exactly zero
+        double b0 = P.ci[0] * x; b0 -= floor(b0);
+        double b1 = P.ci[4] * y; b1 -= floor(b1);
+        double b2 = P.ci[8] * z; b2 -= floor(b2);
+        x = P.cm[0] * b0; y = P.cm[4] * b1; z = P.cm[8] * b2;
+    } else {
+        wrap3(P, x, y, z);
+    }
+}
+
+template <int CELL>
+__device__ __forceinline__ int bin_of(const Pbc &P, double px, double py, double pz, int G0, int G1, int G2)
+{
+    double f0, f1, f2;
+    if (CELL == 1) { f0 = P.ci[0] * px; f1 = P.ci[4] * py; f2 = P.ci[8] * pz; }
+    else {
+        f0 = (P.ci[0] * px + P.ci[1] * py + P.ci[2] * pz);
+        f1 = (P.ci[3] * px + P.ci[4] * py + P.ci[5] * pz);
+        f2 = (P.ci[6] * px + P.ci[7] * py + P.ci[8] * pz);
+    }
+    f0 -= floor(f0); f1 -= floor(f1); f2 -= floor(f2);
+    int b0 = (int)(f0 * G0), b1 = (int)(f1 * G1), b2 = (int)(f2 * G2);
+    b0 = b0 < 0 ? 0 : (b0 >= G0 ? G0 - 1 : b0);
+    b1 = b1 < 0 ? 0 : (b1 >= G1 ? G1 - 1 : b1);
+    b2 = b2 < 0 ? 0 : (b2 >= G2 ? G2 - 1 : b2);
+    return (b0 * G1 + b1) * G2 + b2;
+}
+
+// squared shift-and-wrap distance of static v from the ion (helpers.pyx:99-103,176 before the sqrt)
+template <int CELL>
+__device__ __forceinline__ double dist2_to(const Pbc &P, const double *fsx, const double *fsy, const double *fsz,
+                                           int v, double ox, double oy, double oz)
+{
+    double qx = fsx[v] + ox, qy = fsy[v] + oy, qz = fsz[v] + oz;
+    wrapc<CELL>(P, qx, qy, qz);
+    const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
+    return (dx * dx + dy * dy) + dz * dz;
+}
+
+// pow(acc, 1.0 / nv) of helpers.pyx:212 for acc in (0, 1]: square-root chains for nv = 1, 2, 4, 8
+// (each sqrt is correctly rounded; 1/nv is exact there), the library pow otherwise.
+__device__ __forceinline__ double nth_root(double acc, int nv)
+{
+    if (nv == 8) return sqrt(sqrt(sqrt(acc)));
+    if (nv == 4) return sqrt(sqrt(acc));
+    if (nv == 2) return sqrt(acc);
+    if (nv == 1) return acc;
+    return pow(acc, 1.0 / nv);
+}
+
+// Stage 1: does any vertex lie provably beyond the cut-off?  Same distances as the reference, compared
+// squared against hi2 = (rz * vcd)^2 * (1 + 1e-14); a "true" here implies the component is exactly 0.
+template <int CELL>
+__device__ __forceinline__ bool screen_landmark(const Fill2Args &a, int k, const double *fsx, const double *fsy,
+                                                const double *fsz, const i32 *lmap, double ox, double oy, double oz)
+{
+    const i32 *vk = a.verts + k * a.V;
+    const double *hk = a.hi2 + k * a.V;
+    i32 vn = vk[0];
+    double hn = hk[0];
+    for (int h = 0; h < a.V; h++) {
+        i32 v = vn;
+        const double hb = hn;
+        if (v < 0) break;
+        if (h + 1 < a.V) { vn = vk[h + 1]; hn = hk[h + 1]; }
+        if (lmap) v = lmap[v];
+        if (dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz) > hb) return true;
+    }
+    return false;
+}
+
+// Stage 2: one landmark component, landmark/helpers.pyx:186-212 (and :174-178 for the distances).
+template <int CELL>
+__device__ __forceinline__ double eval_landmark(const Fill2Args &a, int k, const double *fsx, const double *fsy,
+                                                const double *fsz, const i32 *lmap, double ox, double oy, double oz)
+{
+    const i32 *vk = a.verts + k * a.V;
+    const double *dk = a.vcd + k * a.V;
+    double acc = 1.0;
+    int nv = 0;
+    i32 vn = vk[0];
+    double dn = dk[0];
+    for (int h = 0; h < a.V; h++) {
+        i32 v = vn;
+        const double dkh = dn;
+        if (v < 0) break;
+        if (h + 1 < a.V) { vn = vk[h + 1]; dn = dk[h + 1]; }
+        nv++;
+        if (lmap) v = lmap[v];
+        const double dist = sqrt(dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz));
+        double tt = dist / dkh;
+        if (tt > a.rz) return 0.0;
+        tt = 1.0 / (1.0 + exp(a.steepness * (tt - a.midpoint)));
+        acc *= tt;
+    }
+    return nth_root(acc, nv);
+}
+
+template <int CELL>
+__global__ __launch_bounds__(F2_THREADS) void k_fill2(Fill2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = a.S, M = a.M;
+    const int fpb = a.fpb;
+    double *sx = (double *)smem;
+    double *sy = sx + fpb * S;
+    double *sz = sy + fpb * S;
+    double *mx = sz + fpb * S;
+    double *my = mx + fpb * M;
+    double *mz = my + fpb * M;
+    double *tval_all = mz + fpb * M;                            // [4][WTASK]
+    u64 *fmax = (u64 *)(tval_all + 4 * F2_WTASK);               // [fpb] beyond-delta flags
+    i32 *tk_all = (i32 *)(fmax + fpb);                          // [4][WTASK]
+    unsigned short *surv_all = (unsigned short *)(tk_all + 4 * F2_WTASK);   // [4][WTASK]
+    unsigned char *tion_all = (unsigned char *)(surv_all + 4 * F2_WTASK);   // [4][WTASK]
+    const Pbc &P = a.P;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const i64 f0 = (i64)blockIdx.x * fpb;
+    const int nf = (int)((a.F - f0) < fpb ? (a.F - f0) : fpb);
+    const int SM = S + M;
+    const bool dyn = a.lattice_map != nullptr;
+    const u64 errw = (u64)(S + 1 + M);
+
+    if (tid < fpb) fmax[tid] = 0ull;
+    __syncthreads();
+    // ---- phase 1: stream the frames, wrap (Step 0), static-lattice check (helpers.pyx:57-80) ----
+    for (int t = tid; t < nf * SM; t += F2_THREADS) {
+        const int fl = t / SM;
+        const int r = t - fl * SM;
+        const i64 atom = r < S ? a.static_idx[r] : a.mobile_idx[r - S];
+        const double *p = a.frames + ((f0 + fl) * a.A + atom) * 3;
+        double x = p[0], y = p[1], z = p[2];
+        wrapc<CELL>(P, x, y, z);
+        if (r < S) {
+            sx[fl * S + r] = x; sy[fl * S + r] = y; sz[fl * S + r] = z;
+            if (!dyn) {
+                // PBCCalculator.distances(ref, atom) (util/PBCCalculator.pyx:64-103), squared; the sqrt is
+                // taken only inside the rounding band around static_movement_threshold^2
+                const double *rp = a.ref_static + 3 * r;
+                double qx = x + (P.cen[0] - rp[0]), qy = y + (P.cen[1] - rp[1]), qz = z + (P.cen[2] - rp[2]);
+                wrapc<CELL>(P, qx, qy, qz);
+                const double dx = -qx + P.cen[0], dy = -qy + P.cen[1], dz = -qz + P.cen[2];
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 > a.delta2) {
+                    atomicOr(&fmax[fl], 1ull);
+                    if (d2 > a.thr2_lo && (d2 > a.thr2_hi || sqrt(d2) > a.static_thr))
+                        atomicMin(a.err, (u64)(a.frame0 + f0 + fl) * errw + (u64)r);
+                }
+            }
+        } else {
+            mx[fl * M + (r - S)] = x; my[fl * M + (r - S)] = y; mz[fl * M + (r - S)] = z;
+        }
+    }
+    __syncthreads();
+    if (tid < nf) {
+        const bool tight = dyn ? (a.frame_dmax[f0 + tid] * a.frame_dmax[f0 + tid] <= a.delta2) : (fmax[tid] == 0ull);
+        fmax[tid] = tight ? 1ull : 0ull;
+        if (!tight) atomicAdd(&a.scal[2], 1ull);
+    }
+    __syncthreads();
+
+    // ---- phase 2: every wave on its own; no workgroup barrier from here on ----
+    double *tval = tval_all + wave * F2_WTASK;
+    i32 *tk = tk_all + wave * F2_WTASK;
+    unsigned short *surv = surv_all + wave * F2_WTASK;
+    unsigned char *tion = tion_all + wave * F2_WTASK;
+    const bool store = a.row_val != nullptr;
+    const int nions = nf * M;
+    for (int ic0 = wave * F2_IW; ic0 < nions; ic0 += 4 * F2_IW) {
+        const int nic = (nions - ic0) < F2_IW ? (nions - ic0) : F2_IW;
+        // 2a: lanes < nic own one ion: its offset (helpers.pyx:100) and candidate list
+        int fl = 0, j = 0, cnt = 0;
+        double ox = 0, oy = 0, oz = 0;
+        const i32 *list = nullptr;
+        if (lane < nic) {
+            const int ion = ic0 + lane;
+            fl = ion / M; j = ion - fl * M;
+            const double px = mx[fl * M + j], py = my[fl * M + j], pz = mz[fl * M + j];
+            ox = P.cen[0] - px; oy = P.cen[1] - py; oz = P.cen[2] - pz;
+            if (fmax[fl] != 0ull) {
+                const int b = bin_of<CELL>(P, px, py, pz, a.tG0, a.tG1, a.tG2);
+                const i32 lo = a.t_off[b];
+                cnt = a.t_off[b + 1] - lo; list = a.t_list + lo;
+            } else {
+                const int b = bin_of<CELL>(P, px, py, pz, a.lG0, a.lG1, a.lG2);
+                const i32 lo = a.l_off[b];
+                cnt = a.l_off[b + 1] - lo; list = a.l_list + lo;
+            }
+        }
+        // 2b: wave scan of the task counts
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        const int excl = incl - cnt;
+        int nnz = 0;
+        const i64 row = (f0 + fl) * M + j;
+        int ion_s = 0;
+        while (ion_s < nic) {
+            // 2c: batch [ion_s, ion_e) of whole ions with at most WTASK tasks (prefix sums are monotonic)
+            const int pre_s = __shfl(excl, ion_s);
+            const unsigned long long fit = __ballot(lane >= ion_s && lane < nic && incl - pre_s <= F2_WTASK);
+            const int ion_e = ion_s + __popcll(fit);
+            const int ntasks = __shfl(incl, ion_e - 1) - pre_s;
+            // 2d: publish my tasks
+            const bool mine = lane >= ion_s && lane < ion_e;
+            const int at = excl - pre_s;
+            if (mine)
+                for (int c = 0; c < cnt; c++) { tk[at + c] = list[c]; tion[at + c] = (unsigned char)lane; }
+            __builtin_amdgcn_wave_barrier();
+            // 2e-1: screen every (ion, landmark) task; survivors are compacted by ballot
+            int nsurv = 0;
+            for (int t0 = 0; t0 < ntasks; t0 += 64) {
+                const int t = t0 + lane;
+                const int ii = t < ntasks ? tion[t] : 0;
+                const double tox = __shfl(ox, ii), toy = __shfl(oy, ii), toz = __shfl(oz, ii);
+                const int tfl = __shfl(fl, ii);
+                bool alive = false;
+                if (t < ntasks) {
+                    const i32 *lmap = dyn ? a.lattice_map + (f0 + tfl) * S : nullptr;
+                    alive = !screen_landmark<CELL>(a, tk[t], sx + tfl * S, sy + tfl * S, sz + tfl * S, lmap, tox, toy, toz);
+                    if (!alive) tval[t] = 0.0;
+                }
+                const unsigned long long m = __ballot(alive);
+                if (alive) surv[nsurv + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)t;
+                nsurv += __popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // 2e-2: full evaluation of the survivors, one lane each
+            for (int q0 = 0; q0 < nsurv; q0 += 64) {
+                const int q = q0 + lane;
+                const int t = q < nsurv ? surv[q] : 0;
+                const int ii = q < nsurv ? tion[t] : 0;
+                const double tox = __shfl(ox, ii), toy = __shfl(oy, ii), toz = __shfl(oz, ii);
+                const int tfl = __shfl(fl, ii);
+                if (q < nsurv) {
+                    const i32 *lmap = dyn ? a.lattice_map + (f0 + tfl) * S : nullptr;
+                    tval[t] = eval_landmark<CELL>(a, tk[t], sx + tfl * S, sy + tfl * S, sz + tfl * S, lmap, tox, toy, toz);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // 2f: my row, ascending landmark order
+            if (mine) {
+                for (int c = 0; c < cnt; c++) {
+                    const double val = tval[at + c];
+                    if (val != 0.0) {
+                        if (store) {
+                            if (nnz < a.W) { a.row_idx[(i64)nnz * a.N + row] = tk[at + c]; a.row_val[(i64)nnz * a.N + row] = val; }
+                            else atomicAdd(&a.scal[3], 1ull);
+                        }
+                        nnz++;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            ion_s = ion_e;
+        }
+        if (lane < nic) {
+            a.row_nnz[row] = nnz < a.W ? nnz : a.W;
+            if (nnz == 0) {                                               // helpers.pyx:116-120
+                if (a.check_zeros) atomicMin(a.err, (u64)(a.frame0 + f0 + fl) * errw + (u64)(S + 1 + j));
+                else atomicAdd(&a.scal[0], 1ull);
+            }
+        }
+    }
+}
+
+// per-frame maximum static displacement of a strided sample of frames (own-index distance)
+__global__ __launch_bounds__(256) void k_sample_dmax(Pbc P, const double *frames, const i32 *static_idx,
+                                                     const double *ref_static, i64 F, i64 A, i64 S, i64 stride,
+                                                     double *out)
+{
+    __shared__ double red[256];
+    const i64 f = (i64)blockIdx.x * stride;
+    double m = 0.0;
+    if (f < F)
+        for (i64 s = threadIdx.x; s < S; s += 256) {
+            const double *p = frames + (f * A + static_idx[s]) * 3;
+            double x = p[0], y = p[1], z = p[2];
+            wrap3(P, x, y, z);
+            const double d = dist_sw(P, ref_static[3 * s], ref_static[3 * s + 1], ref_static[3 * s + 2], x, y, z);
+            m = d > m ? d : m;
+        }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+int fill2_sample_dmax(sit_ctx *c, std::vector<double> &out)
+{
+    i64 ns = c->F < 2048 ? c->F : 2048;
+    if (ns <= 0) { out.clear(); return SIT_OK; }
+    const i64 stride = c->F / ns;
+    int rc = ensure_scratch(c, ns * 8);
+    if (rc) return rc;
+    k_sample_dmax<<<dim3((unsigned)ns), dim3(256), 0, c->stream>>>(c->pbc, c->d_frames, c->d_static_idx, c->d_ref_static,
+                                                                   c->F, c->A, c->S, stride, (double *)c->d_scratch);
+    HIP_TRY(c, hipGetLastError());
+    out.resize((size_t)ns);
+    HIP_TRY(c, hipMemcpyAsync(out.data(), c->d_scratch, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+size_t fill2_lds_bytes(i64 S, i64 M, int fpb)
+{
+    size_t b = (size_t)fpb * (size_t)(S + M) * 24;
+    b += (size_t)4 * F2_WTASK * 8;      // tval
+    b += (size_t)fpb * 8;               // fmax
+    b += (size_t)4 * F2_WTASK * 4;      // tk
+    b += (size_t)4 * F2_WTASK * 2;      // surv
+    b += (size_t)4 * F2_WTASK;          // tion
+    return (b + 31) & ~(size_t)15;
+}
+
+int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, double threshold)
+{
+    const i64 S = c->S, M = c->M;
+    SIT_REQUIRE(c, c->D * c->V < (1LL << 31) && c->F * S < (1LL << 40), "sit_fill: sizes too large");
+    Fill2Args a;
+    a.P = c->pbc; a.frames = c->d_frames; a.static_idx = c->d_static_idx; a.mobile_idx = c->d_mobile_idx;
+    a.ref_static = c->d_ref_static; a.verts = c->d_verts; a.vcd = c->d_vcd; a.hi2 = c->d_hi2;
+    a.t_off = c->d_tbin_off; a.t_list = c->d_tbin_list; a.l_off = c->d_bin_off; a.l_list = c->d_bin_list;
+    a.lattice_map = p->dynamic_lattice_mapping ? c->d_lattice_map : nullptr;
+    a.frame_dmax = p->dynamic_lattice_mapping ? c->d_frame_dmax : nullptr;
+    a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx; a.row_val = store ? c->d_row_val : nullptr;
+    a.labels = c->d_labels; a.confs = nullptr; (void)assign;
+    a.col_ptr = c->d_col_ptr; a.col_k = c->d_col_k; a.col_val = c->d_col_val;
+    a.err = c->d_err; a.scal = c->d_scal;
+    a.F = c->F; a.A = c->A; a.N = c->N; a.frame0 = c->frame0;
+    a.S = (int)S; a.M = (int)M; a.D = (int)c->D; a.V = (int)c->V; a.W = (int)c->rows_W;
+    a.tG0 = c->tG[0]; a.tG1 = c->tG[1]; a.tG2 = c->tG[2]; a.lG0 = c->G[0]; a.lG1 = c->G[1]; a.lG2 = c->G[2];
+    a.check_zeros = p->check_for_zeros; a.normed = c->centers_normed;
+    a.midpoint = c->midpoint; a.steepness = c->steepness; a.rz = c->rz; a.static_thr = c->static_thr;
+    a.delta2 = c->tight_delta >= 0 ? c->tight_delta * c->tight_delta : -1.0;
+    a.thr2_lo = c->static_thr * c->static_thr * (1.0 - 1e-14);
+    a.thr2_hi = c->static_thr * c->static_thr * (1.0 + 1e-14);
+    a.threshold = threshold;
+    // frames per workgroup: about IC ions, within the LDS budget
+    i64 fpb = (4 * F2_IW) / M; if (fpb < 1) fpb = 1; if (fpb > 8) fpb = 8;
+    while (fpb > 1 && fill2_lds_bytes(S, M, (int)fpb) > 64 * 1024) fpb--;
+    a.fpb = (int)fpb; c->last_fpb = (int)fpb;
+    const size_t lds = fill2_lds_bytes(S, M, (int)fpb);
+    SIT_REQUIRE(c, lds <= 158 * 1024, "sit_fill: one frame's atoms do not fit in LDS");
+    const unsigned grid = (unsigned)((c->F + fpb - 1) / fpb);
+    const bool diag = c->cell_diagonal;
+    if (diag) {
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_fill2<1><<<dim3(grid), dim3(F2_THREADS), lds, c->stream>>>(a);
+    } else {
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_fill2<0><<<dim3(grid), dim3(F2_THREADS), lds, c->stream>>>(a);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return SIT_OK;
+}

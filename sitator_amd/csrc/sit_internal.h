@@ -40,12 +40,26 @@ struct sit_ctx {
     double *d_ref_static = nullptr;   // [S,3]
     i32 *d_verts = nullptr;           // [D,V], -1 padded
     double *d_vcd = nullptr;          // [D,V]
+    double *d_hi2 = nullptr;          // [D,V] squared screening bounds (fill2.hip)
     // result-preserving landmark pruning: fractional-coordinate bins -> candidate landmarks
     int G[3] = {1, 1, 1};
     i32 *d_bin_off = nullptr;         // [nbins+1]
     i32 *d_bin_list = nullptr;
-    i64 W = 0;                        // row width = longest candidate list
+    i64 W = 0;                        // row width = longest candidate list (loose table)
     double mean_candidates = 0;
+    // tight table: built for the static displacement actually present (fill2.hip)
+    int tG[3] = {1, 1, 1};
+    i32 *d_tbin_off = nullptr, *d_tbin_list = nullptr;
+    i64 W_tight = 0;
+    double tight_delta = 0, tight_mean_candidates = 0;
+    bool tight_valid = false;
+    bool cell_diagonal = false;
+    int fill_kernel = 2;              // SITATOR_FILL_KERNEL=1 selects the first-generation kernel
+    std::vector<double> h_ref_static, h_vcd;
+    std::vector<i64> h_verts;
+    i64 fallback_frames = 0;
+    int last_fpb = 0;
+    double *d_frame_dmax = nullptr;   // [F] per-frame displacement maximum (dynamic mapping)
 
     // trajectory (sit_set_frames)
     i64 F = 0, A = 0, M = 0, frame0 = 0;
@@ -171,7 +185,44 @@ __device__ __forceinline__ double dist_sw(const Pbc &P, double ax, double ay, do
     return sqrt((dx * dx + dy * dy) + dz * dz);
 }
 
+// ---- a (value, index) maximum with numpy's argmax rules: first maximum, first NaN wins ----
+struct Best {
+    double v;
+    i64 i;       // -1 = empty
+    int nan;
+};
+
+__device__ __forceinline__ Best best_empty() { Best b; b.v = 0; b.i = -1; b.nan = 0; return b; }
+
+__device__ __forceinline__ Best best_merge(const Best &a, const Best &b)
+{
+    if (a.i < 0) return b;
+    if (b.i < 0) return a;
+    if (a.nan || b.nan) {
+        if (a.nan && b.nan) return a.i < b.i ? a : b;
+        return a.nan ? a : b;
+    }
+    if (a.v > b.v) return a;
+    if (b.v > a.v) return b;
+    return a.i < b.i ? a : b;
+}
+
+__device__ __forceinline__ Best best_of(double v, i64 i)
+{
+    Best b; b.v = v; b.i = i; b.nan = isnan(v) ? 1 : 0; return b;
+}
+
+
 // host-side pieces implemented in other translation units
 int sit_predict_internal(sit_ctx *c, double threshold);
+int sit_label_counts(sit_ctx *c);
+struct CandidateTable {
+    int G[3];
+    i64 W;
+    double mean;
+    std::vector<i32> off, list;
+};
 int sit_build_candidates(sit_ctx *c, const double *ref_static, const i64 *verts, const double *vcd,
-                         std::vector<i32> &bin_off, std::vector<i32> &bin_list);
+                         double displacement, double bin_target, CandidateTable &out);
+int fill2_sample_dmax(sit_ctx *c, std::vector<double> &out);
+int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, double threshold);

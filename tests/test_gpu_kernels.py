@@ -1,0 +1,100 @@
+"""GPU tests of kernel-level invariants through the C-ABI: both fill kernel generations give
+bit-identical rows, the fused assignment equals fill + predict, frames beyond the sampled
+displacement bound take the loose-table path and still match the oracle, empty inputs."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(host, M, F, seed, kernel="2", mutate=None):
+    from sitator_amd import _lib, synth
+    frames, sm, mm, ref = synth.make_trajectory(host, M, F, seed=seed)
+    if mutate is not None:
+        mutate(frames, sm, mm)
+    os.environ["SITATOR_FILL_KERNEL"] = kernel
+    try:
+        ctx = _lib.HipContext(host.cell)
+        ref_static = ref[sm]
+        V = max(len(v) for v in host.vertices)
+        verts = np.full((len(host.vertices), V), -1, dtype=np.int64)
+        vcd = np.full(verts.shape, np.nan)
+        for k, v in enumerate(host.vertices):
+            verts[k, :len(v)] = v
+            vcd[k, :len(v)] = ctx.distances(host.centers[k], ref_static[np.asarray(v)])
+        ctx.set_basis(ref_static, verts, vcd, 1.5, 30, 1.0)
+    finally:
+        os.environ.pop("SITATOR_FILL_KERNEL", None)
+    ctx.set_frames(frames, np.where(sm)[0], np.where(mm)[0])
+    return ctx, frames, sm, mm, ref
+
+
+@pytest.mark.parametrize("cfg,M,F", [("C2", 64, 200), ("C1b", 4, 500), ("C5", 160, 40)])
+def test_fill_generations_agree(cfg, M, F):
+    """v1 evaluates pow(acc, 1/n) with the library pow, v2 with square-root chains for n = 1, 2, 4, 8:
+    same sparsity pattern, values within a few ulp."""
+    from sitator_amd import synth
+    host = synth.config_host(cfg)
+    out = []
+    for kern in ("1", "2"):
+        ctx, *_ = _setup(host, M, F, seed=77, kernel=kern)
+        rc, nz, err = ctx.fill()
+        assert rc == 0
+        out.append(ctx.rows_dense())
+    assert np.array_equal(out[0] != 0, out[1] != 0)
+    np.testing.assert_allclose(out[1], out[0], rtol=1e-14, atol=0)
+
+
+def test_fused_assign_equals_fill_then_predict(oracle):
+    from sitator_amd import synth
+    host = synth.config_host("C2")
+    ctx, frames, sm, mm, ref = _setup(host, 64, 300, seed=5)
+    assert ctx.fill()[0] == 0
+    X = ctx.rows_dense()
+    centers = oracle.fit_centers(X, 0.45)
+    normed = centers / np.linalg.norm(centers, axis=1)[:, None]
+    ctx.set_centers(normed, True)
+    lab_a, conf_a, cnt_a = ctx.predict(0.8)
+    rc, _, _ = ctx.fill(assign=True, predict_threshold=0.8, store_rows=False)
+    assert rc == 0
+    lab_b, conf_b, cnt_b = ctx.assignments()
+    assert np.array_equal(lab_a, lab_b)
+    assert np.array_equal(conf_a, conf_b)
+    assert np.array_equal(cnt_a, cnt_b)
+    lab_o, conf_o = oracle.predict(X, centers, 0.8, True)
+    assert np.array_equal(lab_o, lab_b)
+    m = lab_o >= 0
+    np.testing.assert_allclose(conf_b[m], conf_o[m], rtol=1e-6)
+
+
+def test_frames_beyond_sampled_displacement_fall_back_and_match_oracle(oracle):
+    from sitator_amd import synth
+    host = synth.config_host("C2")
+
+    def shove(frames, sm, mm):
+        sidx = np.where(sm)[0]
+        frames[37, sidx[100]] += (0.55, -0.2, 0.1)      # within static_movement_threshold, far beyond the jitter
+        frames[38, sidx[7]] += (0.0, 0.0, 0.8)
+    # F >= 2048 frames are sampled with a stride, so frames 37/38 are not in the sample
+    ctx, frames, sm, mm, ref = _setup(host, 64, 4100, seed=9, mutate=shove)
+    rc, nz, err = ctx.fill()
+    assert rc == 0
+    lo, n = 30 * 64, 12 * 64
+    mine = ctx.rows_dense(lo, n)
+    wrapped = oracle.wrap_points(host.cell, frames[30:42])
+    verts, vcd = oracle.site_vertex_distances(host.cell, host.centers, host.vertices, ref[sm])
+    exp, _ = oracle.fill(host.cell, wrapped, np.where(sm)[0], np.where(mm)[0], ref[sm], verts, vcd)
+    assert np.array_equal(mine != 0, exp != 0)
+    np.testing.assert_allclose(mine, exp, rtol=1e-6, atol=0)
+
+
+def test_empty_trajectory():
+    from sitator_amd import synth
+    host = synth.config_host("C1")
+    ctx, frames, sm, mm, ref = _setup(host, 4, 256, seed=3)
+    ctx.set_frames(frames[:0], np.where(sm)[0], np.where(mm)[0])
+    rc, nz, err = ctx.fill()
+    assert rc == 0 and nz == 0
+    assert ctx.rows_dense().shape == (0, len(host.centers))
