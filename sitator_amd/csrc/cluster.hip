@@ -20,24 +20,24 @@ __device__ __forceinline__ Best wave_best(Best b)
 
 // ---- predict (util/DotProdClassifier.pyx:129-197) over sparse rows --------------------------
 //
-// One lane per row.  The dense product normed_centres . x is accumulated only over centres that
-// share a non-zero dimension with the row (all others are exactly 0): for every row entry (d, v)
-// in ascending d, the CSC column of d lists (centre, value).  Per-lane accumulators live in an
-// LDS table [TCAP][blockDim]; a row touching more than TCAP centres raises the overflow flag and
-// the launch is redone by the dense fallback.
-#define PRED_TCAP 24
-#define PRED_BLOCK 128
+// One lane per row.  The dense product normed_centres . x is non-zero only for centres that share a
+// dimension with the row; per dimension d the CSC column lists those centres.  No per-row table:
+// a (row entry e, column entry q) pair OWNS its centre if that centre appears in no column of an
+// earlier entry; the owner sums the centre's terms over the later entries in ascending dimension
+// order (the order of the dense dot product, zeros dropped).  Rows have a handful of entries and
+// columns a handful of centres, so the nested scans are short, need no LDS and keep occupancy high.
+// Centre matrices with long columns (dense user-provided centres) use the dense kernel below.
+#define PRED_BLOCK 256
+#define PRED_MAXCOL 24
 
 struct PredArgs {
     const i32 *row_nnz, *row_idx;
     const double *row_val;
     const i32 *col_ptr, *col_k;
     const double *col_val;
-    const double *dense;     // [K,D] (fallback only)
+    const double *dense;     // [K,D] (dense kernel only)
     i64 *labels;
     double *confs;
-    u64 *counts;             // [K]
-    u64 *overflow;
     i64 N, K, D;
     int normed;
     double threshold;
@@ -53,47 +53,44 @@ __device__ __forceinline__ void finish_predict(const PredArgs &a, i64 row, Best 
     if (conf < a.threshold) { to = -1; conf = 0.0; }                  // :184-186 (NaN: false)
     a.labels[row] = to;
     a.confs[row] = conf;
-    if (to >= 0) atomicAdd(&a.counts[to], 1ull);
+}
+
+// value of centre cid in column d, or "absent"
+__device__ __forceinline__ bool col_find(const PredArgs &a, i32 d, i32 cid, double &val)
+{
+    const i32 lo = a.col_ptr[d], hi = a.col_ptr[d + 1];
+    for (i32 q = lo; q < hi; q++)
+        if (a.col_k[q] == cid) { val = a.col_val[q]; return true; }
+    return false;
 }
 
 __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a)
 {
-    __shared__ i32 tk[PRED_TCAP][PRED_BLOCK];
-    __shared__ double tv[PRED_TCAP][PRED_BLOCK];
     const i64 row = (i64)blockIdx.x * PRED_BLOCK + threadIdx.x;
     if (row >= a.N) return;
     const int n = a.row_nnz[row];
     if (n == 0) { a.labels[row] = -1; a.confs[row] = 0.0; return; }   // :168-172 (conf uninitialised there)
-    const int t = threadIdx.x;
-    int used = 0;
     double x2 = 0.0;
-    bool over = false;
+    for (int e = 0; e < n; e++) { const double v = a.row_val[(i64)e * a.N + row]; x2 += v * v; }
+    const double xn = sqrt(x2);
+    Best b = best_empty();
     for (int e = 0; e < n; e++) {
         const i32 d = a.row_idx[(i64)e * a.N + row];
         const double v = a.row_val[(i64)e * a.N + row];
-        x2 += v * v;
         const i32 lo = a.col_ptr[d], hi = a.col_ptr[d + 1];
         for (i32 q = lo; q < hi; q++) {
-            const i32 k = a.col_k[q];
-            const double term = a.col_val[q] * v;
-            int s = 0;
-            while (s < used && tk[s][t] != k) s++;
-            if (s == used) {
-                if (used == PRED_TCAP) { over = true; break; }
-                tk[used][t] = k; tv[used][t] = term; used++;
-            } else {
-                tv[s][t] += term;
-            }
+            const i32 cid = a.col_k[q];
+            bool owner = true;
+            double tmp;
+            for (int e2 = 0; e2 < e && owner; e2++)
+                if (col_find(a, a.row_idx[(i64)e2 * a.N + row], cid, tmp)) owner = false;
+            if (!owner) continue;
+            double dot = a.col_val[q] * v;
+            for (int e3 = e + 1; e3 < n; e3++)
+                if (col_find(a, a.row_idx[(i64)e3 * a.N + row], cid, tmp)) dot += tmp * a.row_val[(i64)e3 * a.N + row];
+            if (a.normed) dot /= xn;                                   // :177-178
+            b = best_merge(b, best_of(fabs(dot), cid));                // :179
         }
-        if (over) break;
-    }
-    if (over) { atomicAdd(a.overflow, 1ull); return; }
-    const double xn = sqrt(x2);
-    Best b = best_empty();
-    for (int s = 0; s < used; s++) {
-        double v = tv[s][t];
-        if (a.normed) v /= xn;                                         // :177-178
-        b = best_merge(b, best_of(fabs(v), tk[s][t]));                 // :179
     }
     finish_predict(a, row, b);
 }
@@ -141,6 +138,8 @@ extern "C" int sit_set_centers(sit_ctx *c, const double *centers, i64 K, int nor
     if ((rc = dev_upload(c, &c->d_col_k, ks.data(), (i64)ks.size()))) return rc;
     if ((rc = dev_upload(c, &c->d_col_val, vals.data(), (i64)vals.size()))) return rc;
     c->K = K; c->centers_normed = normed;
+    c->max_col = 0;
+    for (i64 d = 0; d < D; d++) if (ptr[(size_t)d + 1] - ptr[(size_t)d] > c->max_col) c->max_col = ptr[(size_t)d + 1] - ptr[(size_t)d];
     if ((rc = dev_alloc(c, &c->d_counts, K))) return rc;
     if ((rc = dev_upload(c, &c->d_cen_dense, centers, K * D))) return rc;   // dense fallback
     c->assign_valid = false;
@@ -157,26 +156,22 @@ static int run_predict(sit_ctx *c, double threshold)
         if ((rc = dev_alloc(c, &c->d_confs, c->N))) return rc;
         c->assign_N = c->N;
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream));
-    if (c->N == 0) { c->assign_valid = true; return SIT_OK; }
+    if (c->N == 0) {
+        HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
+        c->assign_valid = true;
+        return SIT_OK;
+    }
     PredArgs a;
     a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx; a.row_val = c->d_row_val;
     a.col_ptr = c->d_col_ptr; a.col_k = c->d_col_k; a.col_val = c->d_col_val; a.dense = c->d_cen_dense;
-    a.labels = c->d_labels; a.confs = c->d_confs; a.counts = (u64 *)c->d_counts; a.overflow = c->d_scal + 1;
-    a.N = c->N; a.K = c->K; a.D = c->D; a.normed = c->centers_normed; a.threshold = threshold;
+    a.labels = c->d_labels; a.confs = c->d_confs;
+    a.N = c->rows_N; a.K = c->K; a.D = c->D; a.normed = c->centers_normed; a.threshold = threshold;
     const unsigned grid = (unsigned)((c->N + PRED_BLOCK - 1) / PRED_BLOCK);
     StageTimer t(c, T_PREDICT);
-    k_predict_rows<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
+    if (c->max_col <= PRED_MAXCOL) k_predict_rows<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
+    else k_predict_rows_dense<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
     HIP_TRY(c, hipGetLastError());
-    u64 over = 0;
-    HIP_TRY(c, hipMemcpyAsync(&over, c->d_scal + 1, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (over) {
-        HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
-        k_predict_rows_dense<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
-        HIP_TRY(c, hipGetLastError());
-    }
+    if ((rc = sit_label_counts(c))) return rc;      // np.bincount(labels[labels >= 0]) (:92)
     t.stop();
     c->assign_valid = true;
     return SIT_OK;

@@ -265,7 +265,7 @@ static int ensure_tight_table(sit_ctx *c)
     if (delta > c->static_thr) delta = c->static_thr;
     CandidateTable tab;
     if ((rc = sit_build_candidates(c, c->h_ref_static.data(), c->h_verts.data(), c->h_vcd.data(), delta, 0.5, tab))) return rc;
-    if (tab.W > 256) {       // F2_WTASK: an ion's tasks must fit one wave batch -> loose table for everything
+    if (tab.W > 128) {       // F2_WTASK: an ion's tasks must fit one wave batch -> loose table for everything
         delta = -1.0;
     }
     if ((rc = dev_upload(c, &c->d_tbin_off, tab.off.data(), (i64)tab.off.size()))) return rc;
@@ -311,7 +311,7 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
     HIP_TRY(c, hipSetDevice(c->device));
     if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
     const i64 N = c->N, W = c->W;
-    const bool v2 = c->fill_kernel == 2 && c->W <= 256;   // F2_WTASK
+    const bool v2 = c->fill_kernel == 2 && c->W <= 128;   // F2_WTASK
     bool assign = p->assign != 0;
     bool store = true;   // rows feed the predict kernel (wave-level fusion: see DESIGN.md)
     if (assign) SIT_REQUIRE(c, c->K > 0 && c->d_col_ptr, "sit_fill: assign requested but no centres set");

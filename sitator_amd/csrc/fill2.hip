@@ -21,7 +21,7 @@
 
 #define F2_THREADS 256
 #define F2_IW 32           // ions per wave chunk
-#define F2_WTASK 256       // tasks per wave batch
+#define F2_WTASK 128       // tasks per wave batch
 
 struct Fill2Args {
     Pbc P;

@@ -1,0 +1,56 @@
+"""GPU: two ranks (gloo rendezvous, both on GPU 0) run the real HIP path on frame shards; the
+result must equal the single-process reference golden outputs.  (RCCL itself needs one GPU per
+rank, so the nccl backend is exercised by bench.py on the multi-GPU node, not here.)"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests import golden_util as G
+from tests.test_sharded_gloo import _free_port
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, case_name, tag, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure
+    from sitator_amd.sharding import TorchComm, shard_frames
+    c = G.Case(case_name)
+    sn = SiteNetwork(Structure(c.ref_positions, c.cell), c.static_mask, c.mobile_mask)
+    sn.centers = c.centers
+    sn.vertices = c.vertices
+    lo, hi = shard_frames(len(c.frames), rank, world)
+    la = LandmarkAnalysis(verbose=False, comm=TorchComm(device="cpu"), device=0, **c.kwargs(tag))
+    st = la.run(sn, np.ascontiguousarray(c.frames[lo:hi]))
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), lo=lo, labels=st.traj, confs=st.confidences,
+             centers=np.asarray(st.site_network.centers), n_multi=la.n_multiple_assignments,
+             avg=la.avg_mobile_per_site, jumps=np.array(list(st.jumps()), dtype=np.int64).reshape(-1, 4))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,tag", [("c1_hex_scgrid", "dotprod"), ("c1b_tri_bcctet", "mcl")])
+def test_two_ranks_on_one_gpu(name, tag):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(2, port, name, tag, d), nprocs=2, join=True)
+        outs = [dict(np.load(os.path.join(d, "rank%d.npz" % r))) for r in range(2)]
+    exp = G.Case(name).out(tag)
+    labels = np.concatenate([o["labels"] for o in outs])
+    assert np.array_equal(labels, exp["labels"])
+    m = exp["labels"] >= 0
+    np.testing.assert_allclose(np.concatenate([o["confs"] for o in outs])[m], exp["confs"][m], rtol=1e-6)
+    for o in outs:
+        np.testing.assert_allclose(o["centers"], exp["site_centers"], rtol=1e-6, atol=1e-8)
+        assert int(o["n_multi"]) == int(exp["n_multiple_assignments"])
+    jumps = np.concatenate([o["jumps"] + np.array([int(o["lo"]), 0, 0, 0]) for o in outs])
+    assert np.array_equal(jumps, exp["jumps"])

@@ -1,0 +1,113 @@
+"""CPU-only: the N>1 path of the host code under torch.distributed (gloo, world_size 2).
+
+Each rank holds a contiguous block of frames and runs the product's ``LandmarkAnalysis`` with a
+``TorchComm``; the device context is replaced by the oracle-backed test double of
+``tests/fake_ctx.py`` (no GPU here), so what is exercised is exactly the multi-rank host logic:
+frame offsets, first-offender merging, the rank-to-rank hand-over of the ordered clustering state,
+count / Gram / site-centre reductions, the occupancy merge and the jump halo.  Results must equal the
+TRUE reference's single-process golden outputs.
+"""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from tests import golden_util as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case_name, tag, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sitator_amd import _lib, errors, LandmarkAnalysis, SiteNetwork, Structure
+    from sitator_amd.sharding import TorchComm, shard_frames
+    from tests.fake_ctx import FakeContext
+    _lib.HipContext = FakeContext                      # no GPU here: oracle-backed test double
+    c = G.Case(case_name)
+    sn = SiteNetwork(Structure(c.ref_positions, c.cell), c.static_mask, c.mobile_mask)
+    sn.centers = c.centers
+    sn.vertices = c.vertices
+    lo, hi = shard_frames(len(c.frames), rank, world)
+    la = LandmarkAnalysis(verbose=False, comm=TorchComm(), **c.kwargs(tag))
+    out = {"lo": lo, "hi": hi}
+    try:
+        st = la.run(sn, np.ascontiguousarray(c.frames[lo:hi]))
+        out.update(labels=st.traj, confs=st.confidences, centers=np.asarray(st.site_network.centers),
+                   n_multi=la.n_multiple_assignments, avg=la.avg_mobile_per_site,
+                   n_zero=la.n_all_zero_lvecs,
+                   jumps=np.array(list(st.jumps()), dtype=np.int64).reshape(-1, 4))
+    except (errors.StaticLatticeError, errors.ZeroLandmarkError, errors.MultipleOccupancyError,
+            errors.InsufficientSitesError) as e:
+        out.update(error=type(e).__name__, frame=getattr(e, "frame", -1),
+                   lattice_atoms=np.atleast_1d(getattr(e, "lattice_atoms", -1)),
+                   site=getattr(e, "site", -1), mobile_index=getattr(e, "mobile_index", -1))
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(case_name, tag, world=2):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, port, case_name, tag, d), nprocs=world, join=True)
+        return [dict(np.load(os.path.join(d, "rank%d.npz" % r), allow_pickle=False)) for r in range(world)]
+
+
+@pytest.mark.parametrize("name,tag", [("c1_hex_scgrid", "dotprod"), ("c1_hex_scgrid", "mcl"),
+                                      ("c1b_tri_bcctet", "dotprod"), ("c1_variants", "unweighted")])
+def test_two_ranks_reproduce_the_reference(name, tag):
+    outs = _run(name, tag)
+    exp = G.Case(name).out(tag)
+    labels = np.concatenate([o["labels"] for o in outs])
+    confs = np.concatenate([o["confs"] for o in outs])
+    assert np.array_equal(labels, exp["labels"]), "site indices must be bit-identical to the single-process reference"
+    m = exp["labels"] >= 0
+    np.testing.assert_allclose(confs[m], exp["confs"][m], rtol=1e-9)
+    for o in outs:                                     # every rank ends with the same global results
+        np.testing.assert_allclose(o["centers"], exp["site_centers"], rtol=1e-9, atol=1e-9)
+        assert int(o["n_multi"]) == int(exp["n_multiple_assignments"])
+        assert float(o["avg"]) == pytest.approx(float(exp["avg_mobile_per_site"]), rel=1e-12)
+        assert int(o["n_zero"]) == int(exp["n_all_zero_lvecs"])
+    jumps = np.concatenate([o["jumps"] + np.array([int(o["lo"]), 0, 0, 0]) for o in outs])
+    assert np.array_equal(jumps, exp["jumps"])
+
+
+@pytest.mark.parametrize("name,tag", [("err_static_threshold", "default"), ("err_multiple_occupancy", "default"),
+                                      ("c1_zero_lvecs", "raise")])
+def test_first_offender_is_global_and_raised_on_every_rank(name, tag):
+    outs = _run(name, tag)
+    exp = G.Case(name).out(tag)
+    for o in outs:
+        assert str(o["error"]) == str(exp["error_type"])
+        assert int(o["frame"]) == int(exp["error_frame"])
+        if "error_lattice_atoms" in exp:
+            assert list(o["lattice_atoms"]) == list(np.atleast_1d(exp["error_lattice_atoms"]))
+        if "error_site" in exp:
+            assert int(o["site"]) == int(exp["error_site"])
+        if "error_mobile_index" in exp:
+            assert int(o["mobile_index"]) == int(exp["error_mobile_index"])
+
+
+def test_shard_frames_partition():
+    from sitator_amd.sharding import shard_frames
+    for n in (0, 1, 7, 100, 101):
+        for size in (1, 2, 3, 8):
+            spans = [shard_frames(n, r, size) for r in range(size)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
