@@ -167,7 +167,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_fill_rows_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("k_fill2_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -181,7 +181,7 @@ def main():
                        "parallelism": "frame-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_fill_rows", "kernel_ms": fill_avg_ms,
+                         "kernel": "k_fill2", "kernel_ms": fill_avg_ms,
                          "algorithmic_bytes_per_lvec": bytes_per_lvec},
             "stages_ms": {"fill": fill_avg_ms, "predict": float(np.mean(pred_ms)), "h2d_frames": h2d_ms,
                           "generate_s": round(t_gen, 2)},
