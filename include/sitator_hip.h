@@ -195,7 +195,8 @@ int sit_timers(sit_ctx *ctx, double *ms, int n);
 /* Diagnostics of the pruning tables and the last fill: [0] row width (loose table), [1] mean
  * candidates per bin (loose), [2] longest tight list, [3] mean candidates per bin (tight),
  * [4] delta (sampled static displacement bound, A), [5] frames of the last fill that exceeded
- * delta, [6..8] loose grid, [9..11] tight grid, [12] frames per workgroup of the last fill.   */
+ * delta, [6..8] loose grid, [9..11] tight grid, [12] frames per workgroup of the last fill,
+ * [13] verified batches / [14] serially applied rows / [15] re-walks of the last speculative fit. */
 int sit_info(sit_ctx *ctx, double *out, int n);
 int sit_synchronize(sit_ctx *ctx);
 

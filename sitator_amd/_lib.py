@@ -362,14 +362,15 @@ class HipContext(object):
         return dict(zip(["fill", "fit", "predict", "gram", "site_centers", "occupancy", "h2d"], t))
 
     def info(self):
-        v = np.zeros(13)
-        self.lib.sit_info(self._h, _d(v), 13)
+        v = np.zeros(16)
+        self.lib.sit_info(self._h, _d(v), 16)
         keys = ["row_width", "mean_candidates_loose", "tight_width", "mean_candidates_tight", "delta",
                 "fallback_frames"]
         out = dict(zip(keys, v[:6]))
         out["grid_loose"] = [int(x) for x in v[6:9]]
         out["grid_tight"] = [int(x) for x in v[9:12]]
         out["frames_per_workgroup"] = int(v[12])
+        out["fit_batches"], out["fit_serial_rows"], out["fit_rewalks"] = int(v[13]), int(v[14]), int(v[15])
         return out
 
     def synchronize(self):

@@ -341,7 +341,11 @@ extern "C" int sit_fit_reset(sit_ctx *c)
     HIP_TRY(c, hipSetDevice(c->device));
     c->fit_K = 0;
     HIP_TRY(c, hipMemsetAsync(c->d_fit_K, 0, 8, c->stream));
-    return fit_ensure(c, 256);
+    int rc = fit_ensure(c, 256);
+    if (rc) return rc;
+    if (c->fit_use_fast) return fitfast_set_state(c, nullptr, nullptr, 0);
+    fitfast_invalidate(c);
+    return SIT_OK;
 }
 
 __global__ void k_row_norms(const double *cen, i64 K, i64 D, double *nrm)
@@ -370,6 +374,8 @@ extern "C" int sit_fit_set_state(sit_ctx *c, const double *centers, const i64 *c
     HIP_TRY(c, hipMemcpyAsync(c->d_fit_K, &K, 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->fit_K = K;
+    if (c->fit_use_fast) return fitfast_set_state(c, centers, counts, K);
+    fitfast_invalidate(c);
     return SIT_OK;
 }
 
@@ -377,6 +383,15 @@ extern "C" int sit_fit_get_state(sit_ctx *c, double *centers, i64 *counts, i64 *
 {
     if (!c || !K) return SIT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    if (fitfast_valid(c)) {
+        std::vector<double> cen; std::vector<i64> cnt;
+        int rc = fitfast_to_dense(c, cen, cnt, K);
+        if (rc) return rc;
+        c->fit_K = *K;
+        if (centers && *K) memcpy(centers, cen.data(), cen.size() * 8);
+        if (counts && *K) memcpy(counts, cnt.data(), cnt.size() * 8);
+        return SIT_OK;
+    }
     *K = c->fit_K;
     if (c->fit_K > 0) {
         if (centers) HIP_TRY(c, hipMemcpyAsync(centers, c->d_fit_centers, (size_t)(c->fit_K * c->D) * 8, hipMemcpyDeviceToHost, c->stream));
@@ -390,13 +405,32 @@ static int fit_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *
                       i64 stride, i64 nrows, double threshold)
 {
     int rc;
+    i64 begin = 0;
+    if (fitfast_valid(c)) {
+        if ((rc = fitfast_stream(c, nnz, idx, val, weights, stride, nrows, threshold, &begin))) return rc;
+        if (begin >= nrows && fitfast_valid(c)) return SIT_OK;
+        // a capacity of the sparse state was exceeded: hand the exact state over to the serial dense kernel
+        std::vector<double> cen; std::vector<i64> cnt; i64 Kd = 0;
+        if ((rc = fitfast_to_dense(c, cen, cnt, &Kd))) return rc;
+        fitfast_invalidate(c);
+        c->fit_K = 0;
+        if ((rc = fit_ensure(c, Kd + 256))) return rc;
+        if (Kd > 0) {
+            HIP_TRY(c, hipMemcpyAsync(c->d_fit_centers, cen.data(), (size_t)(Kd * c->D) * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->d_fit_counts, cnt.data(), (size_t)Kd * 8, hipMemcpyHostToDevice, c->stream));
+            k_row_norms<<<dim3((unsigned)((Kd + 63) / 64)), dim3(64), 0, c->stream>>>(c->d_fit_centers, Kd, c->D, c->d_fit_nrm2);
+            HIP_TRY(c, hipGetLastError());
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->d_fit_K, &Kd, 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->fit_K = Kd;
+    }
     if (!c->d_fit_centers && (rc = fit_ensure(c, 256))) return rc;
     if ((rc = ensure_scratch(c, 64))) return rc;
     const size_t lds = (size_t)c->D * 20 + 16;
     SIT_REQUIRE(c, lds <= 150 * 1024, "fit: landmark dimension too large for the LDS-resident row");
     HIP_TRY(c, hipFuncSetAttribute((const void *)k_fit_stream, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     i64 *status = (i64 *)c->d_scal + 4;
-    i64 begin = 0;
     const i64 chunk = 1 << 20;
     while (begin < nrows) {
         FitArgs a;

@@ -45,6 +45,7 @@ extern "C" void sit_destroy(sit_ctx *c)
                     c->d_counts, c->d_col_ptr, c->d_col_k, c->d_col_val, c->d_cen_dense, c->d_fit_centers,
                     c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scal, c->d_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    fitfast_free(c);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -63,10 +64,11 @@ extern "C" int sit_timers(sit_ctx *c, double *ms, int n)
 extern "C" int sit_info(sit_ctx *c, double *out, int n)
 {
     if (!c || !out) return SIT_ERR_INVALID;
-    const double v[13] = {(double)c->W, c->mean_candidates, (double)c->W_tight, c->tight_mean_candidates,
+    const double v[16] = {(double)c->W, c->mean_candidates, (double)c->W_tight, c->tight_mean_candidates,
                           c->tight_delta, (double)c->fallback_frames, (double)c->G[0], (double)c->G[1],
-                          (double)c->G[2], (double)c->tG[0], (double)c->tG[1], (double)c->tG[2], (double)c->last_fpb};
-    for (int i = 0; i < n; i++) out[i] = i < 13 ? v[i] : 0.0;
+                          (double)c->G[2], (double)c->tG[0], (double)c->tG[1], (double)c->tG[2], (double)c->last_fpb,
+                          (double)c->ff_batches, (double)c->ff_serial_rows, (double)c->ff_rewalks};
+    for (int i = 0; i < n; i++) out[i] = i < 16 ? v[i] : 0.0;
     return SIT_OK;
 }
 
@@ -222,6 +224,8 @@ extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const 
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
             if (i != j && (c->pbc.cm[3 * i + j] != 0.0 || c->pbc.ci[3 * i + j] != 0.0)) c->cell_diagonal = false;
+    const char *ff = getenv("SITATOR_FIT");
+    c->fit_use_fast = !(ff && ff[0] == 's');
     const char *fk = getenv("SITATOR_FILL_KERNEL");
     c->fill_kernel = (fk && fk[0] == '1') ? 1 : 2;
     c->tight_valid = false;

@@ -1,0 +1,530 @@
+// fit_centers (util/DotProdClassifier.pyx:199-315), exact AND parallel: "speculate, walk, verify".
+//
+// The reference streams rows in order; row i either founds a cluster or joins argmax_k cos(c_k, x_i),
+// updating c_k's running mean -- so every decision depends on all earlier rows.
+// k_fit_stream (cluster.hip) does exactly that with one workgroup.  Here the same result is produced
+// in parallel, for a batch of B rows at a time:
+//   A  speculate  (lane per row)    decide every row against the centres AS OF THE BATCH START; record the
+//                                   centres that share a dimension with the row (only those can score != 0).
+//                                   The batch is cut before the first row that founds a cluster.
+//   B  walk       (wave per centre) centre k visits, IN ROW ORDER, the rows that list it: it scores the row
+//                                   with its CURRENT state (bit-for-bit the reference's arithmetic), and if
+//                                   the row was speculated to join k it applies the running-mean update.
+//                                   Centres evolve independently given the decisions, so K waves run in parallel.
+//   C  verify     (lane per row)    re-decide every row from the scores of step B.  By induction the first
+//                                   row whose decision differs from its speculation is the first wrong one:
+//                                   rows before it are exact.  The batch is then re-walked up to that row,
+//                                   committed, and the stream continues from there (state is exact again).
+// Rows that found clusters, rows whose join grows a centre's support (later rows' overlap lists would be
+// stale) and rows exceeding a capacity are applied one at a time by k_ff_serial with the same arithmetic.
+// Centres are kept sparse (sorted support, <= FF_CS entries); dot products sum in ascending dimension
+// order, norms sum in ascending order: identical to the dense left-to-right sums of the oracle.
+#include <cmath>
+#include <cstring>
+
+#include "sit_internal.h"
+
+#define FF_CS 64        // support entries per centre (= lanes of the walking wave)
+#define FF_DC 32        // centres listed per landmark dimension
+#define FF_OC 16        // overlapping centres recorded per row
+#define FF_BMAX 65536   // rows per batch
+#define FF_NEW (-1)
+#define FF_BREAK (-2)   // row must be applied serially (zero row, capacity)
+
+struct FFRows {
+    const i32 *nnz, *idx;
+    const double *val;
+    const i64 *weights;   // null => 1
+    i64 stride;
+};
+
+struct FFState {
+    i32 *cs_n, *cs_idx;
+    double *cs_val;
+    i64 *c_cnt;
+    double *c_nrm;
+    i32 *dc_n, *dc_list;
+    i32 *K;               // device scalar
+    i32 *flags;           // [0] capacity overflow
+    i64 D, Kcap;
+};
+
+struct FFBatch {
+    i32 *dec, *ov_n, *ov_id;
+    double *vcos, *xn;
+    i32 *first_new, *first_bad;
+};
+
+// value of centre c at dimension d (0 when d is outside its support); binary search in the sorted support
+__device__ __forceinline__ double ff_at(const FFState &s, i32 c, i32 d)
+{
+    const i32 *ix = s.cs_idx + (i64)c * FF_CS;
+    int lo = 0, hi = s.cs_n[c];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ix[mid] < d) lo = mid + 1; else hi = mid;
+    }
+    return (lo < s.cs_n[c] && ix[lo] == d) ? s.cs_val[(i64)c * FF_CS + lo] : 0.0;
+}
+
+// The reference's decision for one row against the state `s` (:238-247): overlapping centres into ov[]
+// (ascending id), returns the centre joined, FF_NEW, or FF_BREAK.  `K` centres exist.
+__device__ int ff_decide(const FFState &s, const FFRows &r, i64 row, double threshold, int K,
+                         i32 *ov, int &nov, double &xn_out)
+{
+    const int n = r.nnz[row];
+    nov = 0;
+    double x2 = 0.0;
+    for (int e = 0; e < n; e++) { const double v = r.val[(i64)e * r.stride + row]; x2 += v * v; }
+    const double xn = sqrt(x2);
+    xn_out = xn;
+    if (n == 0) return K == 0 ? FF_NEW : FF_BREAK;       // zero row: NaN argmax semantics, serial path
+    for (int e = 0; e < n; e++) {
+        const i32 d = r.idx[(i64)e * r.stride + row];
+        const int m = s.dc_n[d];
+        if (m > FF_DC) return FF_BREAK;
+        for (int q = 0; q < m; q++) {
+            const i32 c = s.dc_list[(i64)d * FF_DC + q];
+            int p = 0;
+            while (p < nov && ov[p] < c) p++;
+            if (p < nov && ov[p] == c) continue;
+            if (nov == FF_OC) return FF_BREAK;
+            for (int t = nov; t > p; t--) ov[t] = ov[t - 1];
+            ov[p] = c; nov++;
+        }
+    }
+    Best b = best_empty();
+    for (int p = 0; p < nov; p++) {
+        const i32 c = ov[p];
+        double dot = 0.0;
+        for (int e = 0; e < n; e++)
+            dot += ff_at(s, c, r.idx[(i64)e * r.stride + row]) * r.val[(i64)e * r.stride + row];
+        dot /= s.c_nrm[c];                                // :239
+        dot /= xn;                                        // :240
+        b = best_merge(b, best_of(dot, c));
+    }
+    if (nov < K) {                                        // every other centre scores exactly 0
+        i32 k0 = 0;
+        for (int p = 0; p < nov && ov[p] == k0; p++) k0++;
+        b = best_merge(b, best_of(0.0, k0));
+    }
+    if (b.i < 0) return FF_NEW;
+    if (b.v < threshold) return FF_NEW;                   // :245-247 (NaN: false -> joins)
+    return (int)b.i;
+}
+
+// ---- A: speculate ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ff_speculate(FFState s, FFRows r, FFBatch b, i64 row0, int nb, double threshold)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nb) return;
+    const int K = *s.K;
+    int nov;
+    double xn;
+    i32 *ov = b.ov_id + (i64)j * FF_OC;
+    int dec = ff_decide(s, r, row0 + j, threshold, K, ov, nov, xn);
+    if (dec >= 0) {                                       // the joined centre must be in the list the walk reads
+        int p = 0;
+        while (p < nov && ov[p] < dec) p++;
+        if (!(p < nov && ov[p] == dec)) {
+            if (nov == FF_OC) dec = FF_BREAK;
+            else { for (int t = nov; t > p; t--) ov[t] = ov[t - 1]; ov[p] = dec; nov++; }
+        }
+    }
+    b.dec[j] = dec; b.ov_n[j] = nov; b.xn[j] = xn;
+    if (dec < 0) atomicMin(b.first_new, j);
+}
+
+// ---- B: walk ----------------------------------------------------------------------------------------
+// One wave per centre; lane i holds support entry i.  Writes the walked state to the shadow arrays `o`.
+__global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, FFBatch b, i64 row0, int nb)
+{
+    {   // the batch ends before the first row that founds a cluster (speculation ran just before)
+        const int fn = *b.first_new;
+        if (fn < nb) nb = fn;
+    }
+    const int k = blockIdx.x;
+    const int lane = threadIdx.x;
+    int sn = s.cs_n[k];
+    i32 idx = lane < sn ? s.cs_idx[(i64)k * FF_CS + lane] : 0x7fffffff;
+    double val = lane < sn ? s.cs_val[(i64)k * FF_CS + lane] : 0.0;
+    i64 cnt = s.c_cnt[k];
+    double nrm = s.c_nrm[k];
+    for (int j0 = 0; j0 < nb; j0 += 64) {
+        // rows at or after the first known invalid row are void anyway (first_bad only ever decreases)
+        if (j0 > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        const int j = j0 + lane;
+        int slot = -1;
+        if (j < nb) {
+            const int m = b.ov_n[j];
+            const i32 *ov = b.ov_id + (i64)j * FF_OC;
+            if (m > 0 && ov[0] <= k && ov[m - 1] >= k)
+                for (int p = 0; p < m; p++) if (ov[p] == k) { slot = p; break; }
+        }
+        unsigned long long todo = __ballot(slot >= 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int jj = j0 + src;
+            const int sl = __shfl(slot, src);
+            const i64 row = row0 + jj;
+            const int n = r.nnz[row];
+            // score with the current state: dot in ascending dimension order (:238-240)
+            double dot = 0.0;
+            for (int e = 0; e < n; e++) {
+                const i32 d = r.idx[(i64)e * r.stride + row];
+                const unsigned long long hit = __ballot(idx == d);
+                if (hit) dot += __shfl(val, __ffsll((long long)hit) - 1) * r.val[(i64)e * r.stride + row];
+            }
+            dot /= nrm;
+            dot /= b.xn[jj];
+            if (lane == 0) b.vcos[(i64)jj * FF_OC + sl] = dot;
+            if (b.dec[jj] == k) {                                     // running-mean update (:283-288)
+                const i64 w = r.weights ? r.weights[row] : 1;
+                const double fo = (double)cnt, fn = (double)(cnt + w);
+                bool grew = false;
+                val *= fo;
+                for (int e = 0; e < n; e++) {
+                    const i32 d = r.idx[(i64)e * r.stride + row];
+                    const double v = r.val[(i64)e * r.stride + row];
+                    const unsigned long long hit = __ballot(idx == d);
+                    if (hit) { if (idx == d) val += v; }
+                    else grew = true;                                 // new support entry: serial path
+                }
+                if (grew) {
+                    // undo nothing: the walk of this batch is void from row jj on; report and stop using it
+                    if (lane == 0) atomicMin(b.first_bad, jj);
+                    return;
+                }
+                val /= fn;
+                cnt += w;
+                double s2 = 0.0;
+                for (int i = 0; i < sn; i++) { const double vi = __shfl(val, i); s2 += vi * vi; }
+                nrm = sqrt(s2);
+            }
+        }
+    }
+    if (lane < sn) { o.cs_idx[(i64)k * FF_CS + lane] = idx; o.cs_val[(i64)k * FF_CS + lane] = val; }
+    if (lane == 0) { o.cs_n[k] = sn; o.c_cnt[k] = cnt; o.c_nrm[k] = nrm; }
+}
+
+// ---- C: verify ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFBatch b, int nb, double threshold)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    {
+        const int fn = *b.first_new;
+        if (fn < nb) nb = fn;
+    }
+    if (j >= nb) return;
+    const int K = *s.K;
+    const int m = b.ov_n[j];
+    const i32 *ov = b.ov_id + (i64)j * FF_OC;
+    Best best = best_empty();
+    for (int p = 0; p < m; p++) best = best_merge(best, best_of(b.vcos[(i64)j * FF_OC + p], ov[p]));
+    if (m < K) {
+        i32 k0 = 0;
+        for (int p = 0; p < m && ov[p] == k0; p++) k0++;
+        best = best_merge(best, best_of(0.0, k0));
+    }
+    int dec = (best.i < 0 || best.v < threshold) ? FF_NEW : (int)best.i;
+    if (dec != b.dec[j]) atomicMin(b.first_bad, j);
+}
+
+// ---- serial application of rows (founding rows, support growth, capacity breakers) -------------------
+// One thread, `count` rows in order, same arithmetic.  Stops (status) when a capacity is exceeded.
+__global__ void k_ff_serial(FFState s, FFRows r, i64 row0, int count, double threshold, i32 *scratch_ov, i32 *done)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    int K = *s.K;
+    int processed = 0;
+    for (int q = 0; q < count; q++, processed++) {
+        const i64 row = row0 + q;
+        const int n = r.nnz[row];
+        const i64 w = r.weights ? r.weights[row] : 1;
+        int nov;
+        double xn;
+        int dec = ff_decide(s, r, row, threshold, K, scratch_ov, nov, xn);
+        if (dec == FF_BREAK) { s.flags[0] = 1; break; }
+        if (dec == FF_NEW) {                                          // :250-260
+            if (K >= s.Kcap || n > FF_CS) { s.flags[0] = 1; break; }
+            bool ok = true;
+            for (int e = 0; e < n; e++) if (s.dc_n[r.idx[(i64)e * r.stride + row]] >= FF_DC) ok = false;
+            if (!ok) { s.flags[0] = 1; break; }
+            for (int e = 0; e < n; e++) {
+                const i32 d = r.idx[(i64)e * r.stride + row];
+                s.cs_idx[(i64)K * FF_CS + e] = d;
+                s.cs_val[(i64)K * FF_CS + e] = r.val[(i64)e * r.stride + row];
+                s.dc_list[(i64)d * FF_DC + s.dc_n[d]] = K; s.dc_n[d]++;
+            }
+            s.cs_n[K] = n; s.c_cnt[K] = w; s.c_nrm[K] = xn;
+            K++;
+        } else {                                                      // :283-288, support may grow
+            const i32 c = dec;
+            i32 *ix = s.cs_idx + (i64)c * FF_CS;
+            double *vv = s.cs_val + (i64)c * FF_CS;
+            int sn = s.cs_n[c];
+            // merged support size
+            int extra = 0;
+            for (int e = 0; e < n; e++) {
+                const i32 d = r.idx[(i64)e * r.stride + row];
+                bool in = false;
+                for (int i = 0; i < sn; i++) if (ix[i] == d) { in = true; break; }
+                if (!in) { extra++; if (s.dc_n[d] >= FF_DC) extra = FF_CS + 1; }
+            }
+            if (sn + extra > FF_CS) { s.flags[0] = 1; break; }
+            const double fo = (double)s.c_cnt[c], fn = (double)(s.c_cnt[c] + w);
+            for (int i = 0; i < sn; i++) vv[i] *= fo;
+            for (int e = 0; e < n; e++) {
+                const i32 d = r.idx[(i64)e * r.stride + row];
+                const double v = r.val[(i64)e * r.stride + row];
+                int p = 0;
+                while (p < sn && ix[p] < d) p++;
+                if (p < sn && ix[p] == d) vv[p] += v;
+                else {
+                    for (int t = sn; t > p; t--) { ix[t] = ix[t - 1]; vv[t] = vv[t - 1]; }
+                    ix[p] = d; vv[p] = v;                             // 0 * fo + v
+                    sn++;
+                    s.dc_list[(i64)d * FF_DC + s.dc_n[d]] = c; s.dc_n[d]++;
+                }
+            }
+            double s2 = 0.0;
+            for (int i = 0; i < sn; i++) { vv[i] /= fn; s2 += vv[i] * vv[i]; }
+            s.cs_n[c] = sn; s.c_cnt[c] += w; s.c_nrm[c] = sqrt(s2);
+        }
+    }
+    *s.K = K;
+    *done = processed;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------
+
+struct FitFast {
+    bool ready = false;       // device arrays allocated for this D
+    bool valid = false;       // the sparse state is the current truth (else the dense one is)
+    i64 D = 0, Kcap = 0;
+    FFState st, sh;           // main + shadow (walk output)
+    FFBatch bt;
+    i32 *d_scr = nullptr;     // [FF_OC + 8]: serial scratch, done counter
+    void *blob = nullptr;
+};
+
+static FitFast *ff_of(sit_ctx *c)
+{
+    if (!c->fitfast) c->fitfast = new FitFast();
+    return (FitFast *)c->fitfast;
+}
+
+void fitfast_free(sit_ctx *c)
+{
+    if (!c->fitfast) return;
+    FitFast *f = (FitFast *)c->fitfast;
+    if (f->blob) (void)hipFree(f->blob);
+    delete f;
+    c->fitfast = nullptr;
+}
+
+static char *carve(char *&p, size_t bytes)
+{
+    char *r = p;
+    p += (bytes + 255) & ~(size_t)255;
+    return r;
+}
+
+static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
+{
+    if (f->blob) { (void)hipFree(f->blob); f->blob = nullptr; }
+    const i64 D = c->D;
+    size_t per_state = (size_t)Kcap * (4 + FF_CS * 12 + 16) + 4096;
+    size_t total = 2 * per_state + (size_t)D * (4 + FF_DC * 4) + 8192
+                 + (size_t)FF_BMAX * (4 + 4 + FF_OC * 4 + FF_OC * 8 + 8) + 65536;
+    HIP_TRY(c, hipMalloc(&f->blob, total));
+    HIP_TRY(c, hipMemsetAsync(f->blob, 0, total, c->stream));
+    char *p = (char *)f->blob;
+    FFState *ss[2] = {&f->st, &f->sh};
+    i32 *dc_n = (i32 *)carve(p, (size_t)D * 4);
+    i32 *dc_list = (i32 *)carve(p, (size_t)D * FF_DC * 4);
+    i32 *Kp = (i32 *)carve(p, 64);
+    i32 *flags = (i32 *)carve(p, 64);
+    for (FFState *s : ss) {
+        s->cs_n = (i32 *)carve(p, (size_t)Kcap * 4);
+        s->cs_idx = (i32 *)carve(p, (size_t)Kcap * FF_CS * 4);
+        s->cs_val = (double *)carve(p, (size_t)Kcap * FF_CS * 8);
+        s->c_cnt = (i64 *)carve(p, (size_t)Kcap * 8);
+        s->c_nrm = (double *)carve(p, (size_t)Kcap * 8);
+        s->dc_n = dc_n; s->dc_list = dc_list; s->K = Kp; s->flags = flags; s->D = D; s->Kcap = Kcap;
+    }
+    f->bt.dec = (i32 *)carve(p, (size_t)FF_BMAX * 4);
+    f->bt.ov_n = (i32 *)carve(p, (size_t)FF_BMAX * 4);
+    f->bt.ov_id = (i32 *)carve(p, (size_t)FF_BMAX * FF_OC * 4);
+    f->bt.vcos = (double *)carve(p, (size_t)FF_BMAX * FF_OC * 8);
+    f->bt.xn = (double *)carve(p, (size_t)FF_BMAX * 8);
+    f->bt.first_new = (i32 *)carve(p, 64);
+    f->bt.first_bad = f->bt.first_new + 1;
+    f->d_scr = (i32 *)carve(p, 256);
+    f->D = D; f->Kcap = Kcap; f->ready = true; f->valid = false;
+    return SIT_OK;
+}
+
+// dense [K,D] + counts  ->  sparse state.  Returns false when a capacity does not fit (stay dense).
+static int ff_from_dense(sit_ctx *c, FitFast *f, const double *cen, const i64 *cnt, i64 K, bool *fits)
+{
+    const i64 D = c->D;
+    *fits = false;
+    i64 need = K + 1024;
+    if (!f->ready || f->D != D || f->Kcap < need) { int rc = ff_alloc(c, f, need * 2); if (rc) return rc; }
+    std::vector<i32> cs_n((size_t)K, 0), cs_idx((size_t)(K * FF_CS), 0), dc_n((size_t)D, 0), dc_list((size_t)(D * FF_DC), 0);
+    std::vector<double> cs_val((size_t)(K * FF_CS), 0.0), nrm((size_t)K, 0.0);
+    for (i64 k = 0; k < K; k++) {
+        int n = 0;
+        double s2 = 0.0;
+        for (i64 d = 0; d < D; d++) {
+            const double v = cen[k * D + d];
+            if (v != 0.0) {
+                if (n == FF_CS || dc_n[(size_t)d] == FF_DC) return SIT_OK;
+                cs_idx[(size_t)(k * FF_CS + n)] = (i32)d; cs_val[(size_t)(k * FF_CS + n)] = v; n++;
+                dc_list[(size_t)(d * FF_DC + dc_n[(size_t)d])] = (i32)k; dc_n[(size_t)d]++;
+                s2 += v * v;
+            }
+        }
+        cs_n[(size_t)k] = n; nrm[(size_t)k] = std::sqrt(s2);
+    }
+    const i32 K32 = (i32)K, zero = 0;
+    if (K > 0) {
+        HIP_TRY(c, hipMemcpyAsync(f->st.cs_n, cs_n.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(f->st.cs_idx, cs_idx.data(), (size_t)K * FF_CS * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(f->st.cs_val, cs_val.data(), (size_t)K * FF_CS * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(f->st.c_cnt, cnt, (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(f->st.c_nrm, nrm.data(), (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipMemcpyAsync(f->st.dc_n, dc_n.data(), (size_t)D * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(f->st.dc_list, dc_list.data(), (size_t)D * FF_DC * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(f->st.K, &K32, 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(f->st.flags, &zero, 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *fits = true;
+    return SIT_OK;
+}
+
+// sparse state -> dense host arrays (sit_fit_get_state, or hand-over to the serial dense kernel)
+int fitfast_to_dense(sit_ctx *c, std::vector<double> &cen, std::vector<i64> &cnt, i64 *Kout)
+{
+    FitFast *f = ff_of(c);
+    i32 K32 = 0;
+    HIP_TRY(c, hipMemcpyAsync(&K32, f->st.K, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const i64 K = K32, D = c->D;
+    *Kout = K;
+    cen.assign((size_t)(K * D), 0.0); cnt.assign((size_t)K, 0);
+    if (K == 0) return SIT_OK;
+    std::vector<i32> cs_n((size_t)K), cs_idx((size_t)(K * FF_CS));
+    std::vector<double> cs_val((size_t)(K * FF_CS));
+    HIP_TRY(c, hipMemcpyAsync(cs_n.data(), f->st.cs_n, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cs_idx.data(), f->st.cs_idx, (size_t)K * FF_CS * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cs_val.data(), f->st.cs_val, (size_t)K * FF_CS * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cnt.data(), f->st.c_cnt, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (i64 k = 0; k < K; k++)
+        for (int i = 0; i < cs_n[(size_t)k]; i++)
+            cen[(size_t)(k * D + cs_idx[(size_t)(k * FF_CS + i)])] = cs_val[(size_t)(k * FF_CS + i)];
+    return SIT_OK;
+}
+
+bool fitfast_valid(sit_ctx *c) { return c->fitfast && ((FitFast *)c->fitfast)->valid; }
+void fitfast_invalidate(sit_ctx *c) { if (c->fitfast) ((FitFast *)c->fitfast)->valid = false; }
+
+int fitfast_set_state(sit_ctx *c, const double *cen, const i64 *cnt, i64 K)
+{
+    FitFast *f = ff_of(c);
+    bool fits = false;
+    int rc = ff_from_dense(c, f, cen, cnt, K, &fits);
+    if (rc) return rc;
+    f->valid = fits;
+    return SIT_OK;
+}
+
+// Streams rows [0, nrows) through the sparse state.  *consumed = rows applied; less than nrows when a
+// capacity was exceeded (the caller continues with the dense serial kernel from the exported state).
+int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val, const i64 *weights, i64 stride,
+                   i64 nrows, double threshold, i64 *consumed)
+{
+    FitFast *f = ff_of(c);
+    *consumed = 0;
+    if (!f->valid) return SIT_OK;
+    FFRows r; r.nnz = nnz; r.idx = idx; r.val = val; r.weights = weights; r.stride = stride;
+    i64 pos = 0;
+    int B = 256;
+    i32 K = 0;
+    HIP_TRY(c, hipMemcpyAsync(&K, f->st.K, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const i32 big2[2] = {0x7fffffff, 0x7fffffff};
+    auto serial = [&](int count) -> int {     // apply `count` rows one by one (exact), refresh K
+        k_ff_serial<<<dim3(1), dim3(64), 0, c->stream>>>(f->st, r, pos, count, threshold, f->d_scr, f->d_scr + 32);
+        HIP_TRY(c, hipGetLastError());
+        i32 done = 0, flag = 0;
+        HIP_TRY(c, hipMemcpyAsync(&done, f->d_scr + 32, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&flag, f->st.flags, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(&K, f->st.K, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        pos += done; c->ff_serial_rows += done;
+        if (flag) f->valid = false;
+        return SIT_OK;
+    };
+    auto commit = [&]() {                     // the walked (shadow) state becomes the state
+        FFState t = f->st; f->st = f->sh; f->sh = t;
+    };
+    while (pos < nrows && f->valid) {
+        if (K + 64 > f->Kcap) {          // grow: export, reallocate, import
+            std::vector<double> cen; std::vector<i64> cnt; i64 Kd;
+            int rc = fitfast_to_dense(c, cen, cnt, &Kd);
+            if (rc) return rc;
+            bool fits;
+            f->ready = false;
+            if ((rc = ff_from_dense(c, f, cen.data(), cnt.data(), Kd, &fits))) return rc;
+            if (!fits) { f->valid = false; break; }
+        }
+        const int nb = (int)((nrows - pos) < B ? (nrows - pos) : B);
+        // first_new and first_bad are adjacent words
+        HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 8, hipMemcpyHostToDevice, c->stream));
+        k_ff_speculate<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
+        if (K > 0) {
+            k_ff_walk<<<dim3((unsigned)K), dim3(64), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, nb);
+            k_ff_verify<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, f->bt, nb, threshold);
+        }
+        HIP_TRY(c, hipGetLastError());
+        i32 fb[2] = {0, 0};
+        HIP_TRY(c, hipMemcpyAsync(fb, f->bt.first_new, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const int first_new = fb[0] < nb ? fb[0] : nb;       // rows [0, first_new) were walked
+        const int first_bad = fb[1];
+        if (first_new == 0 || K == 0) {
+            // the row at `pos` founds a cluster (or needs the serial path): apply a few rows one by one
+            int rc = serial((int)((nrows - pos) < 32 ? (nrows - pos) : 32));
+            if (rc) return rc;
+            continue;
+        }
+        if (first_bad >= first_new) {                        // every decision verified
+            commit();
+            pos += first_new; c->ff_batches++;
+            if (first_new < nb) { int rc = serial(1); if (rc) return rc; }
+            else B = B * 2 > FF_BMAX ? FF_BMAX : B * 2;
+            continue;
+        }
+        // first wrong speculation (or support growth) at row first_bad: rows before it are exact
+        c->ff_rewalks++;
+        if (first_bad > 0) {
+            // FF_BREAK / founding rows inside [0, first_bad) cannot exist (first_bad < first_new)
+            HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 8, hipMemcpyHostToDevice, c->stream));
+            k_ff_walk<<<dim3((unsigned)K), dim3(64), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, first_bad);
+            HIP_TRY(c, hipGetLastError());
+            commit();
+            pos += first_bad; c->ff_batches++;
+        }
+        int rc = serial(1);
+        if (rc) return rc;
+        // the next event is probably about as far away as this one was
+        B = first_bad * 2 < 256 ? 256 : (first_bad * 2 > FF_BMAX ? FF_BMAX : first_bad * 2);
+    }
+    *consumed = pos;
+    return SIT_OK;
+}

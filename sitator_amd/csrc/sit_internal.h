@@ -97,6 +97,9 @@ struct sit_ctx {
     double *d_fit_nrm2 = nullptr;    // [fit_cap]
     i64 *d_fit_counts = nullptr;      // [fit_cap]
     i64 *d_fit_K = nullptr;           // device scalar
+    void *fitfast = nullptr;          // sparse speculative fit state (fitfast.hip)
+    bool fit_use_fast = true;         // SITATOR_FIT=serial disables it
+    i64 ff_batches = 0, ff_serial_rows = 0, ff_rewalks = 0;
 
     // scalars on device
     u64 *d_err = nullptr;             // packed first-offender key (atomicMin)
@@ -217,6 +220,13 @@ __device__ __forceinline__ Best best_of(double v, i64 i)
 // host-side pieces implemented in other translation units
 int sit_predict_internal(sit_ctx *c, double threshold);
 int sit_label_counts(sit_ctx *c);
+void fitfast_free(sit_ctx *c);
+bool fitfast_valid(sit_ctx *c);
+void fitfast_invalidate(sit_ctx *c);
+int fitfast_set_state(sit_ctx *c, const double *cen, const i64 *cnt, i64 K);
+int fitfast_to_dense(sit_ctx *c, std::vector<double> &cen, std::vector<i64> &cnt, i64 *Kout);
+int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val, const i64 *weights, i64 stride,
+                   i64 nrows, double threshold, i64 *consumed);
 struct CandidateTable {
     int G[3];
     i64 W;

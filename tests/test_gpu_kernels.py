@@ -98,3 +98,51 @@ def test_empty_trajectory():
     rc, nz, err = ctx.fill()
     assert rc == 0 and nz == 0
     assert ctx.rows_dense().shape == (0, len(host.centers))
+
+
+def _fit_once(X_ctx_factory, mode):
+    import os
+    from sitator_amd import DotProdClassifier
+    if mode == "serial":
+        os.environ["SITATOR_FIT"] = "serial"
+    try:
+        lv = X_ctx_factory()
+    finally:
+        os.environ.pop("SITATOR_FIT", None)
+    clf = DotProdClassifier(threshold=0.45, min_samples=1)
+    clf.fit_centers(lv)
+    return clf.cluster_centers, lv.ctx.info()
+
+
+@pytest.mark.parametrize("cfg,M,F", [("C2", 64, 1500), ("C1b", 4, 3000), ("C5", 160, 200)])
+def test_speculative_fit_equals_serial_fit(cfg, M, F):
+    """fit_centers: the parallel speculate/walk/verify path must give the centres of the strictly
+    ordered single-workgroup stream (same decisions; values equal up to the norm's summation order)."""
+    from sitator_amd import synth
+    from sitator_amd.dotprod_classifier import LandmarkVectors
+    host = synth.config_host(cfg)
+
+    def factory():
+        ctx, *_ = _setup(host, M, F, seed=31)
+        assert ctx.fill()[0] == 0
+        return LandmarkVectors(ctx)
+
+    fast, info = _fit_once(factory, "fast")
+    serial, _ = _fit_once(factory, "serial")
+    assert fast.shape == serial.shape
+    np.testing.assert_allclose(fast, serial, rtol=1e-12, atol=1e-300)
+    assert info["fit_batches"] > 0, "the speculative path did not run"
+
+
+def test_speculative_fit_matches_oracle(oracle):
+    from sitator_amd import synth, DotProdClassifier
+    from sitator_amd.dotprod_classifier import LandmarkVectors
+    host = synth.config_host("C2")
+    ctx, *_ = _setup(host, 64, 250, seed=8)
+    assert ctx.fill()[0] == 0
+    X = ctx.rows_dense()
+    clf = DotProdClassifier(threshold=0.45, min_samples=1)
+    clf.fit_centers(LandmarkVectors(ctx))
+    exp = oracle.fit_centers(X, 0.45)
+    assert clf.cluster_centers.shape == exp.shape
+    np.testing.assert_allclose(clf.cluster_centers, exp, rtol=1e-12, atol=1e-300)
