@@ -15,6 +15,8 @@
 // ordered like the dense one.
 #include <algorithm>
 #include <cmath>
+#include <thread>
+#include <utility>
 
 #include "sit_internal.h"
 
@@ -87,66 +89,89 @@ int sit_build_candidates(sit_ctx *c, const double *ref_static, const i64 *verts,
         }
     rb += 1e-6;   // also absorbs rounding of the device-side bin index
     const i64 nb = (i64)G[0] * G[1] * G[2];
-    std::vector<std::vector<i32>> lists((size_t)nb);
+    if (nb * 4 > 2000000000LL) { c->msg = "candidate table too large"; return SIT_ERR_CAPACITY; }
 
-    std::vector<double> T((size_t)V);
-    for (i64 k = 0; k < D; k++) {
-        i64 nv = 0;
-        int best = -1;
-        for (i64 h = 0; h < V; h++) {
-            if (verts[k * V + h] < 0) break;
-            T[h] = c->rz * vcd[k * V + h] * (1.0 + 1e-9) + displacement * (1.0 + 1e-9) + rb + 1e-9;
-            if (best < 0 || T[h] < T[best]) best = (int)h;
-            nv++;
-        }
-        if (nv == 0) {   // no vertex: component is pow(1, inf) = 1 everywhere
-            for (i64 b = 0; b < nb; b++) lists[(size_t)b].push_back((i32)k);
-            continue;
-        }
-        // bins whose centre can be within T[best] of the tightest vertex
-        const double *rv = ref_static + 3 * verts[k * V + best];
-        double f0[3];
-        matvec(cell.ci, rv, f0);
-        int lo[3], cnt[3];
-        for (int i = 0; i < 3; i++) {
-            double w = T[best] / cell.h[i];
-            double a = (f0[i] - w) * G[i] - 0.5, b = (f0[i] + w) * G[i] - 0.5;
-            i64 ia = (i64)std::ceil(a - 1e-9), ib = (i64)std::floor(b + 1e-9);
-            i64 n = ib - ia + 1;
-            if (n >= G[i]) { lo[i] = 0; cnt[i] = G[i]; }
-            else if (n <= 0) { lo[i] = 0; cnt[i] = 0; }
-            else { lo[i] = (int)(((ia % G[i]) + G[i]) % G[i]); cnt[i] = (int)n; }
-        }
-        for (int ix = 0; ix < cnt[0]; ix++)
-            for (int iy = 0; iy < cnt[1]; iy++)
-                for (int iz = 0; iz < cnt[2]; iz++) {
-                    int bx = (lo[0] + ix) % G[0], by = (lo[1] + iy) % G[1], bz = (lo[2] + iz) % G[2];
-                    double fc[3] = {(bx + 0.5) / G[0], (by + 0.5) / G[1], (bz + 0.5) / G[2]}, cb[3];
-                    matvec(cell.cm, fc, cb);
-                    bool ok = true;
-                    for (i64 h = 0; h < nv && ok; h++) {
-                        const double *p = ref_static + 3 * verts[k * V + h];
-                        double d[3] = {p[0] - cb[0], p[1] - cb[1], p[2] - cb[2]};
-                        ok = within_periodic(cell, d, T[h]);
+    // Landmarks are split into contiguous ranges, one per host thread; each thread emits (bin, k) pairs in
+    // ascending k, so concatenating the threads' pairs per bin in thread order keeps every list ascending.
+    unsigned T = std::thread::hardware_concurrency();
+    if (T == 0) T = 4;
+    if (T > 16) T = 16;
+    if ((i64)T > D) T = (unsigned)D;
+    std::vector<std::vector<std::pair<i32, i32>>> pairs(T);
+    auto work = [&](unsigned t) {
+        std::vector<std::pair<i32, i32>> &out_pairs = pairs[t];
+        std::vector<double> Tr((size_t)V);
+        const i64 k_lo = D * t / T, k_hi = D * (t + 1) / T;
+        for (i64 k = k_lo; k < k_hi; k++) {
+            i64 nv = 0;
+            int best = -1;
+            for (i64 h = 0; h < V; h++) {
+                if (verts[k * V + h] < 0) break;
+                Tr[h] = c->rz * vcd[k * V + h] * (1.0 + 1e-9) + displacement * (1.0 + 1e-9) + rb + 1e-9;
+                if (best < 0 || Tr[h] < Tr[best]) best = (int)h;
+                nv++;
+            }
+            if (nv == 0) {   // no vertex: component is pow(1, inf) = 1 everywhere
+                for (i64 b = 0; b < nb; b++) out_pairs.emplace_back((i32)b, (i32)k);
+                continue;
+            }
+            // bins whose centre can be within Tr[best] of the tightest vertex
+            const double *rv = ref_static + 3 * verts[k * V + best];
+            double f0[3];
+            matvec(cell.ci, rv, f0);
+            int lo[3], cnt[3];
+            for (int i = 0; i < 3; i++) {
+                double w = Tr[best] / cell.h[i];
+                double a = (f0[i] - w) * G[i] - 0.5, b = (f0[i] + w) * G[i] - 0.5;
+                i64 ia = (i64)std::ceil(a - 1e-9), ib = (i64)std::floor(b + 1e-9);
+                i64 n = ib - ia + 1;
+                if (n >= G[i]) { lo[i] = 0; cnt[i] = G[i]; }
+                else if (n <= 0) { lo[i] = 0; cnt[i] = 0; }
+                else { lo[i] = (int)(((ia % G[i]) + G[i]) % G[i]); cnt[i] = (int)n; }
+            }
+            const size_t first = out_pairs.size();
+            for (int ix = 0; ix < cnt[0]; ix++)
+                for (int iy = 0; iy < cnt[1]; iy++)
+                    for (int iz = 0; iz < cnt[2]; iz++) {
+                        int bx = (lo[0] + ix) % G[0], by = (lo[1] + iy) % G[1], bz = (lo[2] + iz) % G[2];
+                        double fc[3] = {(bx + 0.5) / G[0], (by + 0.5) / G[1], (bz + 0.5) / G[2]}, cb[3];
+                        matvec(cell.cm, fc, cb);
+                        bool ok = true;
+                        for (i64 h = 0; h < nv && ok; h++) {
+                            const double *p = ref_static + 3 * verts[k * V + h];
+                            double d[3] = {p[0] - cb[0], p[1] - cb[1], p[2] - cb[2]};
+                            ok = within_periodic(cell, d, Tr[h]);
+                        }
+                        if (ok) out_pairs.emplace_back((i32)(((i64)bx * G[1] + by) * G[2] + bz), (i32)k);
                     }
-                    if (ok) {
-                        std::vector<i32> &l = lists[(size_t)(((i64)bx * G[1] + by) * G[2] + bz)];
-                        if (l.empty() || l.back() != (i32)k) l.push_back((i32)k);
-                    }
-                }
+            (void)first;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
     }
+    // counting sort by bin, threads in order (=> ascending k inside a bin)
     bin_off.assign((size_t)nb + 1, 0);
-    i64 total = 0, W = 1;
-    for (i64 b = 0; b < nb; b++) {
-        bin_off[(size_t)b] = (i32)total;
-        total += (i64)lists[(size_t)b].size();
-        W = std::max(W, (i64)lists[(size_t)b].size());
-        if (total > 2000000000LL) { c->msg = "candidate table too large"; return SIT_ERR_CAPACITY; }
+    i64 total = 0;
+    for (unsigned t = 0; t < T; t++) {
+        total += (i64)pairs[t].size();
+        for (auto &pr : pairs[t]) bin_off[(size_t)pr.first + 1]++;
     }
-    bin_off[(size_t)nb] = (i32)total;
-    bin_list.resize((size_t)std::max<i64>(total, 1));
-    for (i64 b = 0; b < nb; b++)
-        std::copy(lists[(size_t)b].begin(), lists[(size_t)b].end(), bin_list.begin() + bin_off[(size_t)b]);
+    if (total > 2000000000LL) { c->msg = "candidate table too large"; return SIT_ERR_CAPACITY; }
+    i64 W = 1;
+    for (i64 b = 0; b < nb; b++) {
+        if (bin_off[(size_t)b + 1] > W) W = bin_off[(size_t)b + 1];
+        bin_off[(size_t)b + 1] += bin_off[(size_t)b];
+    }
+    bin_list.assign((size_t)std::max<i64>(total, 1), 0);
+    {
+        std::vector<i32> cursor(bin_off.begin(), bin_off.end() - 1);
+        for (unsigned t = 0; t < T; t++)
+            for (auto &pr : pairs[t]) bin_list[(size_t)cursor[(size_t)pr.first]++] = pr.second;
+    }
     out.W = W;
     out.mean = (double)total / (double)nb;
     return SIT_OK;

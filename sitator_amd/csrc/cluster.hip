@@ -402,12 +402,12 @@ extern "C" int sit_fit_get_state(sit_ctx *c, double *centers, i64 *counts, i64 *
 }
 
 static int fit_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val, const i64 *weights,
-                      i64 stride, i64 nrows, double threshold)
+                      i64 stride, int width, i64 nrows, double threshold)
 {
     int rc;
     i64 begin = 0;
     if (fitfast_valid(c)) {
-        if ((rc = fitfast_stream(c, nnz, idx, val, weights, stride, nrows, threshold, &begin))) return rc;
+        if ((rc = fitfast_stream(c, nnz, idx, val, weights, stride, width, nrows, threshold, &begin))) return rc;
         if (begin >= nrows && fitfast_valid(c)) return SIT_OK;
         // a capacity of the sparse state was exceeded: hand the exact state over to the serial dense kernel
         std::vector<double> cen; std::vector<i64> cnt; i64 Kd = 0;
@@ -460,7 +460,7 @@ extern "C" int sit_fit_push_stored_rows(sit_ctx *c, double threshold)
     SIT_REQUIRE(c, c->rows_valid, "sit_fit_push_stored_rows: no landmark rows on the device");
     HIP_TRY(c, hipSetDevice(c->device));
     StageTimer t(c, T_FIT);
-    int rc = fit_stream(c, c->d_row_nnz, c->d_row_idx, c->d_row_val, nullptr, c->N, c->N, threshold);
+    int rc = fit_stream(c, c->d_row_nnz, c->d_row_idx, c->d_row_val, nullptr, c->N, (int)c->rows_W, c->N, threshold);
     t.stop();
     return rc;
 }
@@ -490,7 +490,7 @@ extern "C" int sit_fit_push_dense_rows(sit_ctx *c, const double *rows, const i64
     if ((rc = dev_upload(c, &dv, val.data(), nrows * D))) return rc;
     if (weights && (rc = dev_upload(c, &dw, weights, nrows))) return rc;
     StageTimer t(c, T_FIT);
-    rc = fit_stream(c, dn, di, dv, dw, nrows, nrows, threshold);
+    rc = fit_stream(c, dn, di, dv, dw, nrows, (int)D, nrows, threshold);
     t.stop();
     (void)hipFree(dn); (void)hipFree(di); (void)hipFree(dv); if (dw) (void)hipFree(dw);
     return rc;

@@ -28,6 +28,7 @@
 #define FF_DC 32        // centres listed per landmark dimension
 #define FF_OC 16        // overlapping centres recorded per row
 #define FF_BMAX 65536   // rows per batch
+#define FF_LOG 2048     // support-growth records per walk
 #define FF_NEW (-1)
 #define FF_BREAK (-2)   // row must be applied serially (zero row, capacity)
 
@@ -36,6 +37,7 @@ struct FFRows {
     const double *val;
     const i64 *weights;   // null => 1
     i64 stride;
+    int width;            // slots per row
 };
 
 struct FFState {
@@ -49,10 +51,12 @@ struct FFState {
     i64 D, Kcap;
 };
 
+#define OV(b, j, p) (b).ov_id[(i64)(p) * FF_BMAX + (j)]     // slot-major: coalesced across rows
 struct FFBatch {
-    i32 *dec, *ov_n, *ov_id;
+    i32 *dec, *ov_n, *ov_id, *ov_max;
     double *vcos, *xn;
     i32 *first_new, *first_bad;
+    i32 *log_n, *log;         // growth log of the last walk: (centre, dimension, batch row) triples
 };
 
 // value of centre c at dimension d (0 when d is outside its support); binary search in the sorted support
@@ -70,7 +74,7 @@ __device__ __forceinline__ double ff_at(const FFState &s, i32 c, i32 d)
 // The reference's decision for one row against the state `s` (:238-247): overlapping centres into ov[]
 // (ascending id), returns the centre joined, FF_NEW, or FF_BREAK.  `K` centres exist.
 __device__ int ff_decide(const FFState &s, const FFRows &r, i64 row, double threshold, int K,
-                         i32 *ov, int &nov, double &xn_out)
+                         i32 *ovb, i64 ovs, int &nov, double &xn_out)
 {
     const int n = r.nnz[row];
     nov = 0;
@@ -86,16 +90,16 @@ __device__ int ff_decide(const FFState &s, const FFRows &r, i64 row, double thre
         for (int q = 0; q < m; q++) {
             const i32 c = s.dc_list[(i64)d * FF_DC + q];
             int p = 0;
-            while (p < nov && ov[p] < c) p++;
-            if (p < nov && ov[p] == c) continue;
+            while (p < nov && ovb[p * ovs] < c) p++;
+            if (p < nov && ovb[p * ovs] == c) continue;
             if (nov == FF_OC) return FF_BREAK;
-            for (int t = nov; t > p; t--) ov[t] = ov[t - 1];
-            ov[p] = c; nov++;
+            for (int t = nov; t > p; t--) ovb[t * ovs] = ovb[(t - 1) * ovs];
+            ovb[p * ovs] = c; nov++;
         }
     }
     Best b = best_empty();
     for (int p = 0; p < nov; p++) {
-        const i32 c = ov[p];
+        const i32 c = ovb[p * ovs];
         double dot = 0.0;
         for (int e = 0; e < n; e++)
             dot += ff_at(s, c, r.idx[(i64)e * r.stride + row]) * r.val[(i64)e * r.stride + row];
@@ -105,7 +109,7 @@ __device__ int ff_decide(const FFState &s, const FFRows &r, i64 row, double thre
     }
     if (nov < K) {                                        // every other centre scores exactly 0
         i32 k0 = 0;
-        for (int p = 0; p < nov && ov[p] == k0; p++) k0++;
+        for (int p = 0; p < nov && ovb[p * ovs] == k0; p++) k0++;
         b = best_merge(b, best_of(0.0, k0));
     }
     if (b.i < 0) return FF_NEW;
@@ -121,18 +125,46 @@ __global__ __launch_bounds__(256) void k_ff_speculate(FFState s, FFRows r, FFBat
     const int K = *s.K;
     int nov;
     double xn;
-    i32 *ov = b.ov_id + (i64)j * FF_OC;
-    int dec = ff_decide(s, r, row0 + j, threshold, K, ov, nov, xn);
+    i32 *ov = b.ov_id + j;
+    const i64 ovs = FF_BMAX;
+    int dec = ff_decide(s, r, row0 + j, threshold, K, ov, ovs, nov, xn);
     if (dec >= 0) {                                       // the joined centre must be in the list the walk reads
         int p = 0;
-        while (p < nov && ov[p] < dec) p++;
-        if (!(p < nov && ov[p] == dec)) {
+        while (p < nov && ov[p * ovs] < dec) p++;
+        if (!(p < nov && ov[p * ovs] == dec)) {
             if (nov == FF_OC) dec = FF_BREAK;
-            else { for (int t = nov; t > p; t--) ov[t] = ov[t - 1]; ov[p] = dec; nov++; }
+            else { for (int t = nov; t > p; t--) ov[t * ovs] = ov[(t - 1) * ovs]; ov[p * ovs] = dec; nov++; }
         }
     }
     b.dec[j] = dec; b.ov_n[j] = nov; b.xn[j] = xn;
+    b.ov_max[j] = nov > 0 ? ov[(nov - 1) * ovs] : -1;
     if (dec < 0) atomicMin(b.first_new, j);
+}
+
+struct Pre {
+    int m, omax, n, dec;
+    i32 o0, o1, o2, o3;
+    double xn;
+    i64 w;
+    i32 i0, i1, i2, i3;
+    double v0, v1, v2, v3;
+};
+
+__device__ __forceinline__ void ff_load_pre(Pre &P, const FFRows &r, const FFBatch &b, i64 row0, int j, int nb)
+{
+    P.m = 0; P.omax = -1; P.n = 0; P.dec = FF_BREAK; P.xn = 1.0; P.w = 1;
+    P.o0 = P.o1 = P.o2 = P.o3 = 0; P.i0 = P.i1 = P.i2 = P.i3 = 0; P.v0 = P.v1 = P.v2 = P.v3 = 0.0;
+    if (j < nb) {
+        const i64 row = row0 + j;
+        P.m = b.ov_n[j]; P.omax = b.ov_max[j];
+        P.o0 = OV(b, j, 0); P.o1 = OV(b, j, 1); P.o2 = OV(b, j, 2); P.o3 = OV(b, j, 3);
+        P.n = r.nnz[row]; P.dec = b.dec[j]; P.xn = b.xn[j];
+        if (r.weights) P.w = r.weights[row];
+        P.i0 = r.idx[row]; P.v0 = r.val[row];
+        if (r.width > 1) { P.i1 = r.idx[r.stride + row]; P.v1 = r.val[r.stride + row]; }
+        if (r.width > 2) { P.i2 = r.idx[2 * r.stride + row]; P.v2 = r.val[2 * r.stride + row]; }
+        if (r.width > 3) { P.i3 = r.idx[3 * r.stride + row]; P.v3 = r.val[3 * r.stride + row]; }
+    }
 }
 
 // ---- B: walk ----------------------------------------------------------------------------------------
@@ -150,17 +182,28 @@ __global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, 
     double val = lane < sn ? s.cs_val[(i64)k * FF_CS + lane] : 0.0;
     i64 cnt = s.c_cnt[k];
     double nrm = s.c_nrm[k];
+    // Per chunk of 64 rows every lane needs its row's overlap list head and (if it lists me) the row itself.
+    // All of it is loaded unconditionally in one batch of independent loads, one chunk AHEAD of its use, so the
+    // chunk loop pays one memory round trip per iteration instead of three dependent ones.
+    Pre cur, nxt;
+    ff_load_pre(cur, r, b, row0, lane, nb);
     for (int j0 = 0; j0 < nb; j0 += 64) {
         // rows at or after the first known invalid row are void anyway (first_bad only ever decreases)
         if (j0 > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        ff_load_pre(nxt, r, b, row0, j0 + 64 + lane, nb);
         const int j = j0 + lane;
         int slot = -1;
-        if (j < nb) {
-            const int m = b.ov_n[j];
-            const i32 *ov = b.ov_id + (i64)j * FF_OC;
-            if (m > 0 && ov[0] <= k && ov[m - 1] >= k)
-                for (int p = 0; p < m; p++) if (ov[p] == k) { slot = p; break; }
+        if (cur.m > 0 && cur.o0 <= k && cur.omax >= k) {
+            if (cur.o0 == k) slot = 0;
+            else if (cur.m > 1 && cur.o1 == k) slot = 1;
+            else if (cur.m > 2 && cur.o2 == k) slot = 2;
+            else if (cur.m > 3 && cur.o3 == k) slot = 3;
+            else for (int p = 4; p < cur.m; p++) if (OV(b, j, p) == k) { slot = p; break; }
         }
+        const int pn = cur.n, pdec = cur.dec; const i64 pw = cur.w; const double pxn = cur.xn;
+        const i32 pi0 = cur.i0, pi1 = cur.i1, pi2 = cur.i2, pi3 = cur.i3;
+        const double pv0 = cur.v0, pv1 = cur.v1, pv2 = cur.v2, pv3 = cur.v3;
+        cur = nxt;
         unsigned long long todo = __ballot(slot >= 0);
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
@@ -168,33 +211,48 @@ __global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, 
             const int jj = j0 + src;
             const int sl = __shfl(slot, src);
             const i64 row = row0 + jj;
-            const int n = r.nnz[row];
+            const int n = __shfl(pn, src);
+            const int rdec = __shfl(pdec, src);
+            const double rxn = __shfl(pxn, src);
+            const i64 w = __shfl(pw, src);
+            const i32 qi0 = __shfl(pi0, src), qi1 = __shfl(pi1, src), qi2 = __shfl(pi2, src), qi3 = __shfl(pi3, src);
+            const double qv0 = __shfl(pv0, src), qv1 = __shfl(pv1, src), qv2 = __shfl(pv2, src), qv3 = __shfl(pv3, src);
+#define ROW_IDX(e) ((e) == 0 ? qi0 : (e) == 1 ? qi1 : (e) == 2 ? qi2 : (e) == 3 ? qi3 : r.idx[(i64)(e) * r.stride + row])
+#define ROW_VAL(e) ((e) == 0 ? qv0 : (e) == 1 ? qv1 : (e) == 2 ? qv2 : (e) == 3 ? qv3 : r.val[(i64)(e) * r.stride + row])
             // score with the current state: dot in ascending dimension order (:238-240)
             double dot = 0.0;
             for (int e = 0; e < n; e++) {
-                const i32 d = r.idx[(i64)e * r.stride + row];
+                const i32 d = ROW_IDX(e);
                 const unsigned long long hit = __ballot(idx == d);
-                if (hit) dot += __shfl(val, __ffsll((long long)hit) - 1) * r.val[(i64)e * r.stride + row];
+                if (hit) dot += __shfl(val, __ffsll((long long)hit) - 1) * ROW_VAL(e);
             }
             dot /= nrm;
-            dot /= b.xn[jj];
-            if (lane == 0) b.vcos[(i64)jj * FF_OC + sl] = dot;
-            if (b.dec[jj] == k) {                                     // running-mean update (:283-288)
-                const i64 w = r.weights ? r.weights[row] : 1;
+            dot /= rxn;
+            if (lane == 0) b.vcos[(i64)sl * FF_BMAX + jj] = dot;
+            if (rdec == k) {                                          // running-mean update (:283-288)
                 const double fo = (double)cnt, fn = (double)(cnt + w);
-                bool grew = false;
                 val *= fo;
                 for (int e = 0; e < n; e++) {
-                    const i32 d = r.idx[(i64)e * r.stride + row];
-                    const double v = r.val[(i64)e * r.stride + row];
+                    const i32 d = ROW_IDX(e);
+                    const double v = ROW_VAL(e);
                     const unsigned long long hit = __ballot(idx == d);
-                    if (hit) { if (idx == d) val += v; }
-                    else grew = true;                                 // new support entry: serial path
-                }
-                if (grew) {
-                    // undo nothing: the walk of this batch is void from row jj on; report and stop using it
-                    if (lane == 0) atomicMin(b.first_bad, jj);
-                    return;
+                    if (hit) { if (idx == d) val += v; continue; }
+                    // the centre gains dimension d (0 * fo + v): sorted insertion across the lanes, and a log
+                    // record so that later rows holding d without listing this centre are invalidated
+                    int slot_l = 0;
+                    if (lane == 0) slot_l = atomicAdd(b.log_n, 1);
+                    slot_l = __shfl(slot_l, 0);
+                    if (sn == FF_CS || slot_l >= FF_LOG) {
+                        if (lane == 0) atomicMin(b.first_bad, jj);       // capacity: this row goes the serial way
+                        return;
+                    }
+                    if (lane == 0) { b.log[3 * slot_l] = k; b.log[3 * slot_l + 1] = d; b.log[3 * slot_l + 2] = jj; }
+                    const int p = __popcll(__ballot(idx < d));
+                    const i32 idx_up = __shfl_up(idx, 1);
+                    const double val_up = __shfl_up(val, 1);
+                    if (lane > p) { idx = idx_up; val = val_up; }
+                    else if (lane == p) { idx = d; val = v; }
+                    sn++;
                 }
                 val /= fn;
                 cnt += w;
@@ -209,7 +267,7 @@ __global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, 
 }
 
 // ---- C: verify ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFBatch b, int nb, double threshold)
+__global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFRows r, FFBatch b, i64 row0, int nb, double threshold)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     {
@@ -219,16 +277,46 @@ __global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFBatch b, int nb,
     if (j >= nb) return;
     const int K = *s.K;
     const int m = b.ov_n[j];
-    const i32 *ov = b.ov_id + (i64)j * FF_OC;
     Best best = best_empty();
-    for (int p = 0; p < m; p++) best = best_merge(best, best_of(b.vcos[(i64)j * FF_OC + p], ov[p]));
+    for (int p = 0; p < m; p++) best = best_merge(best, best_of(b.vcos[(i64)p * FF_BMAX + j], OV(b, j, p)));
     if (m < K) {
         i32 k0 = 0;
-        for (int p = 0; p < m && ov[p] == k0; p++) k0++;
+        for (int p = 0; p < m && OV(b, j, p) == k0; p++) k0++;
         best = best_merge(best, best_of(0.0, k0));
     }
     int dec = (best.i < 0 || best.v < threshold) ? FF_NEW : (int)best.i;
     if (dec != b.dec[j]) atomicMin(b.first_bad, j);
+    // a centre that gained a dimension earlier in this batch overlaps me now, but I did not list it
+    int nl = *b.log_n;
+    if (nl > FF_LOG) nl = FF_LOG;
+    if (nl > 0) {
+        const i64 row = row0 + j;
+        const int n = r.nnz[row];
+        for (int q = 0; q < nl; q++) {
+            if (b.log[3 * q + 2] >= j) continue;
+            const i32 kk = b.log[3 * q], dd = b.log[3 * q + 1];
+            bool has = false;
+            for (int e = 0; e < n; e++) if (r.idx[(i64)e * r.stride + row] == dd) { has = true; break; }
+            if (!has) continue;
+            bool listed = false;
+            for (int p = 0; p < m; p++) if (OV(b, j, p) == kk) { listed = true; break; }
+            if (!listed) { atomicMin(b.first_bad, j); break; }
+        }
+    }
+}
+
+// after a commit: the centres that gained dimensions become visible in the per-dimension lists
+__global__ void k_ff_apply_growth(FFState s, FFBatch b)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    int nl = *b.log_n;
+    if (nl > FF_LOG) nl = FF_LOG;
+    for (int q = 0; q < nl; q++) {
+        const i32 kk = b.log[3 * q], dd = b.log[3 * q + 1];
+        if (s.dc_n[dd] >= FF_DC) { s.flags[0] = 1; continue; }
+        s.dc_list[(i64)dd * FF_DC + s.dc_n[dd]] = kk; s.dc_n[dd]++;
+    }
+    *b.log_n = 0;
 }
 
 // ---- serial application of rows (founding rows, support growth, capacity breakers) -------------------
@@ -244,7 +332,7 @@ __global__ void k_ff_serial(FFState s, FFRows r, i64 row0, int count, double thr
         const i64 w = r.weights ? r.weights[row] : 1;
         int nov;
         double xn;
-        int dec = ff_decide(s, r, row, threshold, K, scratch_ov, nov, xn);
+        int dec = ff_decide(s, r, row, threshold, K, scratch_ov, 1, nov, xn);
         if (dec == FF_BREAK) { s.flags[0] = 1; break; }
         if (dec == FF_NEW) {                                          // :250-260
             if (K >= s.Kcap || n > FF_CS) { s.flags[0] = 1; break; }
@@ -337,7 +425,7 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     const i64 D = c->D;
     size_t per_state = (size_t)Kcap * (4 + FF_CS * 12 + 16) + 4096;
     size_t total = 2 * per_state + (size_t)D * (4 + FF_DC * 4) + 8192
-                 + (size_t)FF_BMAX * (4 + 4 + FF_OC * 4 + FF_OC * 8 + 8) + 65536;
+                 + (size_t)FF_BMAX * (4 + 4 + 4 + FF_OC * 4 + FF_OC * 8 + 8) + 65536 + (size_t)FF_LOG * 12 + 4096;
     HIP_TRY(c, hipMalloc(&f->blob, total));
     HIP_TRY(c, hipMemsetAsync(f->blob, 0, total, c->stream));
     char *p = (char *)f->blob;
@@ -345,7 +433,7 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     i32 *dc_n = (i32 *)carve(p, (size_t)D * 4);
     i32 *dc_list = (i32 *)carve(p, (size_t)D * FF_DC * 4);
     i32 *Kp = (i32 *)carve(p, 64);
-    i32 *flags = (i32 *)carve(p, 64);
+    i32 *flags = nullptr;     // placed next to first_new below (read back with it)
     for (FFState *s : ss) {
         s->cs_n = (i32 *)carve(p, (size_t)Kcap * 4);
         s->cs_idx = (i32 *)carve(p, (size_t)Kcap * FF_CS * 4);
@@ -356,11 +444,15 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     }
     f->bt.dec = (i32 *)carve(p, (size_t)FF_BMAX * 4);
     f->bt.ov_n = (i32 *)carve(p, (size_t)FF_BMAX * 4);
+    f->bt.ov_max = (i32 *)carve(p, (size_t)FF_BMAX * 4);
     f->bt.ov_id = (i32 *)carve(p, (size_t)FF_BMAX * FF_OC * 4);
     f->bt.vcos = (double *)carve(p, (size_t)FF_BMAX * FF_OC * 8);
     f->bt.xn = (double *)carve(p, (size_t)FF_BMAX * 8);
     f->bt.first_new = (i32 *)carve(p, 64);
     f->bt.first_bad = f->bt.first_new + 1;
+    f->bt.log_n = f->bt.first_new + 2;
+    f->st.flags = f->sh.flags = f->bt.first_new + 3;
+    f->bt.log = (i32 *)carve(p, (size_t)FF_LOG * 12);
     f->d_scr = (i32 *)carve(p, 256);
     f->D = D; f->Kcap = Kcap; f->ready = true; f->valid = false;
     return SIT_OK;
@@ -446,18 +538,18 @@ int fitfast_set_state(sit_ctx *c, const double *cen, const i64 *cnt, i64 K)
 // Streams rows [0, nrows) through the sparse state.  *consumed = rows applied; less than nrows when a
 // capacity was exceeded (the caller continues with the dense serial kernel from the exported state).
 int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val, const i64 *weights, i64 stride,
-                   i64 nrows, double threshold, i64 *consumed)
+                   int width, i64 nrows, double threshold, i64 *consumed)
 {
     FitFast *f = ff_of(c);
     *consumed = 0;
     if (!f->valid) return SIT_OK;
-    FFRows r; r.nnz = nnz; r.idx = idx; r.val = val; r.weights = weights; r.stride = stride;
+    FFRows r; r.nnz = nnz; r.idx = idx; r.val = val; r.weights = weights; r.stride = stride; r.width = width;
     i64 pos = 0;
     int B = 256;
     i32 K = 0;
     HIP_TRY(c, hipMemcpyAsync(&K, f->st.K, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const i32 big2[2] = {0x7fffffff, 0x7fffffff};
+    const i32 big2[3] = {0x7fffffff, 0x7fffffff, 0};     // first_new, first_bad, log_n
     auto serial = [&](int count) -> int {     // apply `count` rows one by one (exact), refresh K
         k_ff_serial<<<dim3(1), dim3(64), 0, c->stream>>>(f->st, r, pos, count, threshold, f->d_scr, f->d_scr + 32);
         HIP_TRY(c, hipGetLastError());
@@ -472,6 +564,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
     };
     auto commit = [&]() {                     // the walked (shadow) state becomes the state
         FFState t = f->st; f->st = f->sh; f->sh = t;
+        k_ff_apply_growth<<<dim3(1), dim3(64), 0, c->stream>>>(f->st, f->bt);
     };
     while (pos < nrows && f->valid) {
         if (K + 64 > f->Kcap) {          // grow: export, reallocate, import
@@ -485,16 +578,17 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         }
         const int nb = (int)((nrows - pos) < B ? (nrows - pos) : B);
         // first_new and first_bad are adjacent words
-        HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 12, hipMemcpyHostToDevice, c->stream));
         k_ff_speculate<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
         if (K > 0) {
             k_ff_walk<<<dim3((unsigned)K), dim3(64), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, nb);
-            k_ff_verify<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, f->bt, nb, threshold);
+            k_ff_verify<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
         }
         HIP_TRY(c, hipGetLastError());
-        i32 fb[2] = {0, 0};
-        HIP_TRY(c, hipMemcpyAsync(fb, f->bt.first_new, 8, hipMemcpyDeviceToHost, c->stream));
+        i32 fb[4] = {0, 0, 0, 0};
+        HIP_TRY(c, hipMemcpyAsync(fb, f->bt.first_new, 16, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (fb[3]) { f->valid = false; break; }              // a capacity was exceeded: state is exact as of `pos`
         const int first_new = fb[0] < nb ? fb[0] : nb;       // rows [0, first_new) were walked
         const int first_bad = fb[1];
         if (first_new == 0 || K == 0) {
@@ -514,7 +608,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         c->ff_rewalks++;
         if (first_bad > 0) {
             // FF_BREAK / founding rows inside [0, first_bad) cannot exist (first_bad < first_new)
-            HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 12, hipMemcpyHostToDevice, c->stream));
             k_ff_walk<<<dim3((unsigned)K), dim3(64), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, first_bad);
             HIP_TRY(c, hipGetLastError());
             commit();

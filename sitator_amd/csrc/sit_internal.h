@@ -226,7 +226,7 @@ void fitfast_invalidate(sit_ctx *c);
 int fitfast_set_state(sit_ctx *c, const double *cen, const i64 *cnt, i64 K);
 int fitfast_to_dense(sit_ctx *c, std::vector<double> &cen, std::vector<i64> &cnt, i64 *Kout);
 int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val, const i64 *weights, i64 stride,
-                   i64 nrows, double threshold, i64 *consumed);
+                   int width, i64 nrows, double threshold, i64 *consumed);
 struct CandidateTable {
     int G[3];
     i64 W;

@@ -14,6 +14,7 @@ and ``device``.
 """
 import importlib
 import logging
+import time
 
 import numpy as np
 
@@ -111,6 +112,13 @@ class LandmarkAnalysis(object):
         comm = self._comm
         n_frames = len(frames)
         logger.info("--- Running Landmark Analysis ---")
+        wall = {}
+        t_last = [time.perf_counter()]
+
+        def lap(name):
+            now = time.perf_counter()
+            wall[name] = wall.get(name, 0.0) + (now - t_last[0])
+            t_last[0] = now
 
         ctx = _lib.HipContext(np.asarray(sn.structure.cell, dtype=np.float64), device=self._device)
         self._ctx = ctx
@@ -129,6 +137,7 @@ class LandmarkAnalysis(object):
         ctx.set_basis(ref_static, verts_np, site_vert_dists, self._cutoff_midpoint, self._cutoff_steepness,
                       self.static_movement_threshold)
 
+        lap("context+basis")
         # Steps 0 + 2: frames to HBM; wrap, static-lattice check and landmark vectors in one pass
         frame0 = 0
         if comm.size > 1:
@@ -137,6 +146,7 @@ class LandmarkAnalysis(object):
         static_idx = np.where(sn.static_mask)[0]
         mobile_idx = np.where(sn.mobile_mask)[0]
         ctx.set_frames(frames, static_idx, mobile_idx, frame0=frame0)
+        lap("upload")
         logger.info("  - computing landmark vectors -")
         rc, n_zero, err = ctx.fill(self.dynamic_lattice_mapping, self.relaxed_lattice_checks,
                                    self.check_for_zero_landmarks)
@@ -148,6 +158,7 @@ class LandmarkAnalysis(object):
                            % self.n_all_zero_lvecs)
         self._landmark_vectors = LandmarkVectors(ctx, comm)
 
+        lap("fill")
         # Step 3: cluster (plugin located by name, :234-242)
         logger.info("  - clustering landmark vectors -")
         clustermod = importlib.import_module(".cluster." + self._cluster_algo, package=__package__)
@@ -155,6 +166,7 @@ class LandmarkAnalysis(object):
             self._landmark_vectors, clustering_params=self._clustering_params,
             min_samples=self._minimum_site_occupancy / float(sn.n_mobile), verbose=self.verbose)
 
+        lap("cluster")
         cluster_counts = clustering[self.CLUSTERING_CLUSTER_SIZE]
         lmk_lbls = clustering[self.CLUSTERING_LABELS]
         lmk_confs = clustering[self.CLUSTERING_CONFIDENCES]
@@ -183,11 +195,14 @@ class LandmarkAnalysis(object):
         if landmark_clusters is not None:                                  # :301-305
             out_sn.vertices = [set.union(*[set(sn.vertices[l]) for l in lclust]) for lclust in landmark_clusters]
 
+        lap("site_centers")
         out_st = SiteTrajectory(out_sn, lmk_lbls, lmk_confs, _ctx=ctx, _comm=comm)
         self.n_multiple_assignments, self.avg_mobile_per_site = out_st.check_multiple_occupancy(
             max_mobile_per_site=self.max_mobile_per_site)
         out_st.set_real_traj(frames)
+        lap("occupancy")
         self.timings = ctx.timers()
+        self.wall_timings = wall
         self._has_run = True
         return out_st
 
