@@ -186,6 +186,33 @@ int sit_set_assignments(sit_ctx *ctx, const int64_t *labels, const double *confs
 int sit_jump_sources(sit_ctx *ctx, int unknown_as_jump, const int64_t *last_known_in,
                      int64_t *from, int64_t *last_known_out);
 
+/* ---- the steps either side of the path ------------------------------ */
+
+/* JumpAnalysis.run (dynamics/JumpAnalysis.py:27-135) on the device-resident labels.  Outputs the raw
+ * accumulators: n_ij[K,K], time_sum[K,K] / time_n[K,K] (jump_lag = time_sum / time_n, inf where time_n
+ * is 0), total_time[K] (total_corrected_residences), n_problems.  last_known / time_at_current in (NULL at
+ * the trajectory start) and out carry the per-ion state across frame shards.                            */
+int sit_jump_analysis(sit_ctx *ctx, int64_t K, const int64_t *last_known_in,
+                      const int64_t *time_at_current_in, double *n_ij, double *time_sum,
+                      int64_t *time_n, int64_t *total_time, int64_t *n_problems,
+                      int64_t *last_known_out, int64_t *time_at_current_out);
+
+/* SiteTrajectory.assign_to_last_known_site (SiteTrajectory.py:235-304): rewrites the device labels in
+ * place (labels_out: optional host copy).  frame_max[F]: per frame the largest unknown-streak length that
+ * ended there; stats3 = (sum of streak lengths, number of streaks, positions reassigned).              */
+int sit_assign_last_known(sit_ctx *ctx, int64_t frame_threshold, const int64_t *last_known_in,
+                          const int64_t *time_unknown_in, int64_t *labels_out, int32_t *frame_max,
+                          int64_t *stats3, int64_t *last_known_out, int64_t *time_unknown_out);
+
+/* running_windowed_mode (dynamics/SmoothSiteTrajectory.pyx:79-111) of the device labels -> out[F*M].   */
+int sit_running_mode(sit_ctx *ctx, int64_t wleft, int64_t wright, int64_t threshold,
+                     int replace_no_winner_unknown, int64_t *out);
+
+/* recenter_traj_array (util/RecenterTrajectory.pyx:66-100) IN PLACE on a host array [F,A,3]:
+ * x -= sum_j (factor_j*mass_j / sum(factor*mass)) x_j per frame, then += add3 (NULL = 0).              */
+int sit_recenter(sit_ctx *ctx, double *arr, int64_t F, int64_t A, const double *masses,
+                 const double *factors, const double *add3);
+
 /* ---- measurement --------------------------------------------------------------------- */
 
 /* Device time (ms, HIP events on the library's stream) of the last call of each stage:

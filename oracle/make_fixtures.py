@@ -312,15 +312,91 @@ def dotprod_cases(ref):
     print("dotprod_known_answers %.1f KB" % (os.path.getsize(path) / 1024.0))
 
 
+def next_tier_cases(ref):
+    """Golden outputs of the steps either side of the path."""
+    import ase
+    from sitator import SiteNetwork, SiteTrajectory
+    from sitator.dynamics import JumpAnalysis
+    from sitator.dynamics.SmoothSiteTrajectory import running_windowed_mode
+    from sitator.util import RecenterTrajectory
+    blob = {}
+
+    def make_st(labels, n_sites, n_mobile):
+        at = ase.Atoms(positions=np.zeros((n_mobile + 1, 3)), numbers=[8] + [3] * n_mobile, cell=np.eye(3) * 10)
+        sm = np.array([True] + [False] * n_mobile)
+        sn = SiteNetwork(at, sm, ~sm)
+        sn.centers = np.zeros((n_sites, 3))
+        return SiteTrajectory(sn, labels.copy())
+
+    sources = {"toy": (np.array([[0, 1, 2], [0, 1, 2], [3, -1, 2], [3, 1, 2], [0, 1, -1], [0, 2, -1]]), 4)}
+    for name, tag in (("c1_hex_scgrid", "dotprod"), ("c1b_tri_bcctet", "mcl"), ("bcc_ortho", "dotprod")):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        lab = z[tag + "/labels"]
+        sources[name] = (lab, int(lab.max()) + 1)
+    rng = np.random.default_rng(9)
+    noisy = rng.integers(-1, 6, size=(400, 5))
+    noisy[rng.uniform(size=noisy.shape) < 0.6] = 2            # long stays with interruptions, early unknowns
+    noisy[:3, 0] = -1
+    sources["noisy"] = (noisy, 6)
+    blob["names"] = np.array(list(sources))
+    for name, (lab, K) in sources.items():
+        M = lab.shape[1]
+        blob[name + "/labels"] = lab
+        blob[name + "/n_sites"] = np.int64(K)
+        st = make_st(lab, K, M)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            JumpAnalysis().run(st)
+        sn = st.site_network
+        for attr in ("n_ij", "p_ij", "jump_lag", "residence_times", "occupancy_freqs", "total_corrected_residences"):
+            blob[name + "/ja_" + attr] = np.asarray(getattr(sn, attr))
+        for thr in (1, 3):
+            st2 = make_st(lab, K, M)
+            res = st2.assign_to_last_known_site(frame_threshold=thr)
+            blob[name + "/alk%d_traj" % thr] = st2.traj.copy()
+            blob[name + "/alk%d_stats" % thr] = np.array([res["max_time_unknown"], res["avg_time_unknown"], res["total_reassigned"]], dtype=np.float64)
+        for thr, factor, repl in ((3, 2.1, True), (5, 2.1, False), (2, 3.0, True)):
+            window = factor * thr
+            wl, wr = int(np.floor(window / 2)), int(np.ceil(window / 2))
+            out = lab.copy()
+            running_windowed_mode(lab.astype(np.int64), out, wl, wr, thr, K, repl)
+            blob[name + "/mode_%d_%g_%d" % (thr, factor, int(repl))] = out
+    # RecenterTrajectory
+    host = synth.config_host("C1")
+    frames, sm, mm, refpos = synth.make_trajectory(host, 4, 40, seed=71, interleave=True)
+    frames += np.linspace(0, 3, 40)[:, None, None] * np.array([1.0, -0.5, 0.25])       # drifting cell
+    at = ase.Atoms(positions=refpos, numbers=np.where(mm, 3, 8), cell=host.cell)
+    blob["rc/frames"] = frames
+    blob["rc/static_mask"] = sm
+    blob["rc/cell"] = host.cell
+    p1 = frames.copy(); v1 = frames[::-1].copy() * 0.1
+    blob["rc/velocities"] = v1.copy()
+    RecenterTrajectory().run(at, sm, p1, velocities=v1)
+    blob["rc/out_default"] = p1
+    blob["rc/out_velocities"] = v1
+    masses = np.random.default_rng(3).uniform(1, 30, size=len(sm))
+    blob["rc/masses"] = masses
+    p2 = frames.copy()
+    RecenterTrajectory().run(at, sm, p2, masses=masses)
+    blob["rc/out_masses"] = p2
+    path = os.path.join(GOLDEN, "next_tier_known_answers.npz")
+    np.savez_compressed(path, **blob)
+    print("next_tier_known_answers %.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
 def main():
     if not ref_build.available():
         print("reference not present; fixtures can only be generated in the development container")
         return 0
     ref = ref_build.import_reference()
     os.makedirs(GOLDEN, exist_ok=True)
+    if "--next-only" in sys.argv:
+        next_tier_cases(ref)
+        return 0
     pbc_cases(ref)
     dotprod_cases(ref)
     pipeline_cases(ref)
+    next_tier_cases(ref)
     return 0
 
 

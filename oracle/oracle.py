@@ -371,3 +371,105 @@ def landmark_analysis(cell, ref_positions, static_mask, mobile_mask, centers, ve
     out["n_multiple_assignments"], out["avg_mobile_per_site"] = \
         check_multiple_occupancy(labels, K, max_mobile_per_site)             # :311
     return out
+
+
+# ---- the steps either side of the path --------------------------------------
+
+def jump_analysis(traj, n_sites):
+    """dynamics/JumpAnalysis.py:27-135 (numpy fancy-index semantics kept: duplicates count once)."""
+    traj = np.asarray(traj)
+    F, M = traj.shape
+    last = traj[0].copy()
+    tac = np.ones(M, dtype=np.int64)
+    total = np.zeros(n_sites, dtype=np.int64)
+    tsum = np.zeros((n_sites, n_sites))
+    tn = np.zeros((n_sites, n_sites), dtype=np.int64)
+    n_ij = np.zeros((n_sites, n_sites))
+    problems = 0
+    for i in range(F):
+        frame = traj[i].copy()
+        unassigned = frame == -1
+        frame[unassigned] = last[unassigned]
+        fknown = (frame >= 0) & (last >= 0)
+        problems += int(np.sum(~fknown))
+        total[frame[fknown]] += 1
+        jumped = (frame != last) & fknown
+        n_ij[last[fknown], frame[fknown]] += 1
+        tsum[last[jumped], frame[jumped]] += tac[jumped]
+        tn[last[jumped], frame[jumped]] += 1
+        tac[~jumped] += 1
+        tac[jumped] = 1
+        last[~unassigned] = frame[~unassigned]
+    lag = np.full((n_sites, n_sites), np.inf)
+    m = tn > 0
+    lag[m] = tsum[m] / tn[m]
+    res = np.empty(n_sites)
+    for s in range(n_sites):
+        fin = lag[s] < np.inf
+        res[s] = np.mean(lag[s][fin]) if np.any(fin) else F
+    with np.errstate(divide="ignore", invalid="ignore"):
+        p_ij = n_ij / total
+    return {"n_ij": n_ij, "p_ij": p_ij, "jump_lag": lag, "residence_times": res,
+            "occupancy_freqs": np.sum(n_ij, axis=0) / F, "total_corrected_residences": total, "n_problems": problems}
+
+
+def assign_to_last_known_site(traj, frame_threshold=1):
+    """SiteTrajectory.py:235-304.  Returns (new traj, [max_time_unknown, avg_time_unknown, total_reassigned])."""
+    traj = np.array(traj)
+    F, M = traj.shape
+    last = np.full(M, -1, dtype=np.int64)
+    tu = np.zeros(M, dtype=np.int64)
+    s = n = 0
+    mx = 0
+    re = 0
+    for i in range(F):
+        unknown = traj[i] == -1
+        last[~unknown] = traj[i][~unknown]
+        times = tu[~unknown]
+        times = times[times != 0]
+        if len(times) > 0:
+            if np.max(times) > frame_threshold:
+                mx = int(np.max(times))
+            s += int(np.sum(times))
+            n += len(times)
+        tu[~unknown] = 0
+        fix = unknown & (tu < frame_threshold)
+        traj[i][fix] = last[fix]
+        re += int(np.sum(fix))
+        tu[unknown] += 1
+    if n > 0:
+        return traj, [mx, float(s) / n, re]
+    return traj, [0, 0, 0]
+
+
+def running_windowed_mode(traj, wleft, wright, threshold, n_sites, replace_no_winner_unknown):
+    """dynamics/SmoothSiteTrajectory.pyx:79-111."""
+    traj = np.asarray(traj)
+    F, M = traj.shape
+    out = traj.copy()
+    for mob in range(M):
+        for f in range(F):
+            cnt = np.bincount(traj[max(f - wleft, 0):min(f + wright, F), mob] + 1, minlength=n_sites + 1)
+            win = int(np.argmax(cnt)) if cnt.size else 0
+            best = int(cnt[win]) if cnt.size else 0
+            if best == 0:
+                win = 0
+            out[f, mob] = win - 1 if best >= threshold else (-1 if replace_no_winner_unknown else traj[f, mob])
+    return out
+
+
+def recenter(arr, masses, factors, add=None):
+    """util/RecenterTrajectory.pyx:66-100 (+ :57-58 when `add` is the cell centroid); returns a new array."""
+    arr = np.array(arr, dtype=np.float64)
+    tmi = 0.0
+    for j in range(len(masses)):
+        tmi += factors[j] * masses[j]
+    tmi = 1.0 / tmi
+    for i in range(len(arr)):
+        com = np.zeros(3)
+        for j in range(arr.shape[1]):
+            com += tmi * factors[j] * masses[j] * arr[i, j]
+        arr[i] -= com
+    if add is not None:
+        arr += add
+    return arr

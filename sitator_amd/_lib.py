@@ -68,6 +68,10 @@ SIGNATURES = {
     "sit_check_occupancy": (C.c_int, [_vp, i64, i64, _ip, _ip, _ip, C.POINTER(SitError)]),
     "sit_set_assignments": (C.c_int, [_vp, _ip, _dp, i64, i64, i64]),
     "sit_jump_sources": (C.c_int, [_vp, C.c_int, _ip, _ip, _ip]),
+    "sit_jump_analysis": (C.c_int, [_vp, i64, _ip, _ip, _dp, _dp, _ip, _ip, _ip, _ip, _ip]),
+    "sit_assign_last_known": (C.c_int, [_vp, i64, _ip, _ip, _ip, _i32p, _ip, _ip, _ip]),
+    "sit_running_mode": (C.c_int, [_vp, i64, i64, i64, C.c_int, _ip]),
+    "sit_recenter": (C.c_int, [_vp, _dp, i64, i64, _dp, _dp, _dp]),
     "sit_timers": (C.c_int, [_vp, _dp, C.c_int]),
     "sit_info": (C.c_int, [_vp, _dp, C.c_int]),
     "sit_synchronize": (C.c_int, [_vp]),
@@ -355,6 +359,41 @@ class HipContext(object):
         self._check(self.lib.sit_jump_sources(self._h, int(unknown_as_jump), None if lin is None else _i(lin),
                                               _i(src), _i(last_out)))
         return src, last_out
+
+    def jump_analysis(self, K, last_known_in=None, time_at_current_in=None):
+        n_ij = np.empty((K, K)); tsum = np.empty((K, K)); tn = np.empty((K, K), dtype=np.int64)
+        total = np.empty(K, dtype=np.int64); nprob = i64(0)
+        lout = np.empty(self.M, dtype=np.int64); tout = np.empty(self.M, dtype=np.int64)
+        lin = None if last_known_in is None else _i64(last_known_in)
+        tin = None if time_at_current_in is None else _i64(time_at_current_in)
+        self._check(self.lib.sit_jump_analysis(self._h, int(K), None if lin is None else _i(lin),
+                                               None if tin is None else _i(tin), _d(n_ij), _d(tsum), _i(tn), _i(total),
+                                               C.byref(nprob), _i(lout), _i(tout)))
+        return n_ij, tsum, tn, total, nprob.value, lout, tout
+
+    def assign_last_known(self, frame_threshold, last_known_in=None, time_unknown_in=None):
+        labels = np.empty((self.F, self.M), dtype=np.int64)
+        fmax = np.zeros(max(self.F, 1), dtype=np.int32)
+        st = np.zeros(3, dtype=np.int64)
+        lout = np.empty(self.M, dtype=np.int64); tout = np.empty(self.M, dtype=np.int64)
+        lin = None if last_known_in is None else _i64(last_known_in)
+        tin = None if time_unknown_in is None else _i64(time_unknown_in)
+        self._check(self.lib.sit_assign_last_known(self._h, int(frame_threshold), None if lin is None else _i(lin),
+                                                   None if tin is None else _i(tin), _i(labels),
+                                                   fmax.ctypes.data_as(_i32p), _i(st), _i(lout), _i(tout)))
+        return labels, fmax[:self.F], st, lout, tout
+
+    def running_mode(self, wleft, wright, threshold, replace_unknown):
+        out = np.empty((self.F, self.M), dtype=np.int64)
+        self._check(self.lib.sit_running_mode(self._h, int(wleft), int(wright), int(threshold), int(replace_unknown), _i(out)))
+        return out
+
+    def recenter(self, arr, masses, factors, add3=None):
+        assert arr.dtype == np.float64 and arr.flags.c_contiguous and arr.ndim == 3 and arr.shape[2] == 3
+        masses = _f64(masses); factors = _f64(factors)
+        a3 = None if add3 is None else _f64(add3)
+        self._check(self.lib.sit_recenter(self._h, _d(arr), arr.shape[0], arr.shape[1], _d(masses), _d(factors),
+                                          None if a3 is None else _d(a3)))
 
     def timers(self):
         t = np.zeros(8)

@@ -1,0 +1,116 @@
+"""The analysis steps right after the landmark path, evaluated on the GPU over the
+device-resident site assignments:
+
+* ``JumpAnalysis``  (reference ``sitator/dynamics/JumpAnalysis.py:11-135``)
+* ``SmoothSiteTrajectory``  (reference ``sitator/dynamics/SmoothSiteTrajectory.pyx:13-111``)
+"""
+import logging
+
+import numpy as np
+
+from .site_trajectory import SiteTrajectory
+
+logger = logging.getLogger(__name__)
+
+
+class JumpAnalysis(object):
+    """Jump statistics of a ``SiteTrajectory``.
+
+    Adds to ``st.site_network`` the edge attributes ``n_ij`` (jumps i -> j), ``p_ij`` (probability of
+    jumping to j being at i), ``jump_lag`` (mean frames spent at i before jumping to j, ``inf`` if never)
+    and the site attributes ``residence_times``, ``occupancy_freqs``, ``total_corrected_residences``.
+    """
+
+    def __init__(self):
+        pass
+
+    def run(self, st):
+        assert isinstance(st, SiteTrajectory)
+        logger.info("Running JumpAnalysis...")
+        sn = st.site_network
+        n_sites = sn.n_sites
+        ctx = st._device()
+        comm = st._comm
+        n_frames = st.n_frames
+        if comm is not None and comm.size > 1:
+            # the per-ion state (last known site, time at it) flows from frame shard to frame shard
+            last_in = tac_in = None
+            parts = None
+            for r in range(comm.size):
+                if comm.rank == r:
+                    parts = ctx.jump_analysis(n_sites, last_in, tac_in)
+                    halo = np.stack([parts[5], parts[6]])
+                else:
+                    halo = np.zeros((2, sn.n_mobile), dtype=np.int64)
+                halo = comm.bcast(halo, root=r)
+                if comm.rank == r + 1:
+                    last_in, tac_in = halo[0], halo[1]
+            n_ij = comm.allreduce_sum(parts[0])
+            tsum = comm.allreduce_sum(parts[1])
+            tn = comm.allreduce_sum(parts[2])
+            total_time = comm.allreduce_sum(parts[3])
+            n_problems = int(comm.allreduce_sum(np.array([parts[4]], dtype=np.int64))[0])
+            n_frames = int(comm.allreduce_sum(np.array([n_frames], dtype=np.int64))[0])
+        else:
+            n_ij, tsum, tn, total_time, n_problems, _, _ = ctx.jump_analysis(n_sites)
+        # the time before "jumping" to oneself is never recorded (JumpAnalysis.py:99)
+        assert not np.any(np.nonzero(tsum.diagonal()))
+        if n_problems != 0:
+            logger.warning("Came across %i times where assignment and last known assignment were unassigned." % n_problems)
+        jump_lag = np.full((n_sites, n_sites), np.inf)
+        seen = tn > 0
+        jump_lag[seen] = tsum[seen] / tn[seen]
+        for name in ("n_ij", "p_ij", "jump_lag", "residence_times", "occupancy_freqs", "total_corrected_residences"):
+            if sn.has_attribute(name):
+                sn.remove_attribute(name)
+        sn.add_edge_attribute("jump_lag", jump_lag)
+        sn.add_edge_attribute("n_ij", n_ij)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sn.add_edge_attribute("p_ij", n_ij / total_time)
+        res_times = np.empty(n_sites)
+        for site in range(n_sites):
+            finite = jump_lag[site] < np.inf
+            res_times[site] = np.mean(jump_lag[site][finite]) if np.any(finite) else n_frames
+        sn.add_site_attribute("residence_times", res_times)
+        sn.add_site_attribute("occupancy_freqs", np.sum(n_ij, axis=0) / n_frames)
+        sn.add_site_attribute("total_corrected_residences", total_time)
+        return st
+
+
+class SmoothSiteTrajectory(object):
+    """Rolling-mode low-pass filter of every particle's site assignment.
+
+    Args as the reference: ``window_threshold_factor`` (window width in units of the threshold),
+    ``remove_unoccupied_sites``, ``set_unassigned_under_threshold``.
+    """
+
+    def __init__(self, window_threshold_factor=2.1, remove_unoccupied_sites=True, set_unassigned_under_threshold=True):
+        self.window_threshold_factor = window_threshold_factor
+        self.remove_unoccupied_sites = remove_unoccupied_sites
+        self.set_unassigned_under_threshold = set_unassigned_under_threshold
+
+    def run(self, st, threshold):
+        window = self.window_threshold_factor * threshold
+        wleft, wright = int(np.floor(window / 2)), int(np.ceil(window / 2))
+        out = st._device().running_mode(wleft, wright, threshold, self.set_unassigned_under_threshold)
+        new = st.copy()
+        new._traj = out
+        new._invalidate_device()
+        if self.remove_unoccupied_sites:
+            # sites left without any assignment are dropped and the rest renumbered in order
+            # (what the reference delegates to dynamics.RemoveUnoccupiedSites)
+            sn = new.site_network
+            seen = np.zeros(sn.n_sites, dtype=bool)
+            seen[np.unique(out[out >= 0])] = True
+            if not np.all(seen):
+                trans = np.full(sn.n_sites + 1, -1, dtype=np.int64)
+                trans[:-1][seen] = np.arange(int(np.sum(seen)))
+                new._traj = trans[out]
+                verts = sn.vertices
+                newsn = sn.copy()
+                newsn.centers = np.asarray(sn.centers)[seen]
+                if verts is not None:
+                    newsn.vertices = [v for v, keep in zip(verts, seen) if keep]
+                new._sn = newsn
+        new.site_network.clear_attributes()
+        return new

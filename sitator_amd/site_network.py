@@ -3,6 +3,8 @@
 structure/masks/counts, ``static_structure``, ``centers``, ``vertices``, ``copy()``.
 Site/edge attribute storage and plotting are out of scope.
 """
+import re
+
 import numpy as np
 
 
@@ -56,6 +58,63 @@ class SiteNetwork(object):
         assert len(self.static_structure) == self.n_static
         self._centers = None
         self._vertices = None
+        self._site_attrs = {}
+        self._edge_attrs = {}
+
+    # -- site / edge attributes (reference SiteNetwork.py:262-306, :330-391): per-site arrays and
+    #    (n_sites, n_sites) per-edge matrices that analysis steps attach, readable as `sn.<name>`
+    ATTR_NAME_REGEX = re.compile("^[a-zA-Z][a-zA-Z0-9_]*$")
+
+    @property
+    def site_attributes(self):
+        return list(self._site_attrs.keys())
+
+    @property
+    def edge_attributes(self):
+        return list(self._edge_attrs.keys())
+
+    def has_attribute(self, attr):
+        return (attr in self._site_attrs) or (attr in self._edge_attrs)
+
+    def remove_attribute(self, attr):
+        if attr in self._site_attrs:
+            del self._site_attrs[attr]
+        elif attr in self._edge_attrs:
+            del self._edge_attrs[attr]
+        else:
+            raise AttributeError("This SiteNetwork has no site or edge attribute `%s`" % attr)
+
+    def clear_attributes(self):
+        self._site_attrs = {}
+        self._edge_attrs = {}
+
+    def _check_name(self, name):
+        if not self.ATTR_NAME_REGEX.match(name):
+            raise ValueError("Attribute name `%s` invalid; must begin with a letter and contain only letters, numbers, and underscores." % name)
+        if name in self.__dict__ or hasattr(type(self), name) or self.has_attribute(name):
+            raise KeyError("Attribute with name `%s` already exists" % name)
+
+    def add_site_attribute(self, name, attr, computed=True):
+        self._check_name(name)
+        attr = np.asarray(attr)
+        if attr.shape[0] != self.n_sites:
+            raise ValueError("Attribute array has only %i entries; need one for all %i sites." % (len(attr), self.n_sites))
+        self._site_attrs[name] = attr
+
+    def add_edge_attribute(self, name, attr, computed=True):
+        self._check_name(name)
+        attr = np.asarray(attr)
+        if attr.shape != (self.n_sites, self.n_sites):
+            raise ValueError("Attribute matrix has shape %s; need first two dimensions to be %s" % (attr.shape, (self.n_sites, self.n_sites)))
+        self._edge_attrs[name] = attr
+
+    def __getattr__(self, attrkey):
+        v = self.__dict__
+        if "_site_attrs" in v and attrkey in v["_site_attrs"]:
+            return v["_site_attrs"][attrkey]
+        if "_edge_attrs" in v and attrkey in v["_edge_attrs"]:
+            return v["_edge_attrs"][attrkey]
+        raise AttributeError("This SiteNetwork has no site or edge attribute `%s`" % attrkey)
 
     def __len__(self):
         return self.n_sites
@@ -80,6 +139,8 @@ class SiteNetwork(object):
         if value.ndim != 2 or value.shape[1] != 3:
             raise ValueError("`centers` must be a list of points")
         self._vertices = None          # new centres invalidate everything derived from the old
+        self._site_attrs = {}
+        self._edge_attrs = {}
         self._centers = value
 
     @property
@@ -106,4 +167,8 @@ class SiteNetwork(object):
             new.centers = self._centers.copy()
         if self._vertices is not None:
             new.vertices = [list(v) for v in self._vertices]
+        for k, v in self._site_attrs.items():
+            new.add_site_attribute(k, v.copy())
+        for k, v in self._edge_attrs.items():
+            new.add_edge_attribute(k, v.copy())
         return new

@@ -165,6 +165,48 @@ class SiteTrajectory(object):
             ctx._check(rc)
         return n_multi, total / nsites
 
+    def assign_to_last_known_site(self, frame_threshold=1):
+        """Assign unassigned mobile particles to their last known site if that was at most
+        ``frame_threshold`` frames ago (reference :235-304).  Modifies this trajectory; returns the
+        reference's diagnostic dict."""
+        import logging
+        logger = logging.getLogger(__name__)
+        total_unknown = self.n_unassigned
+        logger.info("%i unassigned positions (%i%%); assigning unassigned mobile particles to last known positions within %s frames..."
+                    % (total_unknown, 100.0 * self.percent_unassigned, frame_threshold))
+        ctx = self._device()
+        comm = self._comm
+        if comm is not None and comm.size > 1:
+            lin = tin = None
+            res = None
+            for r in range(comm.size):
+                if comm.rank == r:
+                    res = ctx.assign_last_known(frame_threshold, lin, tin)
+                    halo = np.stack([res[3], res[4]])
+                else:
+                    halo = np.zeros((2, self._sn.n_mobile), dtype=np.int64)
+                halo = comm.bcast(halo, root=r)
+                if comm.rank == r + 1:
+                    lin, tin = halo[0], halo[1]
+            labels, fmax, st3 = res[0], res[1], comm.allreduce_sum(res[2])
+            over = np.nonzero(fmax > frame_threshold)[0]
+            pair = np.array([ctx.frame0 + over[-1], fmax[over[-1]]] if len(over) else [-1, 0], dtype=np.int64)
+            pairs = comm.allgather(pair)
+            best = pairs[int(np.argmax(pairs[:, 0]))]
+            max_time_unknown = int(best[1]) if best[0] >= 0 else 0
+        else:
+            labels, fmax, st3, _, _ = ctx.assign_last_known(frame_threshold)
+            over = np.nonzero(fmax > frame_threshold)[0]
+            max_time_unknown = int(fmax[over[-1]]) if len(over) else 0      # the reference keeps the LAST such frame's maximum
+        self._traj[...] = labels
+        if st3[1] > 0:
+            avg = float(st3[0]) / float(st3[1])
+            logger.info("  Maximum # of frames any mobile particle spent unassigned: %i" % max_time_unknown)
+            logger.info("  Avg. # of frames spent unassigned: %f" % avg)
+            return {"max_time_unknown": max_time_unknown, "avg_time_unknown": avg, "total_reassigned": int(st3[2])}
+        logger.info("  None to correct.")
+        return {"max_time_unknown": 0, "avg_time_unknown": 0, "total_reassigned": 0}
+
     def _jump_arrays(self, unknown_as_jump=False):
         """(frames, atoms, from_sites, to_sites) of every jump, frame-major, from the device scan."""
         ctx = self._device()

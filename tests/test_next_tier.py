@@ -1,0 +1,102 @@
+"""The steps either side of the path: JumpAnalysis, assign_to_last_known_site,
+running windowed mode (SmoothSiteTrajectory), RecenterTrajectory -- oracle vs the TRUE reference's
+golden outputs on CPU, and the HIP implementations vs the same goldens on the GPU."""
+import numpy as np
+import pytest
+
+from tests import golden_util as G
+
+Z = None
+
+
+def z():
+    global Z
+    if Z is None:
+        Z = G.load("next_tier_known_answers")
+    return Z
+
+
+NAMES = ["toy", "c1_hex_scgrid", "c1b_tri_bcctet", "bcc_ortho", "noisy"]
+JA = ("n_ij", "p_ij", "jump_lag", "residence_times", "occupancy_freqs", "total_corrected_residences")
+MODES = ((3, 2.1, True), (5, 2.1, False), (2, 3.0, True))
+
+
+def _eq(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return a.shape == b.shape and np.array_equal(np.nan_to_num(a, nan=-7.0, posinf=1e300), np.nan_to_num(b, nan=-7.0, posinf=1e300))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_next_tier_matches_reference(oracle, name):
+    lab, K = z()[name + "/labels"], int(z()[name + "/n_sites"])
+    ja = oracle.jump_analysis(lab, K)
+    for a in JA:
+        assert _eq(ja[a], z()[name + "/ja_" + a]), a
+    for thr in (1, 3):
+        t, st = oracle.assign_to_last_known_site(lab, thr)
+        assert np.array_equal(t, z()[name + "/alk%d_traj" % thr])
+        np.testing.assert_allclose(st, z()[name + "/alk%d_stats" % thr], rtol=1e-15)
+    for thr, factor, repl in MODES:
+        w = factor * thr
+        out = oracle.running_windowed_mode(lab, int(np.floor(w / 2)), int(np.ceil(w / 2)), thr, K, repl)
+        assert np.array_equal(out, z()[name + "/mode_%d_%g_%d" % (thr, factor, int(repl))])
+
+
+def test_oracle_recenter_matches_reference(oracle):
+    sm = z()["rc/static_mask"]
+    f = sm.astype(np.float64)
+    cen = np.sum(0.5 * z()["rc/cell"], axis=0)
+    ones = np.ones(len(sm))
+    np.testing.assert_allclose(oracle.recenter(z()["rc/frames"], ones, f, cen), z()["rc/out_default"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(oracle.recenter(z()["rc/velocities"], ones, f), z()["rc/out_velocities"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(oracle.recenter(z()["rc/frames"], z()["rc/masses"], f, cen), z()["rc/out_masses"], rtol=0, atol=1e-12)
+
+
+def _st(lab, K):
+    from sitator_amd import SiteNetwork, SiteTrajectory, Structure
+    M = lab.shape[1]
+    sm = np.array([True] + [False] * M)
+    sn = SiteNetwork(Structure(np.zeros((M + 1, 3)), np.eye(3) * 10), sm, ~sm)
+    sn.centers = np.zeros((K, 3))
+    return SiteTrajectory(sn, lab)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_next_tier_matches_reference(name):
+    from sitator_amd import JumpAnalysis, SmoothSiteTrajectory
+    lab, K = z()[name + "/labels"], int(z()[name + "/n_sites"])
+    st = JumpAnalysis().run(_st(lab, K))
+    for a in JA:
+        assert _eq(getattr(st.site_network, a), z()[name + "/ja_" + a]), a
+    for thr in (1, 3):
+        s2 = _st(lab, K)
+        res = s2.assign_to_last_known_site(frame_threshold=thr)
+        assert np.array_equal(s2.traj, z()[name + "/alk%d_traj" % thr])
+        exp = z()[name + "/alk%d_stats" % thr]
+        assert res["max_time_unknown"] == int(exp[0]) and res["total_reassigned"] == int(exp[2])
+        assert res["avg_time_unknown"] == pytest.approx(float(exp[1]), rel=1e-15, abs=0)
+    for thr, factor, repl in MODES:
+        sm = SmoothSiteTrajectory(window_threshold_factor=factor, remove_unoccupied_sites=False,
+                                  set_unassigned_under_threshold=repl)
+        out = sm.run(_st(lab, K), thr)
+        assert np.array_equal(out.traj, z()[name + "/mode_%d_%g_%d" % (thr, factor, int(repl))])
+
+
+@pytest.mark.gpu
+def test_gpu_recenter_matches_reference():
+    from sitator_amd import RecenterTrajectory, Structure
+
+    class Atoms(Structure):
+        def get_masses(self):
+            return np.ones(len(self))
+
+    sm = z()["rc/static_mask"]
+    at = Atoms(np.zeros((len(sm), 3)), z()["rc/cell"])
+    p, v = z()["rc/frames"].copy(), z()["rc/velocities"].copy()
+    RecenterTrajectory().run(at, sm, p, velocities=v)
+    np.testing.assert_allclose(p, z()["rc/out_default"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(v, z()["rc/out_velocities"], rtol=0, atol=1e-10)
+    p2 = z()["rc/frames"].copy()
+    RecenterTrajectory().run(at, sm, p2, masses=z()["rc/masses"])
+    np.testing.assert_allclose(p2, z()["rc/out_masses"], rtol=0, atol=1e-10)
