@@ -18,7 +18,7 @@
 // Rows that found clusters, rows whose join grows a centre's support (later rows' overlap lists would be
 // stale) and rows exceeding a capacity are applied one at a time by k_ff_serial with the same arithmetic.
 // Centres are kept sparse (sorted support, <= FF_CS entries); dot products sum in ascending dimension
-// order, norms sum in ascending order: identical to the dense left-to-right sums of the oracle.
+// order, norms sum in ascending order: identical to dense left-to-right sums (zeros add nothing).
 #include <cmath>
 #include <cstring>
 
