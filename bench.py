@@ -9,7 +9,8 @@ rank r holds frames [r*F, (r+1)*F) of an N*F-frame trajectory).  One "step" = on
 path over the resident trajectory: wrap + static-lattice check + landmark vector of every
 (frame, mobile ion) + cosine assignment to the fitted site centres -> int64 label + float64
 confidence per (frame, ion).  Frames are resident in HBM before the timed region; the site
-centres come from the product's own fit on a leading cut (outside the timed region).
+centres come from the product's own end-to-end `run()` on the same trajectory (outside the timed
+region; its wall time is reported as `end_to_end_run`).
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_fill_rows) with the
 algorithmic bytes of SURVEY.md section 8(d): B = 24*A/M + 16 bytes per landmark vector.
@@ -36,9 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=100000, help="frames per GPU")
     ap.add_argument("--config", default="C2")
-    ap.add_argument("--fit-frames", type=int, default=3000)
-    ap.add_argument("--cpu-frames", type=int, default=600, help="frames of the CPU-baseline cut (0 = skip)")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run() timing on a cut")
+    ap.add_argument("--cpu-frames", type=int, default=2000, help="frames of the CPU-baseline cut (0 = skip)")
     ap.add_argument("--compare-v1", action="store_true",
                     help="also time the first-generation kernels (fill + predict), interleaved in this process")
     return ap.parse_args()
@@ -72,16 +71,18 @@ def main():
     sn.centers = host.centers
     sn.vertices = host.vertices
 
-    # --- site centres: the product's own fit on a leading cut (outside the timed region) ---
-    # (a strided sample of the whole trajectory, so that the centres cover every visited site)
-    cut = min(F, args.fit_frames)
-    fit_sample = np.ascontiguousarray(frames[::max(1, F // cut)][:cut])
+    # --- end-to-end: the product's own LandmarkAnalysis.run() on this rank's whole trajectory (upload,
+    #     tables, fill, exact fit_centers, two predict passes, site centres, occupancy check).  It is
+    #     reported beside the headline and supplies the fitted site centres for the timed pass. ---
     t0 = time.time()
     la = LandmarkAnalysis(verbose=False, device=local)
-    st_cut = la.run(sn, fit_sample)
-    t_e2e_cut = time.time() - t0
-    e2e = {"frames": cut, "seconds": round(t_e2e_cut, 4), "lvec_per_s": round(cut * M / t_e2e_cut, 1),
-           "stage_ms": {k: round(v, 3) for k, v in la.timings.items()}, "sites": int(st_cut.site_network.n_sites)}
+    st_full = la.run(sn, frames)
+    t_e2e = time.time() - t0
+    e2e = {"frames": F, "seconds": round(t_e2e, 4), "lvec_per_s": round(F * M / t_e2e, 1),
+           "wall_s": {k: round(v, 4) for k, v in la.wall_timings.items()},
+           "sites": int(st_full.site_network.n_sites), "unassigned_frac": float(st_full.percent_unassigned),
+           "fit": {k: v for k, v in la._ctx.info().items() if k.startswith("fit_")}}
+    e2e_labels = st_full.traj.reshape(-1)
 
     # --- resident context for the timed pass ---
     ctx = _lib.HipContext(host.cell, device=local)
@@ -102,7 +103,7 @@ def main():
     ctx.set_centers(normed, True)
 
     def step():
-        rc, nz, err = ctx.fill(False, False, True, assign=True, predict_threshold=0.8, store_rows=False)
+        rc, nz, err = ctx.fill(False, False, True, assign=True, predict_threshold=0.8)
         if rc != 0:
             raise RuntimeError("fill failed rc=%d frame=%d index=%d: %s" % (rc, err.frame, err.index, ctx.message()))
 
@@ -145,16 +146,17 @@ def main():
             tm = ctx1.timers()
             t_v1.append(tm["fill"] + tm["predict"])
             step()
-            t_v2.append(ctx.timers()["fill"])
+            t_v2.append(ctx.timers()["fill"] + ctx.timers()["predict"])
         l1, c1, n1 = ctx1.assignments()
         l2, c2, n2 = ctx.assignments()
         ab = {"v1_fill_plus_predict_ms": {"median": float(np.median(t_v1)), "min": float(np.min(t_v1))},
-              "v2_fused_ms": {"median": float(np.median(t_v2)), "min": float(np.min(t_v2))},
+              "v2_fill_plus_predict_ms": {"median": float(np.median(t_v2)), "min": float(np.min(t_v2))},
               "labels_identical": bool(np.array_equal(l1, l2)), "confs_identical": bool(np.array_equal(c1, c2))}
         ctx1.close()
 
     labels, confs, counts = ctx.assignments()
     checks = {"unassigned_frac": float(np.mean(labels < 0)), "sites": int(len(counts)),
+              "labels_equal_end_to_end_run": bool(np.array_equal(labels, e2e_labels)),
               "label_checksum": int(np.sum(labels[labels >= 0] * 7 + 1) % 1000003)}
 
     if rank == 0:
@@ -185,7 +187,7 @@ def main():
                          "algorithmic_bytes_per_lvec": bytes_per_lvec},
             "stages_ms": {"fill": fill_avg_ms, "predict": float(np.mean(pred_ms)), "h2d_frames": h2d_ms,
                           "generate_s": round(t_gen, 2)},
-            "end_to_end_cut": e2e,
+            "end_to_end_run": e2e,
             "checks": checks,
         }
         if ab is not None:

@@ -74,6 +74,35 @@ __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a)
     for (int e = 0; e < n; e++) { const double v = a.row_val[(i64)e * a.N + row]; x2 += v * v; }
     const double xn = sqrt(x2);
     Best b = best_empty();
+    if (n <= 4) {
+        // up to four entries: a 4-way merge of the (centre-sorted) CSC columns of the row's dimensions.  Each
+        // step takes the smallest pending centre id and sums its terms in ascending dimension order.
+        i32 q0 = 0, q1 = 0, q2 = 0, q3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        { const i32 d = a.row_idx[row]; q0 = a.col_ptr[d]; e0 = a.col_ptr[d + 1]; v0 = a.row_val[row]; }
+        if (n > 1) { const i32 d = a.row_idx[a.N + row]; q1 = a.col_ptr[d]; e1 = a.col_ptr[d + 1]; v1 = a.row_val[a.N + row]; }
+        if (n > 2) { const i32 d = a.row_idx[2 * a.N + row]; q2 = a.col_ptr[d]; e2 = a.col_ptr[d + 1]; v2 = a.row_val[2 * a.N + row]; }
+        if (n > 3) { const i32 d = a.row_idx[3 * a.N + row]; q3 = a.col_ptr[d]; e3 = a.col_ptr[d + 1]; v3 = a.row_val[3 * a.N + row]; }
+        const i32 none = 0x7fffffff;
+        i32 h0 = q0 < e0 ? a.col_k[q0] : none, h1 = q1 < e1 ? a.col_k[q1] : none;
+        i32 h2 = q2 < e2 ? a.col_k[q2] : none, h3 = q3 < e3 ? a.col_k[q3] : none;
+        while (true) {
+            i32 cid = h0 < h1 ? h0 : h1;
+            const i32 m23 = h2 < h3 ? h2 : h3;
+            cid = cid < m23 ? cid : m23;
+            if (cid == none) break;
+            double dot = 0.0;
+            bool first = true;
+            if (h0 == cid) { const double t = a.col_val[q0] * v0; dot = t; first = false; q0++; h0 = q0 < e0 ? a.col_k[q0] : none; }
+            if (h1 == cid) { const double t = a.col_val[q1] * v1; dot = first ? t : dot + t; first = false; q1++; h1 = q1 < e1 ? a.col_k[q1] : none; }
+            if (h2 == cid) { const double t = a.col_val[q2] * v2; dot = first ? t : dot + t; first = false; q2++; h2 = q2 < e2 ? a.col_k[q2] : none; }
+            if (h3 == cid) { const double t = a.col_val[q3] * v3; dot = first ? t : dot + t; first = false; q3++; h3 = q3 < e3 ? a.col_k[q3] : none; }
+            if (a.normed) dot /= xn;                                   // :177-178
+            b = best_merge(b, best_of(fabs(dot), cid));                // :179
+        }
+        finish_predict(a, row, b);
+        return;
+    }
     for (int e = 0; e < n; e++) {
         const i32 d = a.row_idx[(i64)e * a.N + row];
         const double v = a.row_val[(i64)e * a.N + row];
