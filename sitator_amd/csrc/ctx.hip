@@ -197,20 +197,28 @@ extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const 
     c->midpoint = midpoint; c->steepness = steepness; c->static_thr = static_thr;
     // landmark/helpers.pyx:127-131 with threshold 0.0001 (:42-44)
     c->rz = midpoint + log((1 / 0.0001) - 1.) / steepness;
-    std::vector<i32> v32((size_t)(D * V));
-    for (i64 k = 0; k < D * V; k++) v32[(size_t)k] = (i32)verts[k];
+    // device tables are padded to a multiple of 4 vertices per landmark (16-byte rows: the fill kernels fetch a
+    // landmark's vertex ids and bounds with a few wide loads); the host copies keep the caller's width
+    const i64 Vp = (V + 3) / 4 * 4;
+    c->Vp = Vp;
+    std::vector<i32> v32((size_t)(D * Vp), -1);
+    std::vector<double> vcdp((size_t)(D * Vp), 1.0), hi2((size_t)(D * Vp), 0.0);
+    for (i64 k = 0; k < D; k++)
+        for (i64 h = 0; h < V; h++) {
+            v32[(size_t)(k * Vp + h)] = (i32)verts[k * V + h];
+            const double d = vcd[k * V + h];
+            if (verts[k * V + h] >= 0) {
+                vcdp[(size_t)(k * Vp + h)] = d;
+                // d^2 > hi2  =>  fl(fl(sqrt(d^2)) / vcd) > rz  (three roundings of 2^-53 each << 1e-14)
+                const double r = c->rz * d;
+                hi2[(size_t)(k * Vp + h)] = r * r * (1.0 + 1e-14);
+            }
+        }
     int rc;
     if ((rc = dev_upload(c, &c->d_ref_static, ref_static, S * 3))) return rc;
-    if ((rc = dev_upload(c, &c->d_verts, v32.data(), D * V))) return rc;
-    if ((rc = dev_upload(c, &c->d_vcd, vcd, D * V))) return rc;
-    {   // d^2 > hi2  =>  fl(fl(sqrt(d^2)) / vcd) > rz  (three roundings of 2^-53 each << 1e-14)
-        std::vector<double> hi2((size_t)(D * V));
-        for (i64 k = 0; k < D * V; k++) {
-            const double r = c->rz * vcd[k];
-            hi2[(size_t)k] = (vcd[k] == vcd[k]) ? r * r * (1.0 + 1e-14) : 0.0;
-        }
-        if ((rc = dev_upload(c, &c->d_hi2, hi2.data(), D * V))) return rc;
-    }
+    if ((rc = dev_upload(c, &c->d_verts, v32.data(), D * Vp))) return rc;
+    if ((rc = dev_upload(c, &c->d_vcd, vcdp.data(), D * Vp))) return rc;
+    if ((rc = dev_upload(c, &c->d_hi2, hi2.data(), D * Vp))) return rc;
     CandidateTable tab;
     if ((rc = sit_build_candidates(c, ref_static, verts, vcd, static_thr, 1.0, tab))) return rc;
     if ((rc = dev_upload(c, &c->d_bin_off, tab.off.data(), (i64)tab.off.size()))) return rc;

@@ -227,7 +227,7 @@ static int launch_fill_v1(sit_ctx *c, const sit_fill_params *p)
     a.lattice_map = p->dynamic_lattice_mapping ? c->d_lattice_map : nullptr;
     a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx; a.row_val = c->d_row_val;
     a.err = c->d_err; a.zero_count = c->d_scal;
-    a.F = c->F; a.A = c->A; a.S = S; a.M = M; a.D = c->D; a.V = c->V; a.N = c->N; a.W = c->rows_W; a.frame0 = c->frame0;
+    a.F = c->F; a.A = c->A; a.S = S; a.M = M; a.D = c->D; a.V = c->Vp; a.N = c->N; a.W = c->rows_W; a.frame0 = c->frame0;
     a.G0 = c->G[0]; a.G1 = c->G[1]; a.G2 = c->G[2];
     a.check_zeros = p->check_for_zeros;
     a.midpoint = c->midpoint; a.steepness = c->steepness; a.rz = c->rz; a.static_thr = c->static_thr;

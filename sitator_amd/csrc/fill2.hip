@@ -16,6 +16,7 @@
 //     reference accepts;
 //   * diagonal cells skip the exactly-zero terms of the 3x3 products (x*a + y*0 + z*0 == x*a).
 #include <cmath>
+#include <cstdlib>
 
 #include "sit_internal.h"
 
@@ -46,7 +47,7 @@ struct Fill2Args {
     int S, M, D, V, W;
     int tG0, tG1, tG2, lG0, lG1, lG2;
     int fpb;
-    int check_zeros, normed;
+    int check_zeros, normed, debug_stop;
     double midpoint, steepness, rz, delta2, thr2_lo, thr2_hi, static_thr, threshold;
 };
 
@@ -94,13 +95,37 @@ __device__ __forceinline__ double dist2_to(const Pbc &P, const double *fsx, cons
 
 // pow(acc, 1.0 / nv) of helpers.pyx:212 for acc in (0, 1]: square-root chains for nv = 1, 2, 4, 8
 // (each sqrt is correctly rounded; 1/nv is exact there), the library pow otherwise.
+// kept out of line: the library pow is register-hungry and rarely needed (vertex counts other than 1/2/4/8)
+__device__ __attribute__((noinline)) double pow_generic(double acc, int nv) { return pow(acc, 1.0 / nv); }
+
 __device__ __forceinline__ double nth_root(double acc, int nv)
 {
     if (nv == 8) return sqrt(sqrt(sqrt(acc)));
     if (nv == 4) return sqrt(sqrt(acc));
     if (nv == 2) return sqrt(acc);
     if (nv == 1) return acc;
-    return pow(acc, 1.0 / nv);
+    return pow_generic(acc, nv);
+}
+
+// A landmark's vertex ids and per-vertex constants are fetched with a few 16-byte loads issued together
+// (the device tables are padded to rows of 4 vertices), so a task pays ONE memory round trip for its table
+// rows instead of one per vertex.  Landmarks with more than 8 vertices take the generic loops.
+struct LmkRow {
+    i32 v[8];
+    double c[8];
+};
+
+__device__ __forceinline__ void load_row(LmkRow &r, const i32 *verts, const double *tab, int k, int V)
+{
+    const int4 *vp = (const int4 *)(verts + k * V);
+    const double2 *cp = (const double2 *)(tab + k * V);
+    const int4 a = vp[0];
+    const double2 c0 = cp[0], c1 = cp[1];
+    int4 b = make_int4(-1, -1, -1, -1);
+    double2 c2 = make_double2(1.0, 1.0), c3 = c2;
+    if (V > 4) { b = vp[1]; c2 = cp[2]; c3 = cp[3]; }
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.c[0] = c0.x; r.c[1] = c0.y; r.c[2] = c1.x; r.c[3] = c1.y; r.c[4] = c2.x; r.c[5] = c2.y; r.c[6] = c3.x; r.c[7] = c3.y;
 }
 
 // Stage 1: does any vertex lie provably beyond the cut-off?  Same distances as the reference, compared
@@ -109,19 +134,40 @@ template <int CELL>
 __device__ __forceinline__ bool screen_landmark(const Fill2Args &a, int k, const double *fsx, const double *fsy,
                                                 const double *fsz, const i32 *lmap, double ox, double oy, double oz)
 {
+    if (a.V <= 8) {
+        LmkRow r;
+        load_row(r, a.verts, a.hi2, k, a.V);
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            i32 v = r.v[h];
+            if (v < 0) break;
+            if (lmap) v = lmap[v];
+            if (dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz) > r.c[h]) return true;
+        }
+        return false;
+    }
     const i32 *vk = a.verts + k * a.V;
     const double *hk = a.hi2 + k * a.V;
-    i32 vn = vk[0];
-    double hn = hk[0];
     for (int h = 0; h < a.V; h++) {
-        i32 v = vn;
-        const double hb = hn;
+        i32 v = vk[h];
         if (v < 0) break;
-        if (h + 1 < a.V) { vn = vk[h + 1]; hn = hk[h + 1]; }
         if (lmap) v = lmap[v];
-        if (dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz) > hb) return true;
+        if (dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz) > hk[h]) return true;
     }
     return false;
+}
+
+// one vertex of landmark/helpers.pyx:186-205; returns false when the vertex is beyond the cut-off
+template <int CELL>
+__device__ __forceinline__ bool eval_vertex(const Fill2Args &a, i32 v, double dkh, const double *fsx, const double *fsy,
+                                            const double *fsz, double ox, double oy, double oz, double &acc)
+{
+    const double dist = sqrt(dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz));
+    double tt = dist / dkh;
+    if (tt > a.rz) return false;
+    tt = 1.0 / (1.0 + exp(a.steepness * (tt - a.midpoint)));
+    acc *= tt;
+    return true;
 }
 
 // Stage 2: one landmark component, landmark/helpers.pyx:186-212 (and :174-178 for the distances).
@@ -129,30 +175,35 @@ template <int CELL>
 __device__ __forceinline__ double eval_landmark(const Fill2Args &a, int k, const double *fsx, const double *fsy,
                                                 const double *fsz, const i32 *lmap, double ox, double oy, double oz)
 {
-    const i32 *vk = a.verts + k * a.V;
-    const double *dk = a.vcd + k * a.V;
     double acc = 1.0;
     int nv = 0;
-    i32 vn = vk[0];
-    double dn = dk[0];
+    if (a.V <= 8) {
+        LmkRow r;
+        load_row(r, a.verts, a.vcd, k, a.V);
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            i32 v = r.v[h];
+            if (v < 0) break;
+            nv++;
+            if (lmap) v = lmap[v];
+            if (!eval_vertex<CELL>(a, v, r.c[h], fsx, fsy, fsz, ox, oy, oz, acc)) return 0.0;
+        }
+        return nth_root(acc, nv);
+    }
+    const i32 *vk = a.verts + k * a.V;
+    const double *dk = a.vcd + k * a.V;
     for (int h = 0; h < a.V; h++) {
-        i32 v = vn;
-        const double dkh = dn;
+        i32 v = vk[h];
         if (v < 0) break;
-        if (h + 1 < a.V) { vn = vk[h + 1]; dn = dk[h + 1]; }
         nv++;
         if (lmap) v = lmap[v];
-        const double dist = sqrt(dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz));
-        double tt = dist / dkh;
-        if (tt > a.rz) return 0.0;
-        tt = 1.0 / (1.0 + exp(a.steepness * (tt - a.midpoint)));
-        acc *= tt;
+        if (!eval_vertex<CELL>(a, v, dk[h], fsx, fsy, fsz, ox, oy, oz, acc)) return 0.0;
     }
     return nth_root(acc, nv);
 }
 
 template <int CELL>
-__global__ __launch_bounds__(F2_THREADS) void k_fill2(Fill2Args a)
+__global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = a.S, M = a.M;
@@ -214,6 +265,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_fill2(Fill2Args a)
     }
     __syncthreads();
 
+    if (a.debug_stop == 1) return;
     // ---- phase 2: every wave on its own; no workgroup barrier from here on ----
     double *tval = tval_all + wave * F2_WTASK;
     i32 *tk = tk_all + wave * F2_WTASK;
@@ -264,6 +316,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_fill2(Fill2Args a)
             if (mine)
                 for (int c = 0; c < cnt; c++) { tk[at + c] = list[c]; tion[at + c] = (unsigned char)lane; }
             __builtin_amdgcn_wave_barrier();
+            if (a.debug_stop == 3) { ion_s = ion_e; nnz = 1; continue; }
             // 2e-1: screen every (ion, landmark) task; survivors are compacted by ballot
             int nsurv = 0;
             for (int t0 = 0; t0 < ntasks; t0 += 64) {
@@ -275,13 +328,14 @@ __global__ __launch_bounds__(F2_THREADS) void k_fill2(Fill2Args a)
                 if (t < ntasks) {
                     const i32 *lmap = dyn ? a.lattice_map + (f0 + tfl) * S : nullptr;
                     alive = !screen_landmark<CELL>(a, tk[t], sx + tfl * S, sy + tfl * S, sz + tfl * S, lmap, tox, toy, toz);
-                    if (!alive) tval[t] = 0.0;
+                    if (!alive || a.debug_stop == 4) tval[t] = 0.0;
                 }
                 const unsigned long long m = __ballot(alive);
                 if (alive) surv[nsurv + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)t;
                 nsurv += __popcll(m);
             }
             __builtin_amdgcn_wave_barrier();
+            if (a.debug_stop == 4) { ion_s = ion_e; nnz = 1; continue; }
             // 2e-2: full evaluation of the survivors, one lane each
             for (int q0 = 0; q0 < nsurv; q0 += 64) {
                 const int q = q0 + lane;
@@ -388,9 +442,10 @@ int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, 
     a.col_ptr = c->d_col_ptr; a.col_k = c->d_col_k; a.col_val = c->d_col_val;
     a.err = c->d_err; a.scal = c->d_scal;
     a.F = c->F; a.A = c->A; a.N = c->N; a.frame0 = c->frame0;
-    a.S = (int)S; a.M = (int)M; a.D = (int)c->D; a.V = (int)c->V; a.W = (int)c->rows_W;
+    a.S = (int)S; a.M = (int)M; a.D = (int)c->D; a.V = (int)c->Vp; a.W = (int)c->rows_W;
     a.tG0 = c->tG[0]; a.tG1 = c->tG[1]; a.tG2 = c->tG[2]; a.lG0 = c->G[0]; a.lG1 = c->G[1]; a.lG2 = c->G[2];
     a.check_zeros = p->check_for_zeros; a.normed = c->centers_normed;
+    { const char *ds = getenv("SITATOR_DEBUG_STOP"); a.debug_stop = ds ? atoi(ds) : 0; }
     a.midpoint = c->midpoint; a.steepness = c->steepness; a.rz = c->rz; a.static_thr = c->static_thr;
     a.delta2 = c->tight_delta >= 0 ? c->tight_delta * c->tight_delta : -1.0;
     a.thr2_lo = c->static_thr * c->static_thr * (1.0 - 1e-14);

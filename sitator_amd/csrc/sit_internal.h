@@ -35,7 +35,7 @@ struct sit_ctx {
     Pbc pbc;
 
     // basis (sit_set_basis)
-    i64 S = 0, D = 0, V = 0;
+    i64 S = 0, D = 0, V = 0, Vp = 0;  // Vp: V padded to a multiple of 4 (device tables)
     double midpoint = 1.5, steepness = 30, rz = 0, static_thr = 1.0;
     double *d_ref_static = nullptr;   // [S,3]
     i32 *d_verts = nullptr;           // [D,V], -1 padded
