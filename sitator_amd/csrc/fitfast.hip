@@ -25,8 +25,8 @@
 #include "sit_internal.h"
 
 #define FF_CS 64        // support entries per centre (= lanes of the walking wave)
-#define FF_DC 32        // centres listed per landmark dimension
-#define FF_OC 16        // overlapping centres recorded per row
+#define FF_DC 64        // centres listed per landmark dimension
+#define FF_OC 32        // overlapping centres recorded per row
 #define FF_BMAX 65536   // rows per batch
 #define FF_LOG 2048     // support-growth records per walk
 #define FF_NEW (-1)
