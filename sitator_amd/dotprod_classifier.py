@@ -143,11 +143,7 @@ class DotProdClassifier(object):
         X.ctx.set_centers(matrix, predict_normed)
         labels, confs, counts = X.ctx.predict(threshold, fetch=fetch)
         counts = X.comm.allreduce_sum(counts) if X.comm.size > 1 else counts
-        zeros = 0
-        if fetch:
-            # rows with no non-zero get -1 there; count them for the reference's warning
-            zeros = 0
-        return labels, confs, counts, zeros
+        return labels, confs, counts, 0
 
     def fit_predict(self, X, verbose=True, predict_threshold=None, predict_normed=True, return_info=False):
         """Fit (unless centres were set), assign, drop clusters under ``min_samples``, assign again

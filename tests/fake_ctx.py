@@ -88,10 +88,8 @@ class FakeContext(object):
             if e.kind == "ZeroLandmarkError":
                 return E_ZERO_LANDMARK, 0, _Err(E_ZERO_LANDMARK, e.frame + self.frame0, e.mobile_index)
             la = np.atleast_1d(e.lattice_atoms)
-            if len(la) == 1 and not hasattr(e, "_unassigned") and "seen" not in e.__dict__:
-                pass
             self._unseen = la
-            # the oracle raises kind StaticLatticeError for both variants; tell them apart by how fill() built it
+            # the oracle raises StaticLatticeError for both variants: a list = threshold, an array = unassigned
             if isinstance(e.lattice_atoms, list):
                 return E_STATIC_THRESHOLD, 0, _Err(E_STATIC_THRESHOLD, e.frame + self.frame0, int(la[0]))
             return E_STATIC_UNASSIGNED, 0, _Err(E_STATIC_UNASSIGNED, e.frame + self.frame0, -1)
