@@ -73,6 +73,11 @@ int sit_distances(sit_ctx *ctx, const double *pt1, const double *pts2, int64_t n
 /* PBCCalculator.average, util/PBCCalculator.pyx:106-139; weights may be NULL.        */
 int sit_average(sit_ctx *ctx, const double *pts, const double *weights, int64_t n, double *out3);
 
+/* LandmarkAnalysis.run Step 1 in one call (landmark/LandmarkAnalysis.py:194-202): out[k,h] =
+ * PBCCalculator.distances(centers[k], ref_static[verts[k,h]]), NaN where verts[k,h] == -1.          */
+int sit_site_vertex_distances(sit_ctx *ctx, const double *centers, const double *ref_static,
+                              const int64_t *verts, int64_t D, int64_t V, int64_t S, double *out);
+
 /* ---- landmark basis and trajectory -------------------------------------------------- */
 
 /* Result of LandmarkAnalysis.run Step 1 (landmark/LandmarkAnalysis.py:194-202):

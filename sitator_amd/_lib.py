@@ -42,6 +42,7 @@ SIGNATURES = {
     "sit_wrap_points": (C.c_int, [_vp, _dp, i64]),
     "sit_distances": (C.c_int, [_vp, _dp, _dp, i64, _dp]),
     "sit_average": (C.c_int, [_vp, _dp, _dp, i64, _dp]),
+    "sit_site_vertex_distances": (C.c_int, [_vp, _dp, _dp, _ip, i64, i64, i64, _dp]),
     "sit_set_basis": (C.c_int, [_vp, _dp, i64, _ip, _dp, i64, i64, C.c_double, C.c_double, C.c_double]),
     "sit_set_frames": (C.c_int, [_vp, _dp, i64, i64, _ip, i64, _ip, i64, i64]),
     "sit_set_frames_device": (C.c_int, [_vp, _vp, i64, i64, _ip, i64, _ip, i64, i64]),
@@ -187,6 +188,13 @@ class HipContext(object):
         w = None if weights is None else _f64(weights)
         out = np.empty(3)
         self._check(self.lib.sit_average(self._h, _d(pts), None if w is None else _d(w), len(pts), _d(out)))
+        return out
+
+    def site_vertex_distances(self, centers, ref_static, verts):
+        centers = _f64(centers); ref_static = _f64(ref_static); verts = _i64(verts)
+        out = np.empty(verts.shape)
+        self._check(self.lib.sit_site_vertex_distances(self._h, _d(centers), _d(ref_static), _i(verts), verts.shape[0],
+                                                       verts.shape[1], len(ref_static), _d(out)))
         return out
 
     # -- residency

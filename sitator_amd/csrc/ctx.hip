@@ -130,6 +130,36 @@ extern "C" int sit_distances(sit_ctx *c, const double *pt1, const double *pts2, 
     return SIT_OK;
 }
 
+__global__ void k_site_vertex_distances(Pbc P, const double *centers, const double *ref, const i64 *verts, i64 DV, i64 V, double *out)
+{
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= DV) return;
+    const i64 v = verts[i], k = i / V;
+    out[i] = v < 0 ? NAN : dist_sw(P, centers[3 * k], centers[3 * k + 1], centers[3 * k + 2], ref[3 * v], ref[3 * v + 1], ref[3 * v + 2]);
+}
+
+extern "C" int sit_site_vertex_distances(sit_ctx *c, const double *centers, const double *ref_static, const i64 *verts,
+                                         i64 D, i64 V, i64 S, double *out)
+{
+    if (!c || !centers || !ref_static || !verts || !out) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, D > 0 && V > 0 && S > 0, "sit_site_vertex_distances: bad shape");
+    for (i64 i = 0; i < D * V; i++) SIT_REQUIRE(c, verts[i] >= -1 && verts[i] < S, "vertex index out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 bytes = D * 24 + S * 24 + D * V * 16;
+    int rc = ensure_scratch(c, bytes);
+    if (rc) return rc;
+    double *dc = (double *)c->d_scratch, *dr = dc + 3 * D, *dout = dr + 3 * S;
+    i64 *dv = (i64 *)(dout + D * V);
+    HIP_TRY(c, hipMemcpyAsync(dc, centers, (size_t)D * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dr, ref_static, (size_t)S * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dv, verts, (size_t)(D * V) * 8, hipMemcpyHostToDevice, c->stream));
+    k_site_vertex_distances<<<dim3((unsigned)((D * V + 255) / 256)), dim3(256), 0, c->stream>>>(c->pbc, dc, dr, dv, D * V, V, dout);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)(D * V) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
 // util/PBCCalculator.pyx:106-139.  One block; a fixed-shape tree reduction keeps the result
 // independent of scheduling.  part[] = (sum w, sum w*x, sum w*y, sum w*z) of wrap(p + offset).
 __global__ __launch_bounds__(256) void k_average(Pbc P, const double *pts, const double *w, i64 n,

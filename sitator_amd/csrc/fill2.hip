@@ -38,17 +38,13 @@ struct Fill2Args {
     const double *frame_dmax;         // [F] (dynamic mapping only)
     i32 *row_nnz, *row_idx;
     double *row_val;                  // null when rows are not stored
-    i64 *labels;
-    double *confs;                    // null when not assigning
-    const i32 *col_ptr, *col_k;
-    const double *col_val;
     u64 *err, *scal;                  // scal[0] zero rows, [1] predict overflow, [2] fallback frames, [3] row overflow
     i64 F, A, N, frame0;
     int S, M, D, V, W;
     int tG0, tG1, tG2, lG0, lG1, lG2;
     int fpb;
-    int check_zeros, normed, debug_stop;
-    double midpoint, steepness, rz, delta2, thr2_lo, thr2_hi, static_thr, threshold;
+    int check_zeros, debug_stop;
+    double midpoint, steepness, rz, delta2, thr2_lo, thr2_hi, static_thr;
 };
 
 template <int CELL>
@@ -135,16 +131,28 @@ __device__ __forceinline__ bool screen_landmark(const Fill2Args &a, int k, const
                                                 const double *fsz, const i32 *lmap, double ox, double oy, double oz)
 {
     if (a.V <= 8) {
+        // branch-free over the (padded) row: the wave leaves only with its slowest lane anyway, and without
+        // divergent exits the unrolled body needs no exec-mask bookkeeping
         LmkRow r;
         load_row(r, a.verts, a.hi2, k, a.V);
+        bool beyond = false;
 #pragma unroll
-        for (int h = 0; h < 8; h++) {
-            i32 v = r.v[h];
-            if (v < 0) break;
+        for (int h = 0; h < 4; h++) {
+            const bool valid = r.v[h] >= 0;
+            i32 v = valid ? r.v[h] : 0;
             if (lmap) v = lmap[v];
-            if (dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz) > r.c[h]) return true;
+            beyond |= valid && dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz) > r.c[h];
         }
-        return false;
+        if (a.V > 4) {
+#pragma unroll
+            for (int h = 4; h < 8; h++) {
+                const bool valid = r.v[h] >= 0;
+                i32 v = valid ? r.v[h] : 0;
+                if (lmap) v = lmap[v];
+                beyond |= valid && dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz) > r.c[h];
+            }
+        }
+        return beyond;
     }
     const i32 *vk = a.verts + k * a.V;
     const double *hk = a.hi2 + k * a.V;
@@ -438,19 +446,17 @@ int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, 
     a.lattice_map = p->dynamic_lattice_mapping ? c->d_lattice_map : nullptr;
     a.frame_dmax = p->dynamic_lattice_mapping ? c->d_frame_dmax : nullptr;
     a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx; a.row_val = store ? c->d_row_val : nullptr;
-    a.labels = c->d_labels; a.confs = nullptr; (void)assign;
-    a.col_ptr = c->d_col_ptr; a.col_k = c->d_col_k; a.col_val = c->d_col_val;
+    (void)assign; (void)threshold;
     a.err = c->d_err; a.scal = c->d_scal;
     a.F = c->F; a.A = c->A; a.N = c->N; a.frame0 = c->frame0;
     a.S = (int)S; a.M = (int)M; a.D = (int)c->D; a.V = (int)c->Vp; a.W = (int)c->rows_W;
     a.tG0 = c->tG[0]; a.tG1 = c->tG[1]; a.tG2 = c->tG[2]; a.lG0 = c->G[0]; a.lG1 = c->G[1]; a.lG2 = c->G[2];
-    a.check_zeros = p->check_for_zeros; a.normed = c->centers_normed;
+    a.check_zeros = p->check_for_zeros;
     { const char *ds = getenv("SITATOR_DEBUG_STOP"); a.debug_stop = ds ? atoi(ds) : 0; }
     a.midpoint = c->midpoint; a.steepness = c->steepness; a.rz = c->rz; a.static_thr = c->static_thr;
     a.delta2 = c->tight_delta >= 0 ? c->tight_delta * c->tight_delta : -1.0;
     a.thr2_lo = c->static_thr * c->static_thr * (1.0 - 1e-14);
     a.thr2_hi = c->static_thr * c->static_thr * (1.0 + 1e-14);
-    a.threshold = threshold;
     // frames per workgroup: about IC ions, within the LDS budget
     i64 fpb = (4 * F2_IW) / M; if (fpb < 1) fpb = 1; if (fpb > 8) fpb = 8;
     while (fpb > 1 && fill2_lds_bytes(S, M, (int)fpb) > 64 * 1024) fpb--;

@@ -129,11 +129,9 @@ class LandmarkAnalysis(object):
         ref_static = np.asarray(sn.static_structure.get_positions(), dtype=np.float64)
         widest = max(len(v) for v in sn.vertices)
         verts_np = np.full((sn.n_sites, widest), -1, dtype=np.int64)
-        site_vert_dists = np.full(verts_np.shape, np.nan)
         for i, polyhedron in enumerate(sn.vertices):
-            polyhedron = np.asarray(polyhedron, dtype=np.int64)
-            verts_np[i, :len(polyhedron)] = polyhedron
-            site_vert_dists[i, :len(polyhedron)] = self._pbcc.distances(sn.centers[i], ref_static[polyhedron])
+            verts_np[i, :len(polyhedron)] = np.asarray(polyhedron, dtype=np.int64)
+        site_vert_dists = ctx.site_vertex_distances(np.asarray(sn.centers), ref_static, verts_np)
         ctx.set_basis(ref_static, verts_np, site_vert_dists, self._cutoff_midpoint, self._cutoff_steepness,
                       self.static_movement_threshold)
 

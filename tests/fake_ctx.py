@@ -56,6 +56,13 @@ class FakeContext(object):
     def average(self, pts, weights=None):
         return orc.average(self.cell, pts, weights)
 
+    def site_vertex_distances(self, centers, ref_static, verts):
+        out = np.full(np.shape(verts), np.nan)
+        for k, row in enumerate(np.asarray(verts)):
+            m = row >= 0
+            out[k, m] = orc.distances(self.cell, centers[k], np.asarray(ref_static)[row[m]])
+        return out
+
     # -- residency
     def set_basis(self, ref_static, verts, vert_dists, midpoint, steepness, static_threshold):
         self.ref_static = np.asarray(ref_static, dtype=np.float64)
