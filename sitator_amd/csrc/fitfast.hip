@@ -141,6 +141,19 @@ __global__ __launch_bounds__(256) void k_ff_speculate(FFState s, FFRows r, FFBat
     if (dec < 0) atomicMin(b.first_new, j);
 }
 
+// wave-uniform broadcasts from a lane known to be uniform (v_readlane instead of an LDS permute)
+__device__ __forceinline__ int bc_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ double bc_d(double v, int src)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+__device__ __forceinline__ i64 bc_l(i64 v, int src)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffll), src);
+    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
+    return ((i64)hi << 32) | lo;
+}
+
 struct Pre {
     int m, omax, n, dec;
     i32 o0, o1, o2, o3;
@@ -189,7 +202,7 @@ __global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, 
     ff_load_pre(cur, r, b, row0, lane, nb);
     for (int j0 = 0; j0 < nb; j0 += 64) {
         // rows at or after the first known invalid row are void anyway (first_bad only ever decreases)
-        if (j0 > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        if ((j0 & 511) == 0 && j0 > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         ff_load_pre(nxt, r, b, row0, j0 + 64 + lane, nb);
         const int j = j0 + lane;
         int slot = -1;
@@ -206,17 +219,17 @@ __global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, 
         cur = nxt;
         unsigned long long todo = __ballot(slot >= 0);
         while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
             todo &= todo - 1;
             const int jj = j0 + src;
-            const int sl = __shfl(slot, src);
+            const int sl = bc_i(slot, src);
             const i64 row = row0 + jj;
-            const int n = __shfl(pn, src);
-            const int rdec = __shfl(pdec, src);
-            const double rxn = __shfl(pxn, src);
-            const i64 w = __shfl(pw, src);
-            const i32 qi0 = __shfl(pi0, src), qi1 = __shfl(pi1, src), qi2 = __shfl(pi2, src), qi3 = __shfl(pi3, src);
-            const double qv0 = __shfl(pv0, src), qv1 = __shfl(pv1, src), qv2 = __shfl(pv2, src), qv3 = __shfl(pv3, src);
+            const int n = bc_i(pn, src);
+            const int rdec = bc_i(pdec, src);
+            const double rxn = bc_d(pxn, src);
+            const i64 w = bc_l(pw, src);
+            const i32 qi0 = bc_i(pi0, src), qi1 = bc_i(pi1, src), qi2 = bc_i(pi2, src), qi3 = bc_i(pi3, src);
+            const double qv0 = bc_d(pv0, src), qv1 = bc_d(pv1, src), qv2 = bc_d(pv2, src), qv3 = bc_d(pv3, src);
 #define ROW_IDX(e) ((e) == 0 ? qi0 : (e) == 1 ? qi1 : (e) == 2 ? qi2 : (e) == 3 ? qi3 : r.idx[(i64)(e) * r.stride + row])
 #define ROW_VAL(e) ((e) == 0 ? qv0 : (e) == 1 ? qv1 : (e) == 2 ? qv2 : (e) == 3 ? qv3 : r.val[(i64)(e) * r.stride + row])
             // score with the current state: dot in ascending dimension order (:238-240)
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, 
             for (int e = 0; e < n; e++) {
                 const i32 d = ROW_IDX(e);
                 const unsigned long long hit = __ballot(idx == d);
-                if (hit) dot += __shfl(val, __ffsll((long long)hit) - 1) * ROW_VAL(e);
+                if (hit) dot += bc_d(val, __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1)) * ROW_VAL(e);
             }
             dot /= nrm;
             dot /= rxn;
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, 
                 val /= fn;
                 cnt += w;
                 double s2 = 0.0;
-                for (int i = 0; i < sn; i++) { const double vi = __shfl(val, i); s2 += vi * vi; }
+                for (int i = 0; i < sn; i++) { const double vi = bc_d(val, i); s2 += vi * vi; }
                 nrm = sqrt(s2);
             }
         }
