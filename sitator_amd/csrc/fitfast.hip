@@ -57,6 +57,8 @@ struct FFBatch {
     double *vcos, *xn;
     i32 *first_new, *first_bad;
     i32 *log_n, *log;         // growth log of the last walk: (centre, dimension, batch row) triples
+    i32 *lcnt, *loff, *lcur;  // per-centre visit lists of the batch: counts, offsets [K+1], fill cursors
+    unsigned int *lent;       // entries (row_in_batch << 5 | slot), grouped by centre (unsorted within a group)
 };
 
 // value of centre c at dimension d (0 when d is outside its support); binary search in the sorted support
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void k_ff_speculate(FFState s, FFRows r, FFBat
     }
     b.dec[j] = dec; b.ov_n[j] = nov; b.xn[j] = xn;
     b.ov_max[j] = nov > 0 ? ov[(nov - 1) * ovs] : -1;
+    if (dec >= 0) for (int p = 0; p < nov; p++) atomicAdd(&b.lcnt[ov[p * ovs]], 1);
     if (dec < 0) atomicMin(b.first_new, j);
 }
 
@@ -181,23 +184,88 @@ __device__ __forceinline__ void ff_load_pre(Pre &P, const FFRows &r, const FFBat
 }
 
 // ---- B: walk ----------------------------------------------------------------------------------------
-// One wave per centre; lane i holds support entry i.  Writes the walked state to the shadow arrays `o`.
-__global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, FFBatch b, i64 row0, int nb)
-{
-    {   // the batch ends before the first row that founds a cluster (speculation ran just before)
-        const int fn = *b.first_new;
-        if (fn < nb) nb = fn;
+// One wave per centre; lane i holds support entry i.  The walked state goes to the shadow arrays.
+struct Walker {
+    i32 idx;
+    double val;
+    int sn, k, lane;
+    i64 cnt;
+    double nrm;
+
+    __device__ __forceinline__ void load(const FFState &s, int k_, int lane_)
+    {
+        k = k_; lane = lane_;
+        sn = s.cs_n[k];
+        idx = lane < sn ? s.cs_idx[(i64)k * FF_CS + lane] : 0x7fffffff;
+        val = lane < sn ? s.cs_val[(i64)k * FF_CS + lane] : 0.0;
+        cnt = s.c_cnt[k];
+        nrm = s.c_nrm[k];
     }
-    const int k = blockIdx.x;
-    const int lane = threadIdx.x;
-    int sn = s.cs_n[k];
-    i32 idx = lane < sn ? s.cs_idx[(i64)k * FF_CS + lane] : 0x7fffffff;
-    double val = lane < sn ? s.cs_val[(i64)k * FF_CS + lane] : 0.0;
-    i64 cnt = s.c_cnt[k];
-    double nrm = s.c_nrm[k];
-    // Per chunk of 64 rows every lane needs its row's overlap list head and (if it lists me) the row itself.
-    // All of it is loaded unconditionally in one batch of independent loads, one chunk AHEAD of its use, so the
-    // chunk loop pays one memory round trip per iteration instead of three dependent ones.
+    __device__ __forceinline__ void store(const FFState &o) const
+    {
+        if (lane < sn) { o.cs_idx[(i64)k * FF_CS + lane] = idx; o.cs_val[(i64)k * FF_CS + lane] = val; }
+        if (lane == 0) { o.cs_n[k] = sn; o.c_cnt[k] = cnt; o.c_nrm[k] = nrm; }
+    }
+    // Visit one row (all arguments wave-uniform): score it with the current state, and apply the running-mean
+    // update if it was speculated to join this centre.  false = a capacity was hit (the walk is void from jj on).
+    __device__ __forceinline__ bool visit(const FFRows &r, const FFBatch &b, i64 row, int jj, int sl, int n, int rdec,
+                                          double rxn, i64 w, i32 qi0, i32 qi1, i32 qi2, i32 qi3,
+                                          double qv0, double qv1, double qv2, double qv3)
+    {
+#define ROW_IDX(e) ((e) == 0 ? qi0 : (e) == 1 ? qi1 : (e) == 2 ? qi2 : (e) == 3 ? qi3 : r.idx[(i64)(e) * r.stride + row])
+#define ROW_VAL(e) ((e) == 0 ? qv0 : (e) == 1 ? qv1 : (e) == 2 ? qv2 : (e) == 3 ? qv3 : r.val[(i64)(e) * r.stride + row])
+        // score with the current state: dot in ascending dimension order (:238-240)
+        double dot = 0.0;
+        for (int e = 0; e < n; e++) {
+            const i32 d = ROW_IDX(e);
+            const unsigned long long hit = __ballot(idx == d);
+            if (hit) dot += bc_d(val, __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1)) * ROW_VAL(e);
+        }
+        dot /= nrm;
+        dot /= rxn;
+        if (lane == 0) b.vcos[(i64)sl * FF_BMAX + jj] = dot;
+        if (rdec == k) {                                          // running-mean update (:283-288)
+            const double fo = (double)cnt, fn = (double)(cnt + w);
+            val *= fo;
+            for (int e = 0; e < n; e++) {
+                const i32 d = ROW_IDX(e);
+                const double v = ROW_VAL(e);
+                const unsigned long long hit = __ballot(idx == d);
+                if (hit) { if (idx == d) val += v; continue; }
+                // the centre gains dimension d (0 * fo + v): sorted insertion across the lanes, and a log
+                // record so that later rows holding d without listing this centre are invalidated
+                int slot_l = 0;
+                if (lane == 0) slot_l = atomicAdd(b.log_n, 1);
+                slot_l = __builtin_amdgcn_readfirstlane(slot_l);
+                if (sn == FF_CS || slot_l >= FF_LOG) {
+                    if (lane == 0) atomicMin(b.first_bad, jj);       // capacity: this row goes the serial way
+                    return false;
+                }
+                if (lane == 0) { b.log[3 * slot_l] = k; b.log[3 * slot_l + 1] = d; b.log[3 * slot_l + 2] = jj; }
+                const int p = __popcll(__ballot(idx < d));
+                const i32 idx_up = __shfl_up(idx, 1);
+                const double val_up = __shfl_up(val, 1);
+                if (lane > p) { idx = idx_up; val = val_up; }
+                else if (lane == p) { idx = d; val = v; }
+                sn++;
+            }
+            val /= fn;
+            cnt += w;
+            double s2 = 0.0;
+            for (int i = 0; i < sn; i++) { const double vi = bc_d(val, i); s2 += vi * vi; }
+            nrm = sqrt(s2);
+        }
+        return true;
+#undef ROW_IDX
+#undef ROW_VAL
+    }
+};
+
+// Scanning walk: every centre reads every row's overlap list.  Kept for centres whose visit list does not
+// fit the LDS sort buffer of k_ff_walk_list.
+__device__ void ff_walk_scan(Walker &wk, const FFRows &r, const FFBatch &b, i64 row0, int nb)
+{
+    const int k = wk.k, lane = wk.lane;
     Pre cur, nxt;
     ff_load_pre(cur, r, b, row0, lane, nb);
     for (int j0 = 0; j0 < nb; j0 += 64) {
@@ -213,70 +281,108 @@ __global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, 
             else if (cur.m > 3 && cur.o3 == k) slot = 3;
             else for (int p = 4; p < cur.m; p++) if (OV(b, j, p) == k) { slot = p; break; }
         }
-        const int pn = cur.n, pdec = cur.dec; const i64 pw = cur.w; const double pxn = cur.xn;
-        const i32 pi0 = cur.i0, pi1 = cur.i1, pi2 = cur.i2, pi3 = cur.i3;
-        const double pv0 = cur.v0, pv1 = cur.v1, pv2 = cur.v2, pv3 = cur.v3;
+        const Pre me = cur;
         cur = nxt;
         unsigned long long todo = __ballot(slot >= 0);
         while (todo) {
             const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
             todo &= todo - 1;
-            const int jj = j0 + src;
-            const int sl = bc_i(slot, src);
-            const i64 row = row0 + jj;
-            const int n = bc_i(pn, src);
-            const int rdec = bc_i(pdec, src);
-            const double rxn = bc_d(pxn, src);
-            const i64 w = bc_l(pw, src);
-            const i32 qi0 = bc_i(pi0, src), qi1 = bc_i(pi1, src), qi2 = bc_i(pi2, src), qi3 = bc_i(pi3, src);
-            const double qv0 = bc_d(pv0, src), qv1 = bc_d(pv1, src), qv2 = bc_d(pv2, src), qv3 = bc_d(pv3, src);
-#define ROW_IDX(e) ((e) == 0 ? qi0 : (e) == 1 ? qi1 : (e) == 2 ? qi2 : (e) == 3 ? qi3 : r.idx[(i64)(e) * r.stride + row])
-#define ROW_VAL(e) ((e) == 0 ? qv0 : (e) == 1 ? qv1 : (e) == 2 ? qv2 : (e) == 3 ? qv3 : r.val[(i64)(e) * r.stride + row])
-            // score with the current state: dot in ascending dimension order (:238-240)
-            double dot = 0.0;
-            for (int e = 0; e < n; e++) {
-                const i32 d = ROW_IDX(e);
-                const unsigned long long hit = __ballot(idx == d);
-                if (hit) dot += bc_d(val, __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1)) * ROW_VAL(e);
-            }
-            dot /= nrm;
-            dot /= rxn;
-            if (lane == 0) b.vcos[(i64)sl * FF_BMAX + jj] = dot;
-            if (rdec == k) {                                          // running-mean update (:283-288)
-                const double fo = (double)cnt, fn = (double)(cnt + w);
-                val *= fo;
-                for (int e = 0; e < n; e++) {
-                    const i32 d = ROW_IDX(e);
-                    const double v = ROW_VAL(e);
-                    const unsigned long long hit = __ballot(idx == d);
-                    if (hit) { if (idx == d) val += v; continue; }
-                    // the centre gains dimension d (0 * fo + v): sorted insertion across the lanes, and a log
-                    // record so that later rows holding d without listing this centre are invalidated
-                    int slot_l = 0;
-                    if (lane == 0) slot_l = atomicAdd(b.log_n, 1);
-                    slot_l = __shfl(slot_l, 0);
-                    if (sn == FF_CS || slot_l >= FF_LOG) {
-                        if (lane == 0) atomicMin(b.first_bad, jj);       // capacity: this row goes the serial way
-                        return;
-                    }
-                    if (lane == 0) { b.log[3 * slot_l] = k; b.log[3 * slot_l + 1] = d; b.log[3 * slot_l + 2] = jj; }
-                    const int p = __popcll(__ballot(idx < d));
-                    const i32 idx_up = __shfl_up(idx, 1);
-                    const double val_up = __shfl_up(val, 1);
-                    if (lane > p) { idx = idx_up; val = val_up; }
-                    else if (lane == p) { idx = d; val = v; }
-                    sn++;
-                }
-                val /= fn;
-                cnt += w;
-                double s2 = 0.0;
-                for (int i = 0; i < sn; i++) { const double vi = bc_d(val, i); s2 += vi * vi; }
-                nrm = sqrt(s2);
-            }
+            if (!wk.visit(r, b, row0 + j0 + src, j0 + src, bc_i(slot, src), bc_i(me.n, src), bc_i(me.dec, src), bc_d(me.xn, src),
+                          bc_l(me.w, src), bc_i(me.i0, src), bc_i(me.i1, src), bc_i(me.i2, src), bc_i(me.i3, src),
+                          bc_d(me.v0, src), bc_d(me.v1, src), bc_d(me.v2, src), bc_d(me.v3, src))) return;
         }
     }
-    if (lane < sn) { o.cs_idx[(i64)k * FF_CS + lane] = idx; o.cs_val[(i64)k * FF_CS + lane] = val; }
-    if (lane == 0) { o.cs_n[k] = sn; o.c_cnt[k] = cnt; o.c_nrm[k] = nrm; }
+}
+
+#define FF_LCAP 8192       // LDS sort buffer (entries) of the list walk
+
+// List walk: the batch's (row, slot) visit records of this centre were grouped by k_ff_scatter; sort them by row
+// in LDS (bitonic, one wave) and visit them in order -- no scanning of rows that do not concern this centre.
+__global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, FFBatch b, i64 row0, int nb)
+{
+    __shared__ unsigned int ent[FF_LCAP];
+    {   // the batch ends before the first row that founds a cluster (speculation ran just before)
+        const int fn = *b.first_new;
+        if (fn < nb) nb = fn;
+    }
+    const int k = blockIdx.x, lane = threadIdx.x;
+    Walker wk;
+    wk.load(s, k, lane);
+    const int lo = b.loff[k], n_ent = b.loff[k + 1] - lo;
+    if (n_ent > FF_LCAP) {
+        ff_walk_scan(wk, r, b, row0, nb);
+        wk.store(o);
+        return;
+    }
+    int P = 64;
+    while (P < n_ent) P <<= 1;
+    for (int t = lane; t < P; t += 64) ent[t] = t < n_ent ? b.lent[lo + t] : 0xffffffffu;
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+            for (int t = lane; t < P; t += 64) {
+                const int x = t ^ j2;
+                if (x > t) {
+                    const unsigned int a = ent[t], c = ent[x];
+                    if ((a > c) == ((t & k2) == 0)) { ent[t] = c; ent[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int base = 0; base < n_ent; base += 64) {
+        const unsigned int e = base + lane < n_ent ? ent[base + lane] : 0xffffffffu;
+        const int j = (int)(e >> 5), slot = (int)(e & 31u);
+        const bool valid = e != 0xffffffffu && j < nb;
+        Pre me;
+        me.n = 0; me.dec = FF_BREAK; me.xn = 1.0; me.w = 1; me.i0 = me.i1 = me.i2 = me.i3 = 0; me.v0 = me.v1 = me.v2 = me.v3 = 0.0;
+        if (valid) {
+            const i64 row = row0 + j;
+            me.n = r.nnz[row]; me.dec = b.dec[j]; me.xn = b.xn[j];
+            if (r.weights) me.w = r.weights[row];
+            me.i0 = r.idx[row]; me.v0 = r.val[row];
+            if (r.width > 1) { me.i1 = r.idx[r.stride + row]; me.v1 = r.val[r.stride + row]; }
+            if (r.width > 2) { me.i2 = r.idx[2 * r.stride + row]; me.v2 = r.val[2 * r.stride + row]; }
+            if (r.width > 3) { me.i3 = r.idx[3 * r.stride + row]; me.v3 = r.val[3 * r.stride + row]; }
+        }
+        const int nvalid = __popcll(__ballot(valid));      // sorted by row: the valid entries are a prefix
+        if (nvalid == 0) break;
+        if (bc_i(j, 0) > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        for (int src = 0; src < nvalid; src++) {
+            const int jj = bc_i(j, src);
+            if (!wk.visit(r, b, row0 + jj, jj, bc_i(slot, src), bc_i(me.n, src), bc_i(me.dec, src), bc_d(me.xn, src),
+                          bc_l(me.w, src), bc_i(me.i0, src), bc_i(me.i1, src), bc_i(me.i2, src), bc_i(me.i3, src),
+                          bc_d(me.v0, src), bc_d(me.v1, src), bc_d(me.v2, src), bc_d(me.v3, src))) return;
+        }
+        if (nvalid < 64) break;
+    }
+    wk.store(o);
+}
+
+// offsets of the per-centre visit lists (single block) and the scatter that fills them
+__global__ __launch_bounds__(256) void k_ff_list_offsets(FFState s, FFBatch b)
+{
+    __shared__ int part[256];
+    const int K = *s.K, t = threadIdx.x;
+    const int per = (K + 255) / 256;
+    int sum = 0;
+    for (int i = t * per; i < (t + 1) * per && i < K; i++) sum += b.lcnt[i];
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) { int acc = 0; for (int i = 0; i < 256; i++) { const int v = part[i]; part[i] = acc; acc += v; } b.loff[K] = acc; }
+    __syncthreads();
+    int acc = part[t];
+    for (int i = t * per; i < (t + 1) * per && i < K; i++) { b.loff[i] = acc; acc += b.lcnt[i]; b.lcur[i] = 0; b.lcnt[i] = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_ff_scatter(FFBatch b, int nb)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nb || b.dec[j] < 0) return;
+    const int m = b.ov_n[j];
+    for (int p = 0; p < m; p++) {
+        const i32 c = OV(b, j, p);
+        b.lent[b.loff[c] + atomicAdd(&b.lcur[c], 1)] = ((unsigned int)j << 5) | (unsigned int)p;
+    }
 }
 
 // ---- C: verify ---------------------------------------------------------------------------------------
@@ -438,7 +544,7 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     const i64 D = c->D;
     size_t per_state = (size_t)Kcap * (4 + FF_CS * 12 + 16) + 4096;
     size_t total = 2 * per_state + (size_t)D * (4 + FF_DC * 4) + 8192
-                 + (size_t)FF_BMAX * (4 + 4 + 4 + FF_OC * 4 + FF_OC * 8 + 8) + 65536 + (size_t)FF_LOG * 12 + 4096;
+                 + (size_t)FF_BMAX * (4 + 4 + 4 + FF_OC * 4 + FF_OC * 8 + 8 + FF_OC * 4) + (size_t)Kcap * 12 + 65536 + (size_t)FF_LOG * 12 + 4096;
     HIP_TRY(c, hipMalloc(&f->blob, total));
     HIP_TRY(c, hipMemsetAsync(f->blob, 0, total, c->stream));
     char *p = (char *)f->blob;
@@ -466,6 +572,10 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     f->bt.log_n = f->bt.first_new + 2;
     f->st.flags = f->sh.flags = f->bt.first_new + 3;
     f->bt.log = (i32 *)carve(p, (size_t)FF_LOG * 12);
+    f->bt.lcnt = (i32 *)carve(p, (size_t)(Kcap + 1) * 4);
+    f->bt.loff = (i32 *)carve(p, (size_t)(Kcap + 1) * 4);
+    f->bt.lcur = (i32 *)carve(p, (size_t)(Kcap + 1) * 4);
+    f->bt.lent = (unsigned int *)carve(p, (size_t)FF_BMAX * FF_OC * 4);
     f->d_scr = (i32 *)carve(p, 256);
     f->D = D; f->Kcap = Kcap; f->ready = true; f->valid = false;
     return SIT_OK;
@@ -594,6 +704,8 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 12, hipMemcpyHostToDevice, c->stream));
         k_ff_speculate<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
         if (K > 0) {
+            k_ff_list_offsets<<<dim3(1), dim3(256), 0, c->stream>>>(f->st, f->bt);
+            k_ff_scatter<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->bt, nb);
             k_ff_walk<<<dim3((unsigned)K), dim3(64), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, nb);
             k_ff_verify<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
         }
