@@ -1,0 +1,112 @@
+"""GPU, BASELINE.json full size (config C2: 100 000 frames x 64 mobile ions = 6.4e6 landmark vectors):
+size-independent properties plus oracle parity on a random sample of frames."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2_full():
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth
+    host = synth.config_host("C2")
+    gen = synth.TrajectoryGenerator(host, 64, seed=2)
+    ref = gen.reference_positions()
+    frames = gen.generate(100000)
+    sn = SiteNetwork(Structure(ref, host.cell), gen.static_mask, gen.mobile_mask)
+    sn.centers = host.centers
+    sn.vertices = host.vertices
+    la = LandmarkAnalysis(verbose=False)
+    st = la.run(sn, frames)
+    return host, gen, ref, frames, sn, la, st
+
+
+def test_full_size_outputs_are_consistent(c2_full):
+    host, gen, ref, frames, sn, la, st = c2_full
+    assert st.traj.shape == (100000, 64) and st.traj.dtype == np.int64
+    K = st.site_network.n_sites
+    assert K >= 64 and st.traj.max() == K - 1 and st.traj.min() >= -1
+    # every kept site passed the min_samples filter; confidences of assigned rows are >= the assignment threshold
+    counts = np.bincount(st.traj[st.traj >= 0], minlength=K)
+    assert counts.min() >= 1
+    m = st.traj >= 0
+    assert st.confidences[m].min() >= 0.8 and st.confidences[m].max() <= 1.0 + 1e-12
+    assert np.all(st.confidences[~m] == 0.0)
+    # at most one ion per site and frame (the occupancy check passed), re-derived on the host
+    assert la.n_multiple_assignments == 0 and la.avg_mobile_per_site == 1.0
+    srt = np.sort(st.traj, axis=1)
+    assert not np.any((srt[:, 1:] == srt[:, :-1]) & (srt[:, 1:] >= 0))
+    # site centres lie inside the cell
+    frac = np.asarray(st.site_network.centers) @ np.linalg.inv(host.cell)
+    assert frac.min() >= -1e-9 and frac.max() < 1 + 1e-9
+
+
+def test_full_size_sample_matches_oracle(c2_full, oracle):
+    """Landmark vectors and labels of 40 random frames vs the CPU oracle (same centres)."""
+    host, gen, ref, frames, sn, la, st = c2_full
+    rng = np.random.default_rng(5)
+    pick = np.sort(rng.choice(100000, size=40, replace=False))
+    wrapped = oracle.wrap_points(host.cell, frames[pick])
+    verts, vcd = oracle.site_vertex_distances(host.cell, host.centers, host.vertices, ref[gen.static_mask])
+    exp, _ = oracle.fill(host.cell, wrapped, np.where(gen.static_mask)[0], np.where(gen.mobile_mask)[0],
+                         ref[gen.static_mask], verts, vcd)
+    for i, f in enumerate(pick):
+        mine = la._ctx.rows_dense(int(f) * 64, 64)
+        assert np.array_equal(mine != 0, exp[i * 64:(i + 1) * 64] != 0)
+        np.testing.assert_allclose(mine, exp[i * 64:(i + 1) * 64], rtol=1e-6, atol=0)
+    lab, conf = oracle.predict(exp, np.asarray(la.cluster_centers_), 0.8, True)
+    assert np.array_equal(lab.reshape(40, 64), st.traj[pick])
+    mm = lab >= 0
+    np.testing.assert_allclose(conf[mm], st.confidences[pick].reshape(-1)[mm], rtol=1e-6)
+
+
+def test_full_size_two_shards_equal_one_pass(c2_full):
+    """Frame sharding: two contexts chained through the clustering state give the single-pass labels."""
+    from sitator_amd import _lib
+    from sitator_amd.dotprod_classifier import DotProdClassifier, LandmarkVectors
+    from sitator_amd.sharding import Comm
+    host, gen, ref, frames, sn, la, st = c2_full
+
+    class Chain(Comm):            # two "ranks" executed one after the other in this process
+        size = 1
+
+    ctxs = []
+    for lo, hi in ((0, 50000), (50000, 100000)):
+        c = _lib.HipContext(host.cell)
+        verts = np.full((512, 8), -1, dtype=np.int64)
+        for k, v in enumerate(host.vertices):
+            verts[k] = v
+        vcd = c.site_vertex_distances(host.centers, ref[gen.static_mask], verts)
+        c.set_basis(ref[gen.static_mask], verts, vcd, 1.5, 30, 1.0)
+        c.set_frames(frames[lo:hi], np.where(gen.static_mask)[0], np.where(gen.mobile_mask)[0], frame0=lo)
+        assert c.fill()[0] == 0
+        ctxs.append(c)
+    ctxs[0].fit_reset()
+    ctxs[0].fit_push_stored_rows(0.45)
+    cen, cnt = ctxs[0].fit_get_state()
+    ctxs[1].fit_set_state(cen, cnt)
+    ctxs[1].fit_push_stored_rows(0.45)
+    cen, cnt = ctxs[1].fit_get_state()
+    # iterations >= 2 on one context (replicated on every rank in a real run)
+    last = len(cen)
+    for _ in range(9):
+        ctxs[0].fit_reset()
+        ctxs[0].fit_push_dense_rows(cen, cnt, 0.45)
+        cen, cnt = ctxs[0].fit_get_state()
+        if len(cen) == last:
+            break
+        last = len(cen)
+    clf = DotProdClassifier(threshold=0.45, min_samples=0.01 / 64)
+    clf.set_cluster_centers(cen)
+    normed = cen / np.linalg.norm(cen, axis=1)[:, None]
+    counts = np.zeros(len(cen), dtype=np.int64)
+    for c in ctxs:
+        c.set_centers(normed, True)
+        counts += c.predict(0.8, fetch=False)[2]
+    keep = counts >= max(int(np.floor(0.01 / 64 * counts.sum())), 1)
+    normed = normed[keep]
+    labels = []
+    for c in ctxs:
+        c.set_centers(normed, True)
+        labels.append(c.predict(0.8)[0])
+    assert np.array_equal(np.concatenate(labels).reshape(100000, 64), st.traj)
