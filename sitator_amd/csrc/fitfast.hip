@@ -7,14 +7,18 @@
 //   A  speculate  (lane per row)    decide every row against the centres AS OF THE BATCH START; record the
 //                                   centres that share a dimension with the row (only those can score != 0).
 //                                   The batch is cut before the first row that founds a cluster.
-//   B  walk       (wave per centre) centre k visits, IN ROW ORDER, the rows that list it: it scores the row
-//                                   with its CURRENT state (bit-for-bit the reference's arithmetic), and if
-//                                   the row was speculated to join k it applies the running-mean update.
-//                                   Centres evolve independently given the decisions, so K waves run in parallel.
-//   C  verify     (lane per row)    re-decide every row from the scores of step B.  By induction the first
-//                                   row whose decision differs from its speculation is the first wrong one:
-//                                   rows before it are exact.  The batch is then re-walked up to that row,
-//                                   committed, and the stream continues from there (state is exact again).
+//   B  walk       (wave per centre) centre k applies, IN ROW ORDER, the running-mean updates of the rows that
+//                                   were speculated to join it (bit-for-bit the reference's arithmetic) and
+//                                   publishes every intermediate state as a VERSION, keyed by the joining row.
+//                                   Centres evolve independently given the decisions, so K waves run in
+//                                   parallel, and the sequential chain of a centre is its joins only: multiply,
+//                                   add, divide (norms and scores are computed off the chain, in step C).
+//   C  verify     (lane per row)    score every row against the version of each overlapping centre it sees
+//                                   (the one left by that centre's last join before the row: binary search in
+//                                   the centre's sorted join list) and re-decide it.  By induction the first row whose decision differs from
+//                                   its speculation is the first wrong one: rows before it are exact.  The
+//                                   batch is then re-walked up to that row, committed, and the stream continues
+//                                   from there (state is exact again).
 // Rows that found clusters, rows whose join grows a centre's support (later rows' overlap lists would be
 // stale) and rows exceeding a capacity are applied one at a time by k_ff_serial with the same arithmetic.
 // Centres are kept sparse (sorted support, <= FF_CS entries); dot products sum in ascending dimension
@@ -53,12 +57,14 @@ struct FFState {
 
 #define OV(b, j, p) (b).ov_id[(i64)(p) * FF_BMAX + (j)]     // slot-major: coalesced across rows
 struct FFBatch {
-    i32 *dec, *ov_n, *ov_id, *ov_max;
-    double *vcos, *xn;
+    i32 *dec, *ov_n, *ov_id;
+    double *xn;
+    i32 *vs_n, *vs_idx;       // versions: state of the joined centre right after batch row j joined it
+    double *vs_val;
     i32 *first_new, *first_bad;
     i32 *log_n, *log;         // growth log of the last walk: (centre, dimension, batch row) triples
-    i32 *lcnt, *loff, *lcur;  // per-centre visit lists of the batch: counts, offsets [K+1], fill cursors
-    unsigned int *lent;       // entries (row_in_batch << 5 | slot), grouped by centre (unsorted within a group)
+    i32 *lcnt, *loff, *lcur;  // per-centre join lists of the batch: counts, offsets [K+1], fill cursors
+    i32 *lent;                // batch rows speculated to join each centre, grouped by centre (sorted by the walk)
 };
 
 // value of centre c at dimension d (0 when d is outside its support); binary search in the sorted support
@@ -139,8 +145,7 @@ __global__ __launch_bounds__(256) void k_ff_speculate(FFState s, FFRows r, FFBat
         }
     }
     b.dec[j] = dec; b.ov_n[j] = nov; b.xn[j] = xn;
-    b.ov_max[j] = nov > 0 ? ov[(nov - 1) * ovs] : -1;
-    if (dec >= 0) for (int p = 0; p < nov; p++) atomicAdd(&b.lcnt[ov[p * ovs]], 1);
+    if (dec >= 0) atomicAdd(&b.lcnt[dec], 1);
     if (dec < 0) atomicMin(b.first_new, j);
 }
 
@@ -157,31 +162,19 @@ __device__ __forceinline__ i64 bc_l(i64 v, int src)
     return ((i64)hi << 32) | lo;
 }
 
-struct Pre {
-    int m, omax, n, dec;
-    i32 o0, o1, o2, o3;
-    double xn;
-    i64 w;
-    i32 i0, i1, i2, i3;
-    double v0, v1, v2, v3;
-};
-
-__device__ __forceinline__ void ff_load_pre(Pre &P, const FFRows &r, const FFBatch &b, i64 row0, int j, int nb)
+#ifdef FF_PROFILE
+__device__ unsigned long long ff_prof[8];   // cycles: sort, group-head, joins; counts: joins, groups, waves; max wave cycles
+#define FF_T(x) const long long x = clock64()
+#define FF_ACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&ff_prof[i], (unsigned long long)(v)); } while (0)
+extern "C" void sit_debug_ff_prof(unsigned long long *out, int reset)
 {
-    P.m = 0; P.omax = -1; P.n = 0; P.dec = FF_BREAK; P.xn = 1.0; P.w = 1;
-    P.o0 = P.o1 = P.o2 = P.o3 = 0; P.i0 = P.i1 = P.i2 = P.i3 = 0; P.v0 = P.v1 = P.v2 = P.v3 = 0.0;
-    if (j < nb) {
-        const i64 row = row0 + j;
-        P.m = b.ov_n[j]; P.omax = b.ov_max[j];
-        P.o0 = OV(b, j, 0); P.o1 = OV(b, j, 1); P.o2 = OV(b, j, 2); P.o3 = OV(b, j, 3);
-        P.n = r.nnz[row]; P.dec = b.dec[j]; P.xn = b.xn[j];
-        if (r.weights) P.w = r.weights[row];
-        P.i0 = r.idx[row]; P.v0 = r.val[row];
-        if (r.width > 1) { P.i1 = r.idx[r.stride + row]; P.v1 = r.val[r.stride + row]; }
-        if (r.width > 2) { P.i2 = r.idx[2 * r.stride + row]; P.v2 = r.val[2 * r.stride + row]; }
-        if (r.width > 3) { P.i3 = r.idx[3 * r.stride + row]; P.v3 = r.val[3 * r.stride + row]; }
-    }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_prof), sizeof(ff_prof));
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(ff_prof), z, sizeof(z)); }
 }
+#else
+#define FF_T(x)
+#define FF_ACC(i, v)
+#endif
 
 // ---- B: walk ----------------------------------------------------------------------------------------
 // One wave per centre; lane i holds support entry i.  The walked state goes to the shadow arrays.
@@ -189,8 +182,10 @@ struct Walker {
     i32 idx;
     double val;
     int sn, k, lane;
-    i64 cnt;
+    double cnt;            // sample count, exact in a double (< 2^53)
+    i64 cnt_i;
     double nrm;
+    bool touched;
 
     __device__ __forceinline__ void load(const FFState &s, int k_, int lane_)
     {
@@ -198,167 +193,188 @@ struct Walker {
         sn = s.cs_n[k];
         idx = lane < sn ? s.cs_idx[(i64)k * FF_CS + lane] : 0x7fffffff;
         val = lane < sn ? s.cs_val[(i64)k * FF_CS + lane] : 0.0;
-        cnt = s.c_cnt[k];
+        cnt_i = s.c_cnt[k];
+        cnt = (double)cnt_i;
         nrm = s.c_nrm[k];
+        touched = false;
     }
-    __device__ __forceinline__ void store(const FFState &o) const
+    __device__ __forceinline__ void store(const FFState &o)
     {
-        if (lane < sn) { o.cs_idx[(i64)k * FF_CS + lane] = idx; o.cs_val[(i64)k * FF_CS + lane] = val; }
-        if (lane == 0) { o.cs_n[k] = sn; o.c_cnt[k] = cnt; o.c_nrm[k] = nrm; }
-    }
-    // Visit one row (all arguments wave-uniform): score it with the current state, and apply the running-mean
-    // update if it was speculated to join this centre.  false = a capacity was hit (the walk is void from jj on).
-    __device__ __forceinline__ bool visit(const FFRows &r, const FFBatch &b, i64 row, int jj, int sl, int n, int rdec,
-                                          double rxn, i64 w, i32 qi0, i32 qi1, i32 qi2, i32 qi3,
-                                          double qv0, double qv1, double qv2, double qv3)
-    {
-#define ROW_IDX(e) ((e) == 0 ? qi0 : (e) == 1 ? qi1 : (e) == 2 ? qi2 : (e) == 3 ? qi3 : r.idx[(i64)(e) * r.stride + row])
-#define ROW_VAL(e) ((e) == 0 ? qv0 : (e) == 1 ? qv1 : (e) == 2 ? qv2 : (e) == 3 ? qv3 : r.val[(i64)(e) * r.stride + row])
-        // score with the current state: dot in ascending dimension order (:238-240)
-        double dot = 0.0;
-        for (int e = 0; e < n; e++) {
-            const i32 d = ROW_IDX(e);
-            const unsigned long long hit = __ballot(idx == d);
-            if (hit) dot += bc_d(val, __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1)) * ROW_VAL(e);
-        }
-        dot /= nrm;
-        dot /= rxn;
-        if (lane == 0) b.vcos[(i64)sl * FF_BMAX + jj] = dot;
-        if (rdec == k) {                                          // running-mean update (:283-288)
-            const double fo = (double)cnt, fn = (double)(cnt + w);
-            val *= fo;
-            for (int e = 0; e < n; e++) {
-                const i32 d = ROW_IDX(e);
-                const double v = ROW_VAL(e);
-                const unsigned long long hit = __ballot(idx == d);
-                if (hit) { if (idx == d) val += v; continue; }
-                // the centre gains dimension d (0 * fo + v): sorted insertion across the lanes, and a log
-                // record so that later rows holding d without listing this centre are invalidated
-                int slot_l = 0;
-                if (lane == 0) slot_l = atomicAdd(b.log_n, 1);
-                slot_l = __builtin_amdgcn_readfirstlane(slot_l);
-                if (sn == FF_CS || slot_l >= FF_LOG) {
-                    if (lane == 0) atomicMin(b.first_bad, jj);       // capacity: this row goes the serial way
-                    return false;
-                }
-                if (lane == 0) { b.log[3 * slot_l] = k; b.log[3 * slot_l + 1] = d; b.log[3 * slot_l + 2] = jj; }
-                const int p = __popcll(__ballot(idx < d));
-                const i32 idx_up = __shfl_up(idx, 1);
-                const double val_up = __shfl_up(val, 1);
-                if (lane > p) { idx = idx_up; val = val_up; }
-                else if (lane == p) { idx = d; val = v; }
-                sn++;
-            }
-            val /= fn;
-            cnt += w;
+        if (touched) {                                      // norm of the final state (:288), ascending sum
             double s2 = 0.0;
             for (int i = 0; i < sn; i++) { const double vi = bc_d(val, i); s2 += vi * vi; }
             nrm = sqrt(s2);
         }
+        if (lane < sn) { o.cs_idx[(i64)k * FF_CS + lane] = idx; o.cs_val[(i64)k * FF_CS + lane] = val; }
+        if (lane == 0) { o.cs_n[k] = sn; o.c_cnt[k] = cnt_i; o.c_nrm[k] = nrm; }
+    }
+    // Row jj (all arguments wave-uniform) joins this centre: running-mean update (:283-288), then the new state
+    // is published as version jj.  false = a capacity was hit (the walk is void from jj on).
+    // WIDE = rows may hold more than four entries (the rest is read from memory).  The narrow instance has no
+    // load in it: on gfx9 stores and loads share vmcnt, so a single load anywhere in the join loop would make
+    // every join wait for the previous join's version stores.
+    template <bool WIDE>
+    __device__ __forceinline__ bool join(const FFRows &r, const FFBatch &b, i64 row, int jj, int n, i64 w,
+                                         i32 qi0, i32 qi1, i32 qi2, i32 qi3, double qv0, double qv1, double qv2, double qv3)
+    {
+#define ROW_IDX(e) ((e) == 0 ? qi0 : (e) == 1 ? qi1 : (e) == 2 ? qi2 : (!WIDE || (e) == 3) ? qi3 : r.idx[(i64)(e) * r.stride + row])
+#define ROW_VAL(e) ((e) == 0 ? qv0 : (e) == 1 ? qv1 : (e) == 2 ? qv2 : (!WIDE || (e) == 3) ? qv3 : r.val[(i64)(e) * r.stride + row])
+        const double fo = cnt, fn = cnt + (double)w;          // exact: integers below 2^53
+        val *= fo;
+        for (int e = 0; e < n; e++) {
+            const i32 d = ROW_IDX(e);
+            const double v = ROW_VAL(e);
+            const unsigned long long hit = __ballot(idx == d);
+            if (hit) { if (idx == d) val += v; continue; }
+            // the centre gains dimension d (0 * fo + v): sorted insertion across the lanes, and a log
+            // record so that later rows holding d without listing this centre are invalidated
+            int slot_l = 0;
+            if (lane == 0) slot_l = atomicAdd(b.log_n, 1);
+            slot_l = __builtin_amdgcn_readfirstlane(slot_l);
+            if (sn == FF_CS || slot_l >= FF_LOG) {
+                if (lane == 0) atomicMin(b.first_bad, jj);       // capacity: this row goes the serial way
+                return false;
+            }
+            if (lane == 0) { b.log[3 * slot_l] = k; b.log[3 * slot_l + 1] = d; b.log[3 * slot_l + 2] = jj; }
+            const int p = __popcll(__ballot(idx < d));
+            const i32 idx_up = __shfl_up(idx, 1);
+            const double val_up = __shfl_up(val, 1);
+            if (lane > p) { idx = idx_up; val = val_up; }
+            else if (lane == p) { idx = d; val = v; }
+            sn++;
+        }
+        val /= fn;
+        cnt = fn; cnt_i += w;
+        touched = true;
+        if (lane < sn) { b.vs_idx[(i64)jj * FF_CS + lane] = idx; b.vs_val[(i64)jj * FF_CS + lane] = val; }
+        if (lane == 0) b.vs_n[jj] = sn;
         return true;
 #undef ROW_IDX
 #undef ROW_VAL
     }
+
+    // One group of <= 64 joining rows, ascending by lane.
+    __device__ __forceinline__ bool group(const FFRows &r, const FFBatch &b, i64 row0, int j, bool isjoin)
+    {
+        FF_T(t0);
+        int n = 0;
+        i64 w = 1;
+        i32 i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        if (isjoin) {
+            const i64 row = row0 + j;
+            n = r.nnz[row];
+            if (r.weights) w = r.weights[row];
+            i0 = r.idx[row]; v0 = r.val[row];
+            if (r.width > 1) { i1 = r.idx[r.stride + row]; v1 = r.val[r.stride + row]; }
+            if (r.width > 2) { i2 = r.idx[2 * r.stride + row]; v2 = r.val[2 * r.stride + row]; }
+            if (r.width > 3) { i3 = r.idx[3 * r.stride + row]; v3 = r.val[3 * r.stride + row]; }
+        }
+        unsigned long long jm = __ballot(isjoin);
+        FF_ACC(3, __popcll(jm)); FF_ACC(4, 1);
+        // every load of this group has landed before the join loop starts (no vmcnt wait inside it)
+        asm volatile("" :: "v"(n), "v"(w), "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+        FF_T(t1);
+        FF_ACC(1, t1 - t0);
+        if (__ballot(n > 4) == 0) {
+            while (jm) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)jm) - 1);
+                jm &= jm - 1;
+                const int jj = bc_i(j, src);
+                if (!join<false>(r, b, row0 + jj, jj, bc_i(n, src), bc_l(w, src), bc_i(i0, src), bc_i(i1, src), bc_i(i2, src),
+                                 bc_i(i3, src), bc_d(v0, src), bc_d(v1, src), bc_d(v2, src), bc_d(v3, src))) return false;
+            }
+        } else {
+            while (jm) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)jm) - 1);
+                jm &= jm - 1;
+                const int jj = bc_i(j, src);
+                if (!join<true>(r, b, row0 + jj, jj, bc_i(n, src), bc_l(w, src), bc_i(i0, src), bc_i(i1, src), bc_i(i2, src),
+                                bc_i(i3, src), bc_d(v0, src), bc_d(v1, src), bc_d(v2, src), bc_d(v3, src))) return false;
+            }
+        }
+        FF_T(t2);
+        FF_ACC(2, t2 - t1);
+        return true;
+    }
 };
 
-// Scanning walk: every centre reads every row's overlap list.  Kept for centres whose visit list does not
-// fit the LDS sort buffer of k_ff_walk_list.
-__device__ void ff_walk_scan(Walker &wk, const FFRows &r, const FFBatch &b, i64 row0, int nb)
-{
-    const int k = wk.k, lane = wk.lane;
-    Pre cur, nxt;
-    ff_load_pre(cur, r, b, row0, lane, nb);
-    for (int j0 = 0; j0 < nb; j0 += 64) {
-        // rows at or after the first known invalid row are void anyway (first_bad only ever decreases)
-        if ((j0 & 511) == 0 && j0 > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        ff_load_pre(nxt, r, b, row0, j0 + 64 + lane, nb);
-        const int j = j0 + lane;
-        int slot = -1;
-        if (cur.m > 0 && cur.o0 <= k && cur.omax >= k) {
-            if (cur.o0 == k) slot = 0;
-            else if (cur.m > 1 && cur.o1 == k) slot = 1;
-            else if (cur.m > 2 && cur.o2 == k) slot = 2;
-            else if (cur.m > 3 && cur.o3 == k) slot = 3;
-            else for (int p = 4; p < cur.m; p++) if (OV(b, j, p) == k) { slot = p; break; }
-        }
-        const Pre me = cur;
-        cur = nxt;
-        unsigned long long todo = __ballot(slot >= 0);
-        while (todo) {
-            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-            todo &= todo - 1;
-            if (!wk.visit(r, b, row0 + j0 + src, j0 + src, bc_i(slot, src), bc_i(me.n, src), bc_i(me.dec, src), bc_d(me.xn, src),
-                          bc_l(me.w, src), bc_i(me.i0, src), bc_i(me.i1, src), bc_i(me.i2, src), bc_i(me.i3, src),
-                          bc_d(me.v0, src), bc_d(me.v1, src), bc_d(me.v2, src), bc_d(me.v3, src))) return;
-        }
-    }
-}
+#define FF_LCAP 8192       // LDS sort buffer (entries) of the walk
 
-#define FF_LCAP 8192       // LDS sort buffer (entries) of the list walk
-
-// List walk: the batch's (row, slot) visit records of this centre were grouped by k_ff_scatter; sort them by row
-// in LDS (bitonic, one wave) and visit them in order -- no scanning of rows that do not concern this centre.
-__global__ __launch_bounds__(64) void k_ff_walk(FFState s, FFState o, FFRows r, FFBatch b, i64 row0, int nb)
+// The batch rows speculated to join centre k were grouped by k_ff_scatter (in arbitrary order): the workgroup sorts
+// them in LDS (bitonic), writes the sorted list back (step C searches it) and wave 0 applies the joins in order.
+__global__ __launch_bounds__(256) void k_ff_walk(FFState s, FFState o, FFRows r, FFBatch b, i64 row0, int nb)
 {
-    __shared__ unsigned int ent[FF_LCAP];
+    __shared__ i32 ent[FF_LCAP];
     {   // the batch ends before the first row that founds a cluster (speculation ran just before)
         const int fn = *b.first_new;
         if (fn < nb) nb = fn;
     }
-    const int k = blockIdx.x, lane = threadIdx.x;
-    Walker wk;
-    wk.load(s, k, lane);
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    FF_T(tw0);
     const int lo = b.loff[k], n_ent = b.loff[k + 1] - lo;
+    Walker wk;
+    if (n_ent == 0) {                                       // untouched centre: the shadow state is a copy
+        if (tid < 64) { wk.load(s, k, lane); wk.store(o); }
+        return;
+    }
     if (n_ent > FF_LCAP) {
-        ff_walk_scan(wk, r, b, row0, nb);
-        wk.store(o);
+        // too many joins for the LDS buffer: wave 0 finds them by scanning the decisions (already in row order)
+        if (tid >= 64) return;
+        wk.load(s, k, lane);
+        int filled = 0;
+        bool dead = false;                                  // a capacity was hit: keep listing, stop joining
+        for (int j0 = 0; j0 < nb; j0 += 64) {
+            const int j = j0 + lane;
+            const bool isjoin = j < nb && b.dec[j] == k;
+            const unsigned long long jm = __ballot(isjoin);
+            if (isjoin) b.lent[lo + filled + __popcll(jm & ((1ull << lane) - 1ull))] = j;
+            filled += __popcll(jm);
+            if (dead || !jm) continue;
+            if (j0 > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;   // void rows
+            dead = !wk.group(r, b, row0, j, isjoin);
+        }
+        // joins past the cut of the batch are not listed: step C never looks past the cut either
+        for (int t = filled + lane; t < n_ent; t += 64) b.lent[lo + t] = 0x7fffffff;
+        if (!dead) wk.store(o);
         return;
     }
     int P = 64;
     while (P < n_ent) P <<= 1;
-    for (int t = lane; t < P; t += 64) ent[t] = t < n_ent ? b.lent[lo + t] : 0xffffffffu;
+    for (int t = tid; t < P; t += 256) ent[t] = t < n_ent ? b.lent[lo + t] : 0x7fffffff;
     __syncthreads();
     for (int k2 = 2; k2 <= P; k2 <<= 1)
         for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int t = lane; t < P; t += 64) {
+            for (int t = tid; t < P; t += 256) {
                 const int x = t ^ j2;
                 if (x > t) {
-                    const unsigned int a = ent[t], c = ent[x];
+                    const i32 a = ent[t], c = ent[x];
                     if ((a > c) == ((t & k2) == 0)) { ent[t] = c; ent[x] = a; }
                 }
             }
             __syncthreads();
         }
+    for (int t = tid; t < n_ent; t += 256) b.lent[lo + t] = ent[t];
+    if (tid >= 64) return;
+    wk.load(s, k, lane);
+    FF_T(tw1);
+    FF_ACC(0, tw1 - tw0);
     for (int base = 0; base < n_ent; base += 64) {
-        const unsigned int e = base + lane < n_ent ? ent[base + lane] : 0xffffffffu;
-        const int j = (int)(e >> 5), slot = (int)(e & 31u);
-        const bool valid = e != 0xffffffffu && j < nb;
-        Pre me;
-        me.n = 0; me.dec = FF_BREAK; me.xn = 1.0; me.w = 1; me.i0 = me.i1 = me.i2 = me.i3 = 0; me.v0 = me.v1 = me.v2 = me.v3 = 0.0;
-        if (valid) {
-            const i64 row = row0 + j;
-            me.n = r.nnz[row]; me.dec = b.dec[j]; me.xn = b.xn[j];
-            if (r.weights) me.w = r.weights[row];
-            me.i0 = r.idx[row]; me.v0 = r.val[row];
-            if (r.width > 1) { me.i1 = r.idx[r.stride + row]; me.v1 = r.val[r.stride + row]; }
-            if (r.width > 2) { me.i2 = r.idx[2 * r.stride + row]; me.v2 = r.val[2 * r.stride + row]; }
-            if (r.width > 3) { me.i3 = r.idx[3 * r.stride + row]; me.v3 = r.val[3 * r.stride + row]; }
-        }
+        const int j = base + lane < n_ent ? ent[base + lane] : 0x7fffffff;
+        const bool valid = j < nb;
         const int nvalid = __popcll(__ballot(valid));      // sorted by row: the valid entries are a prefix
         if (nvalid == 0) break;
         if (bc_i(j, 0) > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        for (int src = 0; src < nvalid; src++) {
-            const int jj = bc_i(j, src);
-            if (!wk.visit(r, b, row0 + jj, jj, bc_i(slot, src), bc_i(me.n, src), bc_i(me.dec, src), bc_d(me.xn, src),
-                          bc_l(me.w, src), bc_i(me.i0, src), bc_i(me.i1, src), bc_i(me.i2, src), bc_i(me.i3, src),
-                          bc_d(me.v0, src), bc_d(me.v1, src), bc_d(me.v2, src), bc_d(me.v3, src))) return;
-        }
+        if (!wk.group(r, b, row0, j, valid)) return;
         if (nvalid < 64) break;
     }
     wk.store(o);
+#ifdef FF_PROFILE
+    { FF_T(tw2); FF_ACC(5, 1); if (threadIdx.x == 0) atomicMax(&ff_prof[6], (unsigned long long)(tw2 - tw0)); FF_ACC(7, tw2 - tw0); }
+#endif
 }
 
-// offsets of the per-centre visit lists (single block) and the scatter that fills them
+// offsets of the per-centre join lists (single block) and the scatter that fills them
 __global__ __launch_bounds__(256) void k_ff_list_offsets(FFState s, FFBatch b)
 {
     __shared__ int part[256];
@@ -377,12 +393,10 @@ __global__ __launch_bounds__(256) void k_ff_list_offsets(FFState s, FFBatch b)
 __global__ __launch_bounds__(256) void k_ff_scatter(FFBatch b, int nb)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= nb || b.dec[j] < 0) return;
-    const int m = b.ov_n[j];
-    for (int p = 0; p < m; p++) {
-        const i32 c = OV(b, j, p);
-        b.lent[b.loff[c] + atomicAdd(&b.lcur[c], 1)] = ((unsigned int)j << 5) | (unsigned int)p;
-    }
+    if (j >= nb) return;
+    const i32 c = b.dec[j];
+    if (c < 0) return;
+    b.lent[b.loff[c] + atomicAdd(&b.lcur[c], 1)] = j;
 }
 
 // ---- C: verify ---------------------------------------------------------------------------------------
@@ -396,8 +410,42 @@ __global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFRows r, FFBatch 
     if (j >= nb) return;
     const int K = *s.K;
     const int m = b.ov_n[j];
+    const i64 row = row0 + j;
+    const int n = r.nnz[row];
+    const double xn = b.xn[j];
     Best best = best_empty();
-    for (int p = 0; p < m; p++) best = best_merge(best, best_of(b.vcos[(i64)p * FF_BMAX + j], OV(b, j, p)));
+    for (int p = 0; p < m; p++) {
+        const i32 cc = OV(b, j, p);
+        // the state of centre cc as row j sees it: left by its last join before j (binary search in its sorted
+        // join list), or the batch-start state
+        int pj = -1;
+        {
+            const i32 *jl = b.lent + b.loff[cc];
+            int lo = 0, hi = b.loff[cc + 1] - b.loff[cc];
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (jl[mid] < j) lo = mid + 1; else hi = mid; }
+            if (lo > 0) pj = jl[lo - 1];
+        }
+        const i32 *ix = pj < 0 ? s.cs_idx + (i64)cc * FF_CS : b.vs_idx + (i64)pj * FF_CS;
+        const double *vv = pj < 0 ? s.cs_val + (i64)cc * FF_CS : b.vs_val + (i64)pj * FF_CS;
+        const int sn = pj < 0 ? s.cs_n[cc] : b.vs_n[pj];
+        double nrm;
+        if (pj < 0) nrm = s.c_nrm[cc];
+        else {                                                // :288, ascending sum
+            double s2 = 0.0;
+            for (int i = 0; i < sn; i++) s2 += vv[i] * vv[i];
+            nrm = sqrt(s2);
+        }
+        double dot = 0.0;
+        for (int e = 0; e < n; e++) {                         // ascending dimension order (:238)
+            const i32 d = r.idx[(i64)e * r.stride + row];
+            int lo = 0, hi = sn;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ix[mid] < d) lo = mid + 1; else hi = mid; }
+            if (lo < sn && ix[lo] == d) dot += vv[lo] * r.val[(i64)e * r.stride + row];
+        }
+        dot /= nrm;                                           // :239
+        dot /= xn;                                            // :240
+        best = best_merge(best, best_of(dot, cc));
+    }
     if (m < K) {
         i32 k0 = 0;
         for (int p = 0; p < m && OV(b, j, p) == k0; p++) k0++;
@@ -409,8 +457,6 @@ __global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFRows r, FFBatch 
     int nl = *b.log_n;
     if (nl > FF_LOG) nl = FF_LOG;
     if (nl > 0) {
-        const i64 row = row0 + j;
-        const int n = r.nnz[row];
         for (int q = 0; q < nl; q++) {
             if (b.log[3 * q + 2] >= j) continue;
             const i32 kk = b.log[3 * q], dd = b.log[3 * q + 1];
@@ -544,7 +590,7 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     const i64 D = c->D;
     size_t per_state = (size_t)Kcap * (4 + FF_CS * 12 + 16) + 4096;
     size_t total = 2 * per_state + (size_t)D * (4 + FF_DC * 4) + 8192
-                 + (size_t)FF_BMAX * (4 + 4 + 4 + FF_OC * 4 + FF_OC * 8 + 8 + FF_OC * 4) + (size_t)Kcap * 12 + 65536 + (size_t)FF_LOG * 12 + 4096;
+                 + (size_t)FF_BMAX * (4 + 4 + 4 + FF_OC * 4 + 8 + 4 + 4 + FF_CS * 12) + (size_t)Kcap * 12 + 65536 + (size_t)FF_LOG * 12 + 4096;
     HIP_TRY(c, hipMalloc(&f->blob, total));
     HIP_TRY(c, hipMemsetAsync(f->blob, 0, total, c->stream));
     char *p = (char *)f->blob;
@@ -563,9 +609,10 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     }
     f->bt.dec = (i32 *)carve(p, (size_t)FF_BMAX * 4);
     f->bt.ov_n = (i32 *)carve(p, (size_t)FF_BMAX * 4);
-    f->bt.ov_max = (i32 *)carve(p, (size_t)FF_BMAX * 4);
     f->bt.ov_id = (i32 *)carve(p, (size_t)FF_BMAX * FF_OC * 4);
-    f->bt.vcos = (double *)carve(p, (size_t)FF_BMAX * FF_OC * 8);
+    f->bt.vs_n = (i32 *)carve(p, (size_t)FF_BMAX * 4);
+    f->bt.vs_idx = (i32 *)carve(p, (size_t)FF_BMAX * FF_CS * 4);
+    f->bt.vs_val = (double *)carve(p, (size_t)FF_BMAX * FF_CS * 8);
     f->bt.xn = (double *)carve(p, (size_t)FF_BMAX * 8);
     f->bt.first_new = (i32 *)carve(p, 64);
     f->bt.first_bad = f->bt.first_new + 1;
@@ -575,7 +622,7 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     f->bt.lcnt = (i32 *)carve(p, (size_t)(Kcap + 1) * 4);
     f->bt.loff = (i32 *)carve(p, (size_t)(Kcap + 1) * 4);
     f->bt.lcur = (i32 *)carve(p, (size_t)(Kcap + 1) * 4);
-    f->bt.lent = (unsigned int *)carve(p, (size_t)FF_BMAX * FF_OC * 4);
+    f->bt.lent = (i32 *)carve(p, (size_t)FF_BMAX * 4);
     f->d_scr = (i32 *)carve(p, 256);
     f->D = D; f->Kcap = Kcap; f->ready = true; f->valid = false;
     return SIT_OK;
@@ -706,7 +753,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         if (K > 0) {
             k_ff_list_offsets<<<dim3(1), dim3(256), 0, c->stream>>>(f->st, f->bt);
             k_ff_scatter<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->bt, nb);
-            k_ff_walk<<<dim3((unsigned)K), dim3(64), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, nb);
+            k_ff_walk<<<dim3((unsigned)K), dim3(256), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, nb);
             k_ff_verify<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
         }
         HIP_TRY(c, hipGetLastError());
@@ -734,7 +781,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         if (first_bad > 0) {
             // FF_BREAK / founding rows inside [0, first_bad) cannot exist (first_bad < first_new)
             HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 12, hipMemcpyHostToDevice, c->stream));
-            k_ff_walk<<<dim3((unsigned)K), dim3(64), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, first_bad);
+            k_ff_walk<<<dim3((unsigned)K), dim3(256), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, first_bad);
             HIP_TRY(c, hipGetLastError());
             commit();
             pos += first_bad; c->ff_batches++;

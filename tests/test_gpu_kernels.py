@@ -146,3 +146,37 @@ def test_speculative_fit_matches_oracle(oracle):
     exp = oracle.fit_centers(X, 0.45)
     assert clf.cluster_centers.shape == exp.shape
     np.testing.assert_allclose(clf.cluster_centers, exp, rtol=1e-12, atol=1e-300)
+
+
+def test_speculative_fit_long_dwell_uses_scan_lists():
+    """Two slow ions: one centre takes far more joins per batch than the walk's LDS sort buffer holds, so
+    its join list is built by scanning the decisions instead.  Same centres as the ordered stream."""
+    from sitator_amd import synth
+    from sitator_amd.dotprod_classifier import LandmarkVectors
+    host = synth.config_host("C1")
+
+    def factory():
+        frames, sm, mm, ref = synth.make_trajectory(host, 2, 45000, seed=4, p_hop=2e-5)
+        return LandmarkVectors(_ctx_from(host, frames, sm, mm, ref))
+
+    fast, info = _fit_once(factory, "fast")
+    serial, _ = _fit_once(factory, "serial")
+    assert fast.shape == serial.shape
+    np.testing.assert_allclose(fast, serial, rtol=1e-12, atol=1e-300)
+    assert info["fit_batches"] > 0, "the speculative path did not run"
+
+
+def _ctx_from(host, frames, sm, mm, ref):
+    from sitator_amd import _lib
+    ctx = _lib.HipContext(host.cell)
+    ref_static = ref[sm]
+    V = max(len(v) for v in host.vertices)
+    verts = np.full((len(host.vertices), V), -1, dtype=np.int64)
+    vcd = np.full(verts.shape, np.nan)
+    for k, v in enumerate(host.vertices):
+        verts[k, :len(v)] = v
+        vcd[k, :len(v)] = ctx.distances(host.centers[k], ref_static[np.asarray(v)])
+    ctx.set_basis(ref_static, verts, vcd, 1.5, 30, 1.0)
+    ctx.set_frames(frames, np.where(sm)[0], np.where(mm)[0])
+    assert ctx.fill()[0] == 0
+    return ctx
