@@ -125,25 +125,199 @@ __device__ int ff_decide(const FFState &s, const FFRows &r, i64 row, double thre
     return (int)b.i;
 }
 
+// ---- lane-per-row helpers: no dependent chains of global loads -------------------------------------------
+// First eight support entries of a centre (or of one of its versions) in registers, the rest behind pointers.
+struct Sup8 {
+    i32 ix[8];
+    double vv[8];
+    int sn;
+    const i32 *pix;
+    const double *pvv;
+};
+
+__device__ __forceinline__ void sup_load(Sup8 &S, const i32 *ix, const double *vv, int sn)
+{
+    // rows of cs_idx / vs_idx are 256-byte aligned, rows of cs_val / vs_val 512-byte aligned
+    const int4 a = *(const int4 *)ix, b = *(const int4 *)(ix + 4);
+    const double2 v0 = *(const double2 *)vv, v1 = *(const double2 *)(vv + 2), v2 = *(const double2 *)(vv + 4), v3 = *(const double2 *)(vv + 6);
+    S.ix[0] = a.x; S.ix[1] = a.y; S.ix[2] = a.z; S.ix[3] = a.w; S.ix[4] = b.x; S.ix[5] = b.y; S.ix[6] = b.z; S.ix[7] = b.w;
+    S.vv[0] = v0.x; S.vv[1] = v0.y; S.vv[2] = v1.x; S.vv[3] = v1.y; S.vv[4] = v2.x; S.vv[5] = v2.y; S.vv[6] = v3.x; S.vv[7] = v3.y;
+    S.sn = sn; S.pix = ix; S.pvv = vv;
+}
+
+// value of the support at dimension d; hit = false when d is outside it
+__device__ __forceinline__ double sup_at(const Sup8 &S, i32 d, bool &hit)
+{
+    double cv = 0.0;
+    hit = false;
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (q < S.sn && S.ix[q] == d) { cv = S.vv[q]; hit = true; }
+    if (!hit && S.sn > 8 && d > S.ix[7])
+        for (int q = 8; q < S.sn; q++) {
+            const i32 t = S.pix[q];
+            if (t == d) { cv = S.pvv[q]; hit = true; break; }
+            if (t > d) break;
+        }
+    return cv;
+}
+
+// norm of the support (:288): ascending sum of squares
+__device__ __forceinline__ double sup_norm(const Sup8 &S)
+{
+    double s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (q < S.sn) s2 += S.vv[q] * S.vv[q];
+    for (int q = 8; q < S.sn; q++) { const double v = S.pvv[q]; s2 += v * v; }
+    return sqrt(s2);
+}
+
+// A row's entries: the first four in registers.
+struct Row4 {
+    int n;
+    i32 i[4];
+    double v[4];
+};
+
+__device__ __forceinline__ void row_load(Row4 &R, const FFRows &r, i64 row)
+{
+    R.n = r.nnz[row];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        R.i[e] = 0; R.v[e] = 0.0;
+        if (e < r.width) { R.i[e] = r.idx[(i64)e * r.stride + row]; R.v[e] = r.val[(i64)e * r.stride + row]; }
+    }
+}
+
+// cos numerator: dot of the row with a support, ascending dimension order (:238)
+__device__ __forceinline__ double row_dot(const Row4 &R, const FFRows &r, i64 row, const Sup8 &S)
+{
+    double dot = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+        if (e < R.n) { bool hit; const double cv = sup_at(S, R.i[e], hit); if (hit) dot += cv * R.v[e]; }
+    for (int e = 4; e < R.n; e++) {
+        bool hit;
+        const double cv = sup_at(S, r.idx[(i64)e * r.stride + row], hit);
+        if (hit) dot += cv * r.val[(i64)e * r.stride + row];
+    }
+    return dot;
+}
+
+// Sorted set of centre ids: the eight smallest in registers, the rest in a per-thread LDS column (ascending).
+struct OvSet {
+    i32 r[8];
+    int nx;               // entries in the LDS column
+    i32 *x;               // x[p * 256]
+    bool overflow;
+
+    __device__ __forceinline__ void init(i32 *col)
+    {
+#pragma unroll
+        for (int q = 0; q < 8; q++) r[q] = 0x7fffffff;
+        nx = 0; x = col; overflow = false;
+    }
+    __device__ __forceinline__ int size() const
+    {
+        int n = nx;
+#pragma unroll
+        for (int q = 0; q < 8; q++) n += r[q] != 0x7fffffff;
+        return n;
+    }
+    __device__ __forceinline__ void insert(i32 c)
+    {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {           // bubble c through the sorted registers; a duplicate vanishes
+            const i32 cur = r[q];
+            if (c == cur) c = 0x7fffffff;
+            const i32 lo = c < cur ? c : cur, hi = c < cur ? cur : c;
+            r[q] = lo; c = hi;
+        }
+        if (c == 0x7fffffff) return;
+        int p = 0;
+        while (p < nx && x[p * 256] < c) p++;
+        if (p < nx && x[p * 256] == c) return;
+        if (nx == FF_OC - 8) { overflow = true; return; }
+        for (int t = nx; t > p; t--) x[t * 256] = x[(t - 1) * 256];
+        x[p * 256] = c; nx++;
+    }
+    __device__ __forceinline__ i32 at(int p) const
+    {
+        if (p >= 8) return x[(p - 8) * 256];
+        i32 v = r[0];
+#pragma unroll
+        for (int q = 1; q < 8; q++) v = p == q ? r[q] : v;
+        return v;
+    }
+};
+
 // ---- A: speculate ---------------------------------------------------------------------------------
+// ff_decide for a lane per row: the overlap set lives in registers / LDS and supports are fetched with wide
+// loads, so that a row costs a handful of memory round trips instead of a hundred dependent ones.
 __global__ __launch_bounds__(256) void k_ff_speculate(FFState s, FFRows r, FFBatch b, i64 row0, int nb, double threshold)
 {
+    __shared__ i32 ovx[(FF_OC - 8) * 256];
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= nb) return;
     const int K = *s.K;
-    int nov;
-    double xn;
-    i32 *ov = b.ov_id + j;
-    const i64 ovs = FF_BMAX;
-    int dec = ff_decide(s, r, row0 + j, threshold, K, ov, ovs, nov, xn);
-    if (dec >= 0) {                                       // the joined centre must be in the list the walk reads
-        int p = 0;
-        while (p < nov && ov[p * ovs] < dec) p++;
-        if (!(p < nov && ov[p * ovs] == dec)) {
-            if (nov == FF_OC) dec = FF_BREAK;
-            else { for (int t = nov; t > p; t--) ov[t * ovs] = ov[(t - 1) * ovs]; ov[p * ovs] = dec; nov++; }
+    const i64 row = row0 + j;
+    Row4 R;
+    row_load(R, r, row);
+    const int n = R.n;
+    double x2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (e < n) x2 += R.v[e] * R.v[e];
+    for (int e = 4; e < n; e++) { const double v = r.val[(i64)e * r.stride + row]; x2 += v * v; }
+    const double xn = sqrt(x2);
+    OvSet ov;
+    ov.init(ovx + threadIdx.x);
+    int dec;
+    if (n == 0) dec = K == 0 ? FF_NEW : FF_BREAK;           // zero row: NaN argmax semantics, serial path
+    else {
+        bool brk = false;
+        for (int e = 0; e < n && !brk; e++) {
+            i32 d = R.i[0];
+            if (e == 1) d = R.i[1];
+            if (e == 2) d = R.i[2];
+            if (e == 3) d = R.i[3];
+            if (e > 3) d = r.idx[(i64)e * r.stride + row];
+            const int m = s.dc_n[d];
+            if (m > FF_DC) { brk = true; break; }
+            const i32 *dl = s.dc_list + (i64)d * FF_DC;
+            for (int q0 = 0; q0 < m; q0 += 4) {              // rows of dc_list are 256-byte aligned
+                const int4 c4 = *(const int4 *)(dl + q0);
+                ov.insert(c4.x);
+                if (q0 + 1 < m) ov.insert(c4.y);
+                if (q0 + 2 < m) ov.insert(c4.z);
+                if (q0 + 3 < m) ov.insert(c4.w);
+            }
+        }
+        if (brk || ov.overflow) dec = FF_BREAK;
+        else {
+            const int nov = ov.size();
+            Best best = best_empty();
+            for (int p = 0; p < nov; p++) {
+                const i32 c = ov.at(p);
+                Sup8 S;
+                sup_load(S, s.cs_idx + (i64)c * FF_CS, s.cs_val + (i64)c * FF_CS, s.cs_n[c]);
+                double dot = row_dot(R, r, row, S);
+                dot /= s.c_nrm[c];                            // :239
+                dot /= xn;                                    // :240
+                best = best_merge(best, best_of(dot, c));
+            }
+            if (nov < K) {                                    // every other centre scores exactly 0
+                i32 k0 = 0;
+                for (int p = 0; p < nov && ov.at(p) == k0; p++) k0++;
+                best = best_merge(best, best_of(0.0, k0));
+            }
+            dec = (best.i < 0 || best.v < threshold) ? FF_NEW : (int)best.i;   // :245-247 (NaN: false -> joins)
+            if (dec >= 0) {                                   // the joined centre must be in the list step C reads
+                ov.insert(dec);
+                if (ov.overflow) dec = FF_BREAK;
+            }
         }
     }
+    const int nov = ov.size();
+    for (int p = 0; p < nov; p++) OV(b, j, p) = ov.at(p);
     b.dec[j] = dec; b.ov_n[j] = nov; b.xn[j] = xn;
     if (dec >= 0) atomicAdd(&b.lcnt[dec], 1);
     if (dec < 0) atomicMin(b.first_new, j);
@@ -411,7 +585,9 @@ __global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFRows r, FFBatch 
     const int K = *s.K;
     const int m = b.ov_n[j];
     const i64 row = row0 + j;
-    const int n = r.nnz[row];
+    Row4 R;
+    row_load(R, r, row);
+    const int n = R.n;
     const double xn = b.xn[j];
     Best best = best_empty();
     for (int p = 0; p < m; p++) {
@@ -425,23 +601,16 @@ __global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFRows r, FFBatch 
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (jl[mid] < j) lo = mid + 1; else hi = mid; }
             if (lo > 0) pj = jl[lo - 1];
         }
-        const i32 *ix = pj < 0 ? s.cs_idx + (i64)cc * FF_CS : b.vs_idx + (i64)pj * FF_CS;
-        const double *vv = pj < 0 ? s.cs_val + (i64)cc * FF_CS : b.vs_val + (i64)pj * FF_CS;
-        const int sn = pj < 0 ? s.cs_n[cc] : b.vs_n[pj];
+        Sup8 S;
         double nrm;
-        if (pj < 0) nrm = s.c_nrm[cc];
-        else {                                                // :288, ascending sum
-            double s2 = 0.0;
-            for (int i = 0; i < sn; i++) s2 += vv[i] * vv[i];
-            nrm = sqrt(s2);
+        if (pj < 0) {
+            sup_load(S, s.cs_idx + (i64)cc * FF_CS, s.cs_val + (i64)cc * FF_CS, s.cs_n[cc]);
+            nrm = s.c_nrm[cc];
+        } else {
+            sup_load(S, b.vs_idx + (i64)pj * FF_CS, b.vs_val + (i64)pj * FF_CS, b.vs_n[pj]);
+            nrm = sup_norm(S);
         }
-        double dot = 0.0;
-        for (int e = 0; e < n; e++) {                         // ascending dimension order (:238)
-            const i32 d = r.idx[(i64)e * r.stride + row];
-            int lo = 0, hi = sn;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (ix[mid] < d) lo = mid + 1; else hi = mid; }
-            if (lo < sn && ix[lo] == d) dot += vv[lo] * r.val[(i64)e * r.stride + row];
-        }
+        double dot = row_dot(R, r, row, S);
         dot /= nrm;                                           // :239
         dot /= xn;                                            // :240
         best = best_merge(best, best_of(dot, cc));
