@@ -651,11 +651,12 @@ __global__ void k_ff_apply_growth(FFState s, FFBatch b)
         s.dc_list[(i64)dd * FF_DC + s.dc_n[dd]] = kk; s.dc_n[dd]++;
     }
     *b.log_n = 0;
+    *b.first_new = 0x7fffffff; *b.first_bad = 0x7fffffff;       // ready for the next batch
 }
 
 // ---- serial application of rows (founding rows, support growth, capacity breakers) -------------------
 // One thread, `count` rows in order, same arithmetic.  Stops (status) when a capacity is exceeded.
-__global__ void k_ff_serial(FFState s, FFRows r, i64 row0, int count, double threshold, i32 *scratch_ov, i32 *done)
+__global__ void k_ff_serial(FFState s, FFRows r, FFBatch b, i64 row0, int count, double threshold, i32 *scratch_ov)
 {
     if (threadIdx.x || blockIdx.x) return;
     int K = *s.K;
@@ -716,7 +717,9 @@ __global__ void k_ff_serial(FFState s, FFRows r, i64 row0, int count, double thr
         }
     }
     *s.K = K;
-    *done = processed;
+    // report (read back in one copy with the batch scalars) and reset the scalars for the next batch
+    b.first_new[4] = processed; b.first_new[5] = K;
+    *b.first_new = 0x7fffffff; *b.first_bad = 0x7fffffff; *b.log_n = 0;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------
@@ -727,7 +730,8 @@ struct FitFast {
     i64 D = 0, Kcap = 0;
     FFState st, sh;           // main + shadow (walk output)
     FFBatch bt;
-    i32 *d_scr = nullptr;     // [FF_OC + 8]: serial scratch, done counter
+    i32 *d_scr = nullptr;     // [FF_OC + 8]: serial scratch
+    i32 *h_ctl = nullptr;     // pinned: read-back of the batch scalars {first_new, first_bad, log_n, flags, done, K}
     void *blob = nullptr;
 };
 
@@ -742,6 +746,7 @@ void fitfast_free(sit_ctx *c)
     if (!c->fitfast) return;
     FitFast *f = (FitFast *)c->fitfast;
     if (f->blob) (void)hipFree(f->blob);
+    if (f->h_ctl) (void)hipHostFree(f->h_ctl);
     delete f;
     c->fitfast = nullptr;
 }
@@ -761,6 +766,7 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     size_t total = 2 * per_state + (size_t)D * (4 + FF_DC * 4) + 8192
                  + (size_t)FF_BMAX * (4 + 4 + 4 + FF_OC * 4 + 8 + 4 + 4 + FF_CS * 12) + (size_t)Kcap * 12 + 65536 + (size_t)FF_LOG * 12 + 4096;
     HIP_TRY(c, hipMalloc(&f->blob, total));
+    if (!f->h_ctl) HIP_TRY(c, hipHostMalloc((void **)&f->h_ctl, 64));
     HIP_TRY(c, hipMemsetAsync(f->blob, 0, total, c->stream));
     char *p = (char *)f->blob;
     FFState *ss[2] = {&f->st, &f->sh};
@@ -889,16 +895,23 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
     HIP_TRY(c, hipMemcpyAsync(&K, f->st.K, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const i32 big2[3] = {0x7fffffff, 0x7fffffff, 0};     // first_new, first_bad, log_n
-    auto serial = [&](int count) -> int {     // apply `count` rows one by one (exact), refresh K
-        k_ff_serial<<<dim3(1), dim3(64), 0, c->stream>>>(f->st, r, pos, count, threshold, f->d_scr, f->d_scr + 32);
-        HIP_TRY(c, hipGetLastError());
-        i32 done = 0, flag = 0;
-        HIP_TRY(c, hipMemcpyAsync(&done, f->d_scr + 32, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(&flag, f->st.flags, 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(&K, f->st.K, 4, hipMemcpyDeviceToHost, c->stream));
+    // the scalars are reset here once; afterwards by the kernel that ends each step (k_ff_apply_growth, k_ff_serial)
+    HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 12, hipMemcpyHostToDevice, c->stream));
+    volatile i32 *ctl = f->h_ctl;
+    auto readback = [&]() -> int {
+        HIP_TRY(c, hipMemcpyAsync(f->h_ctl, f->bt.first_new, 32, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return SIT_OK;
+    };
+    auto serial = [&](int count) -> int {     // apply `count` rows one by one (exact), refresh K
+        k_ff_serial<<<dim3(1), dim3(64), 0, c->stream>>>(f->st, r, f->bt, pos, count, threshold, f->d_scr);
+        HIP_TRY(c, hipGetLastError());
+        int rc = readback();
+        if (rc) return rc;
+        const i32 done = ctl[4];
+        K = ctl[5];
         pos += done; c->ff_serial_rows += done;
-        if (flag) f->valid = false;
+        if (ctl[3]) f->valid = false;
         return SIT_OK;
     };
     auto commit = [&]() {                     // the walked (shadow) state becomes the state
@@ -914,10 +927,9 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
             f->ready = false;
             if ((rc = ff_from_dense(c, f, cen.data(), cnt.data(), Kd, &fits))) return rc;
             if (!fits) { f->valid = false; break; }
+            HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 12, hipMemcpyHostToDevice, c->stream));
         }
         const int nb = (int)((nrows - pos) < B ? (nrows - pos) : B);
-        // first_new and first_bad are adjacent words
-        HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 12, hipMemcpyHostToDevice, c->stream));
         k_ff_speculate<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
         if (K > 0) {
             k_ff_list_offsets<<<dim3(1), dim3(256), 0, c->stream>>>(f->st, f->bt);
@@ -926,9 +938,8 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
             k_ff_verify<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
         }
         HIP_TRY(c, hipGetLastError());
-        i32 fb[4] = {0, 0, 0, 0};
-        HIP_TRY(c, hipMemcpyAsync(fb, f->bt.first_new, 16, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        { int rc = readback(); if (rc) return rc; }
+        const i32 fb[4] = {ctl[0], ctl[1], ctl[2], ctl[3]};
         if (fb[3]) { f->valid = false; break; }              // a capacity was exceeded: state is exact as of `pos`
         const int first_new = fb[0] < nb ? fb[0] : nb;       // rows [0, first_new) were walked
         const int first_bad = fb[1];
@@ -949,7 +960,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         c->ff_rewalks++;
         if (first_bad > 0) {
             // FF_BREAK / founding rows inside [0, first_bad) cannot exist (first_bad < first_new)
-            HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 12, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemsetAsync(f->bt.log_n, 0, 4, c->stream));      // the re-walk logs its growth afresh
             k_ff_walk<<<dim3((unsigned)K), dim3(256), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, first_bad);
             HIP_TRY(c, hipGetLastError());
             commit();
