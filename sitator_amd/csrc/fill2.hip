@@ -47,6 +47,23 @@ struct Fill2Args {
     double midpoint, steepness, rz, delta2, thr2_lo, thr2_hi, static_thr;
 };
 
+// What phase 1 needs, passed by value.  Everything else is read from the device copy of Fill2Args AFTER the
+// phase-1 barrier, through a constant-address-space pointer (scalar loads): the kernel has far more uniform
+// values than SGPRs, and keeping phase-2 constants live across phase 1 cost ~70 SGPR spills (v_readlane traffic
+// in the streaming loop).
+struct Fill2Head {
+    Pbc P;
+    const double *frames;
+    const i32 *static_idx, *mobile_idx;
+    const double *ref_static;
+    const double *frame_dmax;
+    u64 *err, *scal;
+    i64 F, A, frame0;
+    int S, M, fpb, dyn, debug_stop;
+    double delta2, thr2_lo, thr2_hi, static_thr;
+};
+typedef const Fill2Args __attribute__((address_space(4))) *Fill2ArgsPtr;
+
 template <int CELL>
 __device__ __forceinline__ void wrapc(const Pbc &P, double &x, double &y, double &z)
 {
@@ -211,11 +228,11 @@ __device__ __forceinline__ double eval_landmark(const Fill2Args &a, int k, const
 }
 
 template <int CELL>
-__global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Args a)
+__global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsPtr full)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int S = a.S, M = a.M;
-    const int fpb = a.fpb;
+    const int S = h.S, M = h.M;
+    const int fpb = h.fpb;
     double *sx = (double *)smem;
     double *sy = sx + fpb * S;
     double *sz = sy + fpb * S;
@@ -227,12 +244,12 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Args a)
     i32 *tk_all = (i32 *)(fmax + fpb);                          // [4][WTASK]
     unsigned short *surv_all = (unsigned short *)(tk_all + 4 * F2_WTASK);   // [4][WTASK]
     unsigned char *tion_all = (unsigned char *)(surv_all + 4 * F2_WTASK);   // [4][WTASK]
-    const Pbc &P = a.P;
+    const Pbc &P = h.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i64 f0 = (i64)blockIdx.x * fpb;
-    const int nf = (int)((a.F - f0) < fpb ? (a.F - f0) : fpb);
+    const int nf = (int)((h.F - f0) < fpb ? (h.F - f0) : fpb);
     const int SM = S + M;
-    const bool dyn = a.lattice_map != nullptr;
+    const bool dyn = h.dyn != 0;
     const u64 errw = (u64)(S + 1 + M);
 
     if (tid < fpb) fmax[tid] = 0ull;
@@ -241,8 +258,8 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Args a)
     for (int t = tid; t < nf * SM; t += F2_THREADS) {
         const int fl = t / SM;
         const int r = t - fl * SM;
-        const i64 atom = r < S ? a.static_idx[r] : a.mobile_idx[r - S];
-        const double *p = a.frames + ((f0 + fl) * a.A + atom) * 3;
+        const i64 atom = r < S ? h.static_idx[r] : h.mobile_idx[r - S];
+        const double *p = h.frames + ((f0 + fl) * h.A + atom) * 3;
         double x = p[0], y = p[1], z = p[2];
         wrapc<CELL>(P, x, y, z);
         if (r < S) {
@@ -250,15 +267,15 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Args a)
             if (!dyn) {
                 // PBCCalculator.distances(ref, atom) (util/PBCCalculator.pyx:64-103), squared; the sqrt is
                 // taken only inside the rounding band around static_movement_threshold^2
-                const double *rp = a.ref_static + 3 * r;
+                const double *rp = h.ref_static + 3 * r;
                 double qx = x + (P.cen[0] - rp[0]), qy = y + (P.cen[1] - rp[1]), qz = z + (P.cen[2] - rp[2]);
                 wrapc<CELL>(P, qx, qy, qz);
                 const double dx = -qx + P.cen[0], dy = -qy + P.cen[1], dz = -qz + P.cen[2];
                 const double d2 = (dx * dx + dy * dy) + dz * dz;
-                if (d2 > a.delta2) {
+                if (d2 > h.delta2) {
                     atomicOr(&fmax[fl], 1ull);
-                    if (d2 > a.thr2_lo && (d2 > a.thr2_hi || sqrt(d2) > a.static_thr))
-                        atomicMin(a.err, (u64)(a.frame0 + f0 + fl) * errw + (u64)r);
+                    if (d2 > h.thr2_lo && (d2 > h.thr2_hi || sqrt(d2) > h.static_thr))
+                        atomicMin(h.err, (u64)(h.frame0 + f0 + fl) * errw + (u64)r);
                 }
             }
         } else {
@@ -267,13 +284,27 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Args a)
     }
     __syncthreads();
     if (tid < nf) {
-        const bool tight = dyn ? (a.frame_dmax[f0 + tid] * a.frame_dmax[f0 + tid] <= a.delta2) : (fmax[tid] == 0ull);
+        const bool tight = dyn ? (h.frame_dmax[f0 + tid] * h.frame_dmax[f0 + tid] <= h.delta2) : (fmax[tid] == 0ull);
         fmax[tid] = tight ? 1ull : 0ull;
-        if (!tight) atomicAdd(&a.scal[2], 1ull);
+        if (!tight) atomicAdd(&h.scal[2], 1ull);
     }
     __syncthreads();
 
-    if (a.debug_stop == 1) return;
+    if (h.debug_stop == 1) return;
+    // phase-2 constants: scalar loads from the device copy of the arguments, issued after the barrier
+    Fill2Args a;
+    {
+        const Fill2Args __attribute__((address_space(4))) &g = *full;
+        a.P = h.P; a.frames = h.frames; a.static_idx = h.static_idx; a.mobile_idx = h.mobile_idx; a.ref_static = h.ref_static;
+        a.verts = g.verts; a.vcd = g.vcd; a.hi2 = g.hi2; a.t_off = g.t_off; a.t_list = g.t_list; a.l_off = g.l_off; a.l_list = g.l_list;
+        a.lattice_map = g.lattice_map; a.frame_dmax = h.frame_dmax; a.row_nnz = g.row_nnz; a.row_idx = g.row_idx; a.row_val = g.row_val;
+        a.err = h.err; a.scal = h.scal; a.F = h.F; a.A = h.A; a.N = g.N; a.frame0 = h.frame0;
+        a.S = S; a.M = M; a.D = g.D; a.V = g.V; a.W = g.W;
+        a.tG0 = g.tG0; a.tG1 = g.tG1; a.tG2 = g.tG2; a.lG0 = g.lG0; a.lG1 = g.lG1; a.lG2 = g.lG2;
+        a.fpb = fpb; a.check_zeros = g.check_zeros; a.debug_stop = h.debug_stop;
+        a.midpoint = g.midpoint; a.steepness = g.steepness; a.rz = g.rz; a.delta2 = h.delta2; a.thr2_lo = h.thr2_lo; a.thr2_hi = h.thr2_hi;
+        a.static_thr = h.static_thr;
+    }
     // ---- phase 2: every wave on its own; no workgroup barrier from here on ----
     double *tval = tval_all + wave * F2_WTASK;
     i32 *tk = tk_all + wave * F2_WTASK;
@@ -464,13 +495,21 @@ int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, 
     const size_t lds = fill2_lds_bytes(S, M, (int)fpb);
     SIT_REQUIRE(c, lds <= 158 * 1024, "sit_fill: one frame's atoms do not fit in LDS");
     const unsigned grid = (unsigned)((c->F + fpb - 1) / fpb);
+    Fill2Head h;
+    h.P = a.P; h.frames = a.frames; h.static_idx = a.static_idx; h.mobile_idx = a.mobile_idx; h.ref_static = a.ref_static;
+    h.frame_dmax = a.frame_dmax; h.err = a.err; h.scal = a.scal; h.F = a.F; h.A = a.A; h.frame0 = a.frame0;
+    h.S = a.S; h.M = a.M; h.fpb = a.fpb; h.dyn = a.lattice_map != nullptr; h.debug_stop = a.debug_stop;
+    h.delta2 = a.delta2; h.thr2_lo = a.thr2_lo; h.thr2_hi = a.thr2_hi; h.static_thr = a.static_thr;
+    if (!c->d_fill_args) { int rc = dev_alloc(c, &c->d_fill_args, (i64)sizeof(Fill2Args)); if (rc) return rc; }
+    HIP_TRY(c, hipMemcpyAsync(c->d_fill_args, &a, sizeof(Fill2Args), hipMemcpyHostToDevice, c->stream));
+    const Fill2ArgsPtr full = (Fill2ArgsPtr)c->d_fill_args;
     const bool diag = c->cell_diagonal;
     if (diag) {
         HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_fill2<1><<<dim3(grid), dim3(F2_THREADS), lds, c->stream>>>(a);
+        k_fill2<1><<<dim3(grid), dim3(F2_THREADS), lds, c->stream>>>(h, full);
     } else {
         HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_fill2<0><<<dim3(grid), dim3(F2_THREADS), lds, c->stream>>>(a);
+        k_fill2<0><<<dim3(grid), dim3(F2_THREADS), lds, c->stream>>>(h, full);
     }
     HIP_TRY(c, hipGetLastError());
     return SIT_OK;
