@@ -249,15 +249,8 @@ extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const 
     if ((rc = dev_upload(c, &c->d_verts, v32.data(), D * Vp))) return rc;
     if ((rc = dev_upload(c, &c->d_vcd, vcdp.data(), D * Vp))) return rc;
     if ((rc = dev_upload(c, &c->d_hi2, hi2.data(), D * Vp))) return rc;
-    CandidateTable tab;
-    if ((rc = sit_build_candidates(c, ref_static, verts, vcd, static_thr, 1.0, tab))) return rc;
-    if ((rc = dev_upload(c, &c->d_bin_off, tab.off.data(), (i64)tab.off.size()))) return rc;
-    if ((rc = dev_upload(c, &c->d_bin_list, tab.list.data(), (i64)tab.list.size()))) return rc;
-    for (int i = 0; i < 3; i++) c->G[i] = tab.G[i];
-    c->W = tab.W; c->mean_candidates = tab.mean;
-    c->h_ref_static.assign(ref_static, ref_static + 3 * S);
-    c->h_verts.assign(verts, verts + D * V);
-    c->h_vcd.assign(vcd, vcd + D * V);
+    // loose table: valid for any frame the static-lattice check accepts (displacement <= static_thr), 1 A bins
+    if ((rc = sit_build_candidates(c, static_thr, 1.0, &c->d_bin_off, &c->d_bin_list, c->G, &c->W, &c->mean_candidates))) return rc;
     c->cell_diagonal = true;
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)

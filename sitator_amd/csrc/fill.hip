@@ -4,7 +4,7 @@
 // v1 layout: one workgroup handles `fpb` consecutive frames.  Phase 1 streams the frames'
 // atoms from HBM, wraps them and parks statics + mobiles in LDS (SoA), running the
 // static-lattice check on the way.  Phase 2 gives every (frame, ion) to one lane, which walks
-// the candidate landmarks of the ion's bin (candidates.cpp) in ascending order and evaluates
+// the candidate landmarks of the ion's bin (candidates.hip) in ascending order and evaluates
 // them with the reference's arithmetic, vertex by vertex with the reference's early exit.
 // Rows go to HBM slot-major (idx[e*N+row]) so that the stores of a wave coalesce.
 #include <cmath>
@@ -263,15 +263,11 @@ static int ensure_tight_table(sit_ctx *c)
     for (double d : sample) if (d == d && d <= c->static_thr && d > mx) mx = d;
     double delta = mx * 1.15 + 0.02;
     if (delta > c->static_thr) delta = c->static_thr;
-    CandidateTable tab;
-    if ((rc = sit_build_candidates(c, c->h_ref_static.data(), c->h_verts.data(), c->h_vcd.data(), delta, 0.5, tab))) return rc;
-    if (tab.W > 128) {       // F2_WTASK: an ion's tasks must fit one wave batch -> loose table for everything
+    if ((rc = sit_build_candidates(c, delta, 0.5, &c->d_tbin_off, &c->d_tbin_list, c->tG, &c->W_tight, &c->tight_mean_candidates))) return rc;
+    if (c->W_tight > 128) {  // F2_WTASK: an ion's tasks must fit one wave batch -> loose table for everything
         delta = -1.0;
     }
-    if ((rc = dev_upload(c, &c->d_tbin_off, tab.off.data(), (i64)tab.off.size()))) return rc;
-    if ((rc = dev_upload(c, &c->d_tbin_list, tab.list.data(), (i64)tab.list.size()))) return rc;
-    for (int i = 0; i < 3; i++) c->tG[i] = tab.G[i];
-    c->W_tight = tab.W; c->tight_mean_candidates = tab.mean; c->tight_delta = delta;
+    c->tight_delta = delta;
     c->tight_valid = true;
     return SIT_OK;
 }

@@ -56,8 +56,6 @@ struct sit_ctx {
     bool tight_valid = false;
     bool cell_diagonal = false;
     int fill_kernel = 2;              // SITATOR_FILL_KERNEL=1 selects the first-generation kernel
-    std::vector<double> h_ref_static, h_vcd;
-    std::vector<i64> h_verts;
     i64 fallback_frames = 0;
     int last_fpb = 0;
     double *d_frame_dmax = nullptr;   // [F] per-frame displacement maximum (dynamic mapping)
@@ -228,13 +226,8 @@ int fitfast_set_state(sit_ctx *c, const double *cen, const i64 *cnt, i64 K);
 int fitfast_to_dense(sit_ctx *c, std::vector<double> &cen, std::vector<i64> &cnt, i64 *Kout);
 int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val, const i64 *weights, i64 stride,
                    int width, i64 nrows, double threshold, i64 *consumed);
-struct CandidateTable {
-    int G[3];
-    i64 W;
-    double mean;
-    std::vector<i32> off, list;
-};
-int sit_build_candidates(sit_ctx *c, const double *ref_static, const i64 *verts, const double *vcd,
-                         double displacement, double bin_target, CandidateTable &out);
+// pruning table for static displacements up to `displacement`, built and kept on the device (candidates.hip)
+int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32 **d_off, i32 **d_list, int G_out[3],
+                         i64 *W, double *mean);
 int fill2_sample_dmax(sit_ctx *c, std::vector<double> &out);
 int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, double threshold);
