@@ -23,6 +23,9 @@
 #define F2_THREADS 256
 #define F2_IW 32           // ions per wave chunk
 #define F2_WTASK 128       // tasks per wave batch
+#ifndef F2_LL
+#define F2_LL 2            // log2 of the lanes a surviving task's evaluation is spread over
+#endif
 
 struct Fill2Args {
     Pbc P;
@@ -227,7 +230,119 @@ __device__ __forceinline__ double eval_landmark(const Fill2Args &a, int k, const
     return nth_root(acc, nv);
 }
 
-template <int CELL>
+
+// ---- evaluation with a task's vertices spread over adjacent lanes ------------------------------------------
+// A lane-per-task pass runs all G = 2^LG (padded) vertices in every lane, and a second pass for a handful of
+// left-over survivors costs as much as a full one (at C2 a 32-ion chunk has 63 +- 8 survivors: half the chunks
+// need that second pass).  Here a task occupies L = 2^LL adjacent lanes with R = G / L vertices each, so a pass
+// costs R/G of a full one and the tail wastes little.  The logistic factors are multiplied in vertex order by
+// handing the partial product from lane to lane (bit-identical to the sequential loop).
+template <int LG, int LL>
+struct VpItem {
+    int t, ii;
+    i32 v[1 << (LG - LL)];
+    double c[1 << (LG - LL)];
+};
+
+template <int LG, int LL>
+__device__ __forceinline__ void vp_fetch(VpItem<LG, LL> &it, int i, int items, const i32 *tk, const unsigned char *tion,
+                                         const unsigned short *surv, const i32 *verts, const double *tab)
+{
+    constexpr int R = 1 << (LG - LL);
+    it.t = 0; it.ii = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) { it.v[r] = -1; it.c[r] = 1.0; }
+    if (i < items) {
+        const int q = i >> LL, sub = i & ((1 << LL) - 1);
+        it.t = surv[q];
+        const int k = tk[it.t];
+        it.ii = tion[it.t];
+        const i32 *vp = verts + (k << LG) + sub * R;
+        const double *cp = tab + (k << LG) + sub * R;
+        if (R == 1) { it.v[0] = vp[0]; it.c[0] = cp[0]; }
+        else if (R == 2) {
+            const int2 v2 = *(const int2 *)vp; const double2 c2 = *(const double2 *)cp;
+            it.v[0] = v2.x; it.v[R > 1 ? 1 : 0] = v2.y; it.c[0] = c2.x; it.c[R > 1 ? 1 : 0] = c2.y;
+        } else {
+#pragma unroll
+            for (int r0 = 0; r0 < R; r0 += 4) {
+                const int4 v4 = *(const int4 *)(vp + r0);
+                const double2 ca = *(const double2 *)(cp + r0), cb = *(const double2 *)(cp + r0 + 2);
+                it.v[r0] = v4.x; it.v[(r0 + 1) % R] = v4.y; it.v[(r0 + 2) % R] = v4.z; it.v[(r0 + 3) % R] = v4.w;
+                it.c[r0] = ca.x; it.c[(r0 + 1) % R] = ca.y; it.c[(r0 + 2) % R] = cb.x; it.c[(r0 + 3) % R] = cb.y;
+            }
+        }
+    }
+}
+
+// landmark/helpers.pyx:186-212 for the survivors listed in surv[]
+template <int CELL, int LG, int LL>
+__device__ __forceinline__ void eval_vp(const Fill2Args &a, int nsurv, const i32 *tk, const unsigned char *tion,
+                                        const unsigned short *surv, double *tval, unsigned char *tnv, const double *sx,
+                                        const double *sy, const double *sz, i64 f0, bool dyn, double ox, double oy,
+                                        double oz, int fl, int lane)
+{
+    constexpr int L = 1 << LL, R = 1 << (LG - LL);
+    const int items = nsurv << LL;
+    const int sub = lane & (L - 1), base = lane & ~(L - 1);
+    const unsigned long long gmask = ((1ull << L) - 1ull) << base;
+    VpItem<LG, LL> cur, nxt;
+    vp_fetch<LG, LL>(cur, lane, items, tk, tion, surv, a.verts, a.vcd);
+    for (int i0 = 0; i0 < items; i0 += 64) {
+        vp_fetch<LG, LL>(nxt, i0 + 64 + lane, items, tk, tion, surv, a.verts, a.vcd);
+        const bool live = i0 + lane < items;
+        const double tox = __shfl(ox, cur.ii), toy = __shfl(oy, cur.ii), toz = __shfl(oz, cur.ii);
+        const int tfl = __shfl(fl, cur.ii);
+        double ci[R];
+        bool zero = false;
+        int mine = 0;                                       // my valid vertices (a prefix of the padded row)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            ci[r] = 1.0;
+            if (cur.v[r] >= 0) {
+                mine++;
+                i32 v = cur.v[r];
+                if (dyn) v = a.lattice_map[(f0 + tfl) * a.S + v];
+                const double dist = sqrt(dist2_to<CELL>(a.P, sx + tfl * a.S, sy + tfl * a.S, sz + tfl * a.S, v, tox, toy, toz));
+                const double tt = dist / cur.c[r];
+                if (tt > a.rz) zero = true;
+                else ci[r] = 1.0 / (1.0 + exp(a.steepness * (tt - a.midpoint)));
+            }
+        }
+        const unsigned long long zm = __ballot(zero);
+        // acc *= ci in vertex order (:205): the partial product travels from lane to lane
+        double acc = 1.0;
+        int nv = mine;
+#pragma unroll
+        for (int sp = 0; sp < L; sp++) {
+            if (sp > 0) {
+                const double in = __shfl(acc, base + sp - 1);
+                const int nin = __shfl(nv, base + sp - 1);
+                if (sub == sp) { acc = in; nv = nin + mine; }
+            }
+            if (sub == sp) {
+#pragma unroll
+                for (int r = 0; r < R; r++) if (r < mine) acc *= ci[r];
+            }
+        }
+        if (live && sub == L - 1) {
+            tval[cur.t] = (zm & gmask) ? 0.0 : acc;
+            tnv[cur.t] = (unsigned char)nv;
+        }
+        cur = nxt;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int q0 = 0; q0 < nsurv; q0 += 64) {              // pow(acc, 1 / n_vertices) (:212)
+        const int q = q0 + lane;
+        if (q < nsurv) {
+            const int t = surv[q];
+            const double acc = tval[t];
+            if (acc != 0.0) tval[t] = nth_root(acc, tnv[t]);
+        }
+    }
+}
+
+template <int CELL, int LG>      // LG: log2 of the padded vertices per landmark for the vertex-parallel passes (0: generic)
 __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsPtr full)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -244,6 +359,7 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
     i32 *tk_all = (i32 *)(fmax + fpb);                          // [4][WTASK]
     unsigned short *surv_all = (unsigned short *)(tk_all + 4 * F2_WTASK);   // [4][WTASK]
     unsigned char *tion_all = (unsigned char *)(surv_all + 4 * F2_WTASK);   // [4][WTASK]
+    unsigned char *tnv_all = tion_all + 4 * F2_WTASK;                       // [4][WTASK] vertices per task
     const Pbc &P = h.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i64 f0 = (i64)blockIdx.x * fpb;
@@ -310,6 +426,7 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
     i32 *tk = tk_all + wave * F2_WTASK;
     unsigned short *surv = surv_all + wave * F2_WTASK;
     unsigned char *tion = tion_all + wave * F2_WTASK;
+    unsigned char *tnv = tnv_all + wave * F2_WTASK;
     const bool store = a.row_val != nullptr;
     const int nions = nf * M;
     for (int ic0 = wave * F2_IW; ic0 < nions; ic0 += 4 * F2_IW) {
@@ -358,33 +475,43 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
             if (a.debug_stop == 3) { ion_s = ion_e; nnz = 1; continue; }
             // 2e-1: screen every (ion, landmark) task; survivors are compacted by ballot
             int nsurv = 0;
-            for (int t0 = 0; t0 < ntasks; t0 += 64) {
-                const int t = t0 + lane;
-                const int ii = t < ntasks ? tion[t] : 0;
-                const double tox = __shfl(ox, ii), toy = __shfl(oy, ii), toz = __shfl(oz, ii);
-                const int tfl = __shfl(fl, ii);
-                bool alive = false;
-                if (t < ntasks) {
-                    const i32 *lmap = dyn ? a.lattice_map + (f0 + tfl) * S : nullptr;
-                    alive = !screen_landmark<CELL>(a, tk[t], sx + tfl * S, sy + tfl * S, sz + tfl * S, lmap, tox, toy, toz);
-                    if (!alive || a.debug_stop == 4) tval[t] = 0.0;
+            {
+                for (int t0 = 0; t0 < ntasks; t0 += 64) {
+                    const int t = t0 + lane;
+                    const int ii = t < ntasks ? tion[t] : 0;
+                    const double tox = __shfl(ox, ii), toy = __shfl(oy, ii), toz = __shfl(oz, ii);
+                    const int tfl = __shfl(fl, ii);
+                    bool alive = false;
+                    if (t < ntasks) {
+                        const i32 *lmap = dyn ? a.lattice_map + (f0 + tfl) * S : nullptr;
+                        alive = !screen_landmark<CELL>(a, tk[t], sx + tfl * S, sy + tfl * S, sz + tfl * S, lmap, tox, toy, toz);
+                        if (!alive) tval[t] = 0.0;
+                    }
+                    const unsigned long long m = __ballot(alive);
+                    if (alive) surv[nsurv + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)t;
+                    nsurv += __popcll(m);
                 }
-                const unsigned long long m = __ballot(alive);
-                if (alive) surv[nsurv + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)t;
-                nsurv += __popcll(m);
             }
             __builtin_amdgcn_wave_barrier();
-            if (a.debug_stop == 4) { ion_s = ion_e; nnz = 1; continue; }
-            // 2e-2: full evaluation of the survivors, one lane each
-            for (int q0 = 0; q0 < nsurv; q0 += 64) {
-                const int q = q0 + lane;
-                const int t = q < nsurv ? surv[q] : 0;
-                const int ii = q < nsurv ? tion[t] : 0;
-                const double tox = __shfl(ox, ii), toy = __shfl(oy, ii), toz = __shfl(oz, ii);
-                const int tfl = __shfl(fl, ii);
-                if (q < nsurv) {
-                    const i32 *lmap = dyn ? a.lattice_map + (f0 + tfl) * S : nullptr;
-                    tval[t] = eval_landmark<CELL>(a, tk[t], sx + tfl * S, sy + tfl * S, sz + tfl * S, lmap, tox, toy, toz);
+            if (a.debug_stop == 4) {
+                for (int t = lane; t < ntasks; t += 64) tval[t] = 0.0;
+                __builtin_amdgcn_wave_barrier();
+                ion_s = ion_e; nnz = 1; continue;
+            }
+            // 2e-2: full evaluation of the survivors
+            if constexpr (LG != 0) {
+                eval_vp<CELL, LG, (F2_LL < LG ? F2_LL : LG)>(a, nsurv, tk, tion, surv, tval, tnv, sx, sy, sz, f0, dyn, ox, oy, oz, fl, lane);
+            } else {
+                for (int q0 = 0; q0 < nsurv; q0 += 64) {
+                    const int q = q0 + lane;
+                    const int t = q < nsurv ? surv[q] : 0;
+                    const int ii = q < nsurv ? tion[t] : 0;
+                    const double tox = __shfl(ox, ii), toy = __shfl(oy, ii), toz = __shfl(oz, ii);
+                    const int tfl = __shfl(fl, ii);
+                    if (q < nsurv) {
+                        const i32 *lmap = dyn ? a.lattice_map + (f0 + tfl) * S : nullptr;
+                        tval[t] = eval_landmark<CELL>(a, tk[t], sx + tfl * S, sy + tfl * S, sz + tfl * S, lmap, tox, toy, toz);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -463,6 +590,7 @@ size_t fill2_lds_bytes(i64 S, i64 M, int fpb)
     b += (size_t)4 * F2_WTASK * 4;      // tk
     b += (size_t)4 * F2_WTASK * 2;      // surv
     b += (size_t)4 * F2_WTASK;          // tion
+    b += (size_t)4 * F2_WTASK;          // tnv
     return (b + 31) & ~(size_t)15;
 }
 
@@ -504,13 +632,15 @@ int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, 
     HIP_TRY(c, hipMemcpyAsync(c->d_fill_args, &a, sizeof(Fill2Args), hipMemcpyHostToDevice, c->stream));
     const Fill2ArgsPtr full = (Fill2ArgsPtr)c->d_fill_args;
     const bool diag = c->cell_diagonal;
-    if (diag) {
-        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_fill2<1><<<dim3(grid), dim3(F2_THREADS), lds, c->stream>>>(h, full);
-    } else {
-        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_fill2<0><<<dim3(grid), dim3(F2_THREADS), lds, c->stream>>>(h, full);
-    }
+    const int lg = c->Vp == 8 ? 3 : (c->Vp == 4 ? 2 : 0);
+#define F2_LAUNCH(CELL, LGV)                                                                                               \
+    do {                                                                                                               \
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill2<CELL, LGV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        k_fill2<CELL, LGV><<<dim3(grid), dim3(F2_THREADS), lds, c->stream>>>(h, full);                                  \
+    } while (0)
+    if (diag) { if (lg == 3) F2_LAUNCH(1, 3); else if (lg == 2) F2_LAUNCH(1, 2); else F2_LAUNCH(1, 0); }
+    else { if (lg == 3) F2_LAUNCH(0, 3); else if (lg == 2) F2_LAUNCH(0, 2); else F2_LAUNCH(0, 0); }
+#undef F2_LAUNCH
     HIP_TRY(c, hipGetLastError());
     return SIT_OK;
 }

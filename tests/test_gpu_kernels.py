@@ -180,3 +180,33 @@ def _ctx_from(host, frames, sm, mm, ref):
     ctx.set_frames(frames, np.where(sm)[0], np.where(mm)[0])
     assert ctx.fill()[0] == 0
     return ctx
+
+
+def test_wide_landmarks_take_the_generic_passes(oracle):
+    """Landmarks with 12 vertices (two face-sharing cubes merged): rows are not 4 or 8 wide, so the fill kernel
+    runs its lane-per-task screening / evaluation instead of the vertex-parallel passes.  Same rows as the oracle."""
+    from sitator_amd import _lib, synth
+    host = synth.config_host("C1")
+    frames, sm, mm, ref = synth.make_trajectory(host, 4, 60, seed=12)
+    ref_static = ref[sm]
+    base = [list(v) for v in host.vertices]
+    verts12, centers = [], []
+    for k in range(len(base) - 1):
+        u = sorted(set(base[k]) | set(base[k + 1]))
+        if len(u) == 12:
+            verts12.append(u)
+            centers.append(0.5 * (host.centers[k] + host.centers[k + 1]))
+    assert len(verts12) >= 8
+    verts = np.array(verts12, dtype=np.int64)
+    ctx = _lib.HipContext(host.cell)
+    vcd = np.array([ctx.distances(c, ref_static[v]) for c, v in zip(centers, verts)])
+    ctx.set_basis(ref_static, verts, vcd, 1.5, 30, 1.0)
+    ctx.set_frames(frames, np.where(sm)[0], np.where(mm)[0])
+    rc, nz, err = ctx.fill(check_for_zeros=False)
+    assert rc == 0
+    wrapped = oracle.wrap_points(host.cell, frames)
+    exp, _ = oracle.fill(host.cell, wrapped, np.where(sm)[0], np.where(mm)[0], ref_static, verts, vcd,
+                         check_for_zeros=False)
+    got = ctx.rows_dense()
+    assert np.array_equal(got != 0, exp != 0) and (exp != 0).any()
+    np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
