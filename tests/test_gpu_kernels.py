@@ -210,3 +210,44 @@ def test_wide_landmarks_take_the_generic_passes(oracle):
     got = ctx.rows_dense()
     assert np.array_equal(got != 0, exp != 0) and (exp != 0).any()
     np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_geometry_rows_match_oracle(oracle, seed):
+    """Fuzz: random triclinic cells (some smaller than the cut-off, so periodic images matter), random ragged
+    landmark definitions (1-9 vertices, repeated statics allowed), mobile atoms anywhere (also outside the cell)."""
+    from sitator_amd import _lib
+    rng = np.random.default_rng(1000 + seed)
+    L = rng.uniform(5.0, 14.0, size=3) if seed % 3 else rng.uniform(3.0, 5.0, size=3)
+    cell = np.diag(L)
+    if seed % 2:
+        cell[1, 0] = rng.uniform(-0.3, 0.3) * L[0]
+        cell[2, 0] = rng.uniform(-0.3, 0.3) * L[0]
+        cell[2, 1] = rng.uniform(-0.3, 0.3) * L[1]
+    S, M, F = int(rng.integers(6, 40)), int(rng.integers(1, 9)), 25
+    D = int(rng.integers(3, 30))
+    Vmax = [1, 3, 4, 6, 8, 9][seed % 6]
+    ref_static = rng.uniform(0, 1, size=(S, 3)) @ cell
+    verts = np.full((D, Vmax), -1, dtype=np.int64)
+    for k in range(D):
+        nv = int(rng.integers(1, Vmax + 1))
+        verts[k, :nv] = rng.choice(S, size=nv, replace=nv > S)
+    ctx = _lib.HipContext(cell)
+    centers = np.array([oracle.average(cell, ref_static[verts[k][verts[k] >= 0]]) for k in range(D)])
+    vcd = ctx.site_vertex_distances(centers, ref_static, verts)
+    vcd = np.where(verts >= 0, np.maximum(vcd, 0.3), vcd)         # no zero distances (division)
+    A = S + M
+    frames = np.empty((F, A, 3))
+    frames[:, :S] = ref_static + rng.normal(scale=0.08, size=(F, S, 3))
+    frames[:, S:] = (rng.uniform(-0.5, 1.5, size=(F, M, 3)) @ cell)
+    static_idx, mobile_idx = np.arange(S), S + np.arange(M)
+    ctx.set_basis(ref_static, verts, vcd, 1.5, 30, 1.0)
+    ctx.set_frames(frames, static_idx, mobile_idx)
+    rc, nz, err = ctx.fill(check_for_zeros=False)
+    assert rc == 0
+    exp, nz_exp = oracle.fill(cell, oracle.wrap_points(cell, frames), static_idx, mobile_idx, ref_static, verts, vcd,
+                              check_for_zeros=False)
+    got = ctx.rows_dense()
+    assert nz == nz_exp
+    assert np.array_equal(got != 0, exp != 0)
+    np.testing.assert_allclose(got, exp, rtol=1e-11, atol=0)
