@@ -49,11 +49,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = os.environ.get("SITATOR_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path on a 1-GPU box
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        ndev = torch.cuda.device_count()
+        if backend == "nccl":
+            if local >= ndev:
+                raise RuntimeError("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local, ndev))
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            local = local % max(ndev, 1)
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend)
     from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth, _lib
 
     host = synth.config_host(args.config)
@@ -128,7 +137,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -192,7 +201,7 @@ def main():
         }
         if ab is not None:
             out["ab_kernels"] = ab
-        if args.cpu_frames > 0:
+        if args.cpu_frames > 0 and world == 1:          # a reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(host, gen, frames[:min(F, args.cpu_frames)], ref, fit_ctx_centers, M)
         print(json.dumps(out))
     if dist is not None:
