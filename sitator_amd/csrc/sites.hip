@@ -54,35 +54,62 @@ __global__ void k_site_anchor_pts(Pbc P, const double *frames, const i32 *mobile
     pts[3 * k] = x; pts[3 * k + 1] = y; pts[3 * k + 2] = z;
 }
 
-// Pass 2: per site (sum w, sum w*q) with q = wrap(p + (centroid - anchor)) (:127-134).
-// Workgroup-private partial sums in LDS (ds_add_f64), then one global atomic per site and block.
+// Pass 2: per site (sum w, sum w*q) with q = wrap(p + (centroid - anchor)) (:127-134), in a FIXED summation
+// order (run-to-run reproducible, no floating-point atomics): a workgroup owns a contiguous row range; rows are
+// staged 256 at a time in LDS and thread t then adds, in row order, the staged rows of the sites it owns
+// (site % 256 == t) into its LDS accumulators; the per-workgroup partials are summed in workgroup order by
+// k_site_sums_final.
 __global__ __launch_bounds__(256) void k_site_sums(Pbc P, const double *frames, const i32 *mobile_idx, i64 A,
                                                    i64 M, const i64 *labels, const double *confs, i64 N, i64 K,
-                                                   int weighted, const double *anchors, double *sums,
+                                                   int weighted, const double *anchors, double *partials,
                                                    i64 rows_per_block)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *part = (double *)smem;     // [K,4]
-    for (i64 q = threadIdx.x; q < K * 4; q += blockDim.x) part[q] = 0.0;
-    __syncthreads();
+    double *part = (double *)smem;                 // [K,4]
+    double *stage = part + 4 * K;                  // [256,4]
+    int *slab = (int *)(stage + 4 * 256);          // [256]
+    const int t = threadIdx.x;
+    for (i64 q = t; q < K * 4; q += 256) part[q] = 0.0;
     const i64 r0 = (i64)blockIdx.x * rows_per_block;
     const i64 r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
-    for (i64 row = r0 + threadIdx.x; row < r1; row += blockDim.x) {
-        const i64 l = labels[row];
-        if (l < 0 || l >= K) continue;
-        const double w = weighted ? confs[row] : 1.0;
-        double x, y, z;
-        ion_position(P, frames, mobile_idx, A, M, row, x, y, z);
-        x += (P.cen[0] - anchors[3 * l]); y += (P.cen[1] - anchors[3 * l + 1]); z += (P.cen[2] - anchors[3 * l + 2]);
-        wrap3(P, x, y, z);
-        unsafeAtomicAdd(&part[4 * l + 0], w);
-        unsafeAtomicAdd(&part[4 * l + 1], w * x);
-        unsafeAtomicAdd(&part[4 * l + 2], w * y);
-        unsafeAtomicAdd(&part[4 * l + 3], w * z);
+    for (i64 base = r0; base < r1; base += 256) {
+        __syncthreads();
+        const i64 row = base + t;
+        int l = -1;
+        double w = 0.0, x = 0.0, y = 0.0, z = 0.0;
+        if (row < r1) {
+            const i64 lab = labels[row];
+            if (lab >= 0 && lab < K) {
+                l = (int)lab;
+                w = weighted ? confs[row] : 1.0;
+                ion_position(P, frames, mobile_idx, A, M, row, x, y, z);
+                x += (P.cen[0] - anchors[3 * l]); y += (P.cen[1] - anchors[3 * l + 1]); z += (P.cen[2] - anchors[3 * l + 2]);
+                wrap3(P, x, y, z);
+            }
+        }
+        slab[t] = l;
+        stage[4 * t] = w; stage[4 * t + 1] = w * x; stage[4 * t + 2] = w * y; stage[4 * t + 3] = w * z;
+        __syncthreads();
+        for (int i = 0; i < 256; i++) {
+            const int li = slab[i];
+            if (li >= 0 && (li & 255) == t) {
+                part[4 * li] += stage[4 * i]; part[4 * li + 1] += stage[4 * i + 1];
+                part[4 * li + 2] += stage[4 * i + 2]; part[4 * li + 3] += stage[4 * i + 3];
+            }
+        }
     }
     __syncthreads();
-    for (i64 q = threadIdx.x; q < K * 4; q += blockDim.x)
-        if (part[q] != 0.0) unsafeAtomicAdd(&sums[q], part[q]);
+    double *out = partials + (i64)blockIdx.x * K * 4;
+    for (i64 q = t; q < K * 4; q += 256) out[q] = part[q];
+}
+
+__global__ __launch_bounds__(256) void k_site_sums_final(const double *partials, i64 nblocks, i64 K4, double *sums)
+{
+    const i64 q = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (q >= K4) return;
+    double acc = 0.0;
+    for (i64 b = 0; b < nblocks; b++) acc += partials[b * K4 + q];
+    sums[q] = acc;
 }
 
 extern "C" int sit_site_anchors(sit_ctx *c, int weighted, i64 K, double *wmax, i64 *first_row, double *anchor_pts)
@@ -120,20 +147,25 @@ extern "C" int sit_site_sums(sit_ctx *c, int weighted, i64 K, const double *anch
 {
     if (!c || !anchor_pts || !sums) return SIT_ERR_INVALID;
     SIT_REQUIRE(c, c->assign_valid && c->d_frames && K > 0, "sit_site_sums: assignments and frames needed");
-    SIT_REQUIRE(c, K * 32 <= 150 * 1024, "sit_site_sums: too many sites for the LDS-private partial sums");
+    SIT_REQUIRE(c, K * 32 + 256 * 36 <= 150 * 1024, "sit_site_sums: too many sites for the LDS-private partial sums");
     HIP_TRY(c, hipSetDevice(c->device));
-    int rc = ensure_scratch(c, K * (24 + 32));
+    // at most 1024 workgroups, each a contiguous row range (a multiple of 256 rows)
+    i64 rpb = (c->N + 1023) / 1024;
+    rpb = (rpb + 255) / 256 * 256;
+    if (rpb < 4096) rpb = 4096;
+    const i64 nblocks = c->N > 0 ? (c->N + rpb - 1) / rpb : 0;
+    int rc = ensure_scratch(c, K * (24 + 32) + nblocks * K * 32);
     if (rc) return rc;
-    double *da = (double *)c->d_scratch, *ds = da + 3 * K;
+    double *da = (double *)c->d_scratch, *ds = da + 3 * K, *dp = ds + 4 * K;
     HIP_TRY(c, hipMemcpyAsync(da, anchor_pts, (size_t)K * 24, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(ds, 0, (size_t)K * 32, c->stream));
     StageTimer t(c, T_CENTERS);
     if (c->N > 0) {
-        const i64 rpb = 4096;
-        const size_t lds = (size_t)K * 32;
+        const size_t lds = (size_t)K * 32 + 256 * 36;
         HIP_TRY(c, hipFuncSetAttribute((const void *)k_site_sums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_site_sums<<<dim3((unsigned)((c->N + rpb - 1) / rpb)), dim3(256), lds, c->stream>>>(
-            c->pbc, c->d_frames, c->d_mobile_idx, c->A, c->M, c->d_labels, c->d_confs, c->N, K, weighted, da, ds, rpb);
+        k_site_sums<<<dim3((unsigned)nblocks), dim3(256), lds, c->stream>>>(
+            c->pbc, c->d_frames, c->d_mobile_idx, c->A, c->M, c->d_labels, c->d_confs, c->N, K, weighted, da, dp, rpb);
+        k_site_sums_final<<<dim3((unsigned)((K * 4 + 255) / 256)), dim3(256), 0, c->stream>>>(dp, nblocks, K * 4, ds);
         HIP_TRY(c, hipGetLastError());
     }
     t.stop();

@@ -251,3 +251,21 @@ def test_random_geometry_rows_match_oracle(oracle, seed):
     assert nz == nz_exp
     assert np.array_equal(got != 0, exp != 0)
     np.testing.assert_allclose(got, exp, rtol=1e-11, atol=0)
+
+
+def test_site_centres_are_reproducible_bit_for_bit():
+    """Site-centre sums use a fixed summation order (no floating-point atomics): two runs give identical bits."""
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth
+    host = synth.config_host("C2")
+    gen = synth.TrajectoryGenerator(host, 64, seed=9)
+    ref = gen.reference_positions()
+    frames = gen.generate(3000)
+    out = []
+    for _ in range(2):
+        sn = SiteNetwork(Structure(ref, host.cell), gen.static_mask, gen.mobile_mask)
+        sn.centers = host.centers
+        sn.vertices = host.vertices
+        st = LandmarkAnalysis(verbose=False).run(sn, frames)
+        out.append((np.asarray(st.site_network.centers).copy(), st.traj.copy()))
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][0], out[1][0])
