@@ -64,45 +64,41 @@ __device__ __forceinline__ bool col_find(const PredArgs &a, i32 d, i32 cid, doub
     return false;
 }
 
-__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a)
-{
-    const i64 row = (i64)blockIdx.x * PRED_BLOCK + threadIdx.x;
-    if (row >= a.N) return;
-    const int n = a.row_nnz[row];
-    if (n == 0) { a.labels[row] = -1; a.confs[row] = 0.0; return; }   // :168-172 (conf uninitialised there)
-    double x2 = 0.0;
-    for (int e = 0; e < n; e++) { const double v = a.row_val[(i64)e * a.N + row]; x2 += v * v; }
-    const double xn = sqrt(x2);
-    Best b = best_empty();
-    if (n <= 4) {
-        // up to four entries: a 4-way merge of the (centre-sorted) CSC columns of the row's dimensions.  Each
-        // step takes the smallest pending centre id and sums its terms in ascending dimension order.
-        i32 q0 = 0, q1 = 0, q2 = 0, q3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-        { const i32 d = a.row_idx[row]; q0 = a.col_ptr[d]; e0 = a.col_ptr[d + 1]; v0 = a.row_val[row]; }
-        if (n > 1) { const i32 d = a.row_idx[a.N + row]; q1 = a.col_ptr[d]; e1 = a.col_ptr[d + 1]; v1 = a.row_val[a.N + row]; }
-        if (n > 2) { const i32 d = a.row_idx[2 * a.N + row]; q2 = a.col_ptr[d]; e2 = a.col_ptr[d + 1]; v2 = a.row_val[2 * a.N + row]; }
-        if (n > 3) { const i32 d = a.row_idx[3 * a.N + row]; q3 = a.col_ptr[d]; e3 = a.col_ptr[d + 1]; v3 = a.row_val[3 * a.N + row]; }
-        const i32 none = 0x7fffffff;
-        i32 h0 = q0 < e0 ? a.col_k[q0] : none, h1 = q1 < e1 ? a.col_k[q1] : none;
-        i32 h2 = q2 < e2 ? a.col_k[q2] : none, h3 = q3 < e3 ? a.col_k[q3] : none;
-        while (true) {
-            i32 cid = h0 < h1 ? h0 : h1;
-            const i32 m23 = h2 < h3 ? h2 : h3;
-            cid = cid < m23 ? cid : m23;
-            if (cid == none) break;
-            double dot = 0.0;
-            bool first = true;
-            if (h0 == cid) { const double t = a.col_val[q0] * v0; dot = t; first = false; q0++; h0 = q0 < e0 ? a.col_k[q0] : none; }
-            if (h1 == cid) { const double t = a.col_val[q1] * v1; dot = first ? t : dot + t; first = false; q1++; h1 = q1 < e1 ? a.col_k[q1] : none; }
-            if (h2 == cid) { const double t = a.col_val[q2] * v2; dot = first ? t : dot + t; first = false; q2++; h2 = q2 < e2 ? a.col_k[q2] : none; }
-            if (h3 == cid) { const double t = a.col_val[q3] * v3; dot = first ? t : dot + t; first = false; q3++; h3 = q3 < e3 ? a.col_k[q3] : none; }
-            if (a.normed) dot /= xn;                                   // :177-178
-            b = best_merge(b, best_of(fabs(dot), cid));                // :179
+// Running argmax of fabs(dot_k) / xn over centres visited in ASCENDING id (numpy argmax: first maximum, NaN first).
+// Dividing by the same xn is monotonic, so the quotient of a later centre can only be STRICTLY greater if its
+// |dot| is greater; when it is greater by more than a few ulps the quotient is certainly greater and no division
+// is needed, inside that band both quotients are computed (rare).  One division per row instead of one per centre.
+struct ArgMaxQ {
+    double m;      // |dot| of the incumbent (undivided)
+    i64 i;         // its centre id, -1 = none yet
+    int nan;
+
+    __device__ __forceinline__ void init() { m = 0.0; i = -1; nan = 0; }
+    __device__ __forceinline__ void push(double dot, i64 cid, double xn, bool normed)
+    {
+        const double v = fabs(dot);
+        if (nan) return;                                   // the first NaN stays (np.argmax)
+        if (isnan(v)) { m = v; i = cid; nan = 1; return; }
+        if (i < 0) { m = v; i = cid; return; }
+        if (!(v > m)) return;
+        if (normed && !(v > m * (1.0 + 1e-15))) {
+            if (!(v / xn > m / xn)) return;                // equal quotients: the earlier centre keeps the place
         }
-        finish_predict(a, row, b);
-        return;
+        m = v; i = cid;
     }
+    __device__ __forceinline__ Best result(double xn, bool normed) const
+    {
+        Best b;
+        b.i = i; b.nan = nan;
+        b.v = (i >= 0 && normed) ? m / xn : m;             // :177-178 (NaN / xn stays NaN)
+        return b;
+    }
+};
+
+// rows with more than four entries: owner scan over the global CSC (centres come in no particular order)
+__device__ void predict_row_generic(const PredArgs &a, i64 row, int n, double xn)
+{
+    Best b = best_empty();
     for (int e = 0; e < n; e++) {
         const i32 d = a.row_idx[(i64)e * a.N + row];
         const double v = a.row_val[(i64)e * a.N + row];
@@ -122,6 +118,60 @@ __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a)
         }
     }
     finish_predict(a, row, b);
+}
+
+// One row with at most four entries: a 4-way merge of the (centre-sorted) CSC columns of the row's dimensions.
+// Each step takes the smallest pending centre id and sums its terms in ascending dimension order.  The CSC arrays
+// may live in global memory or (k_predict_rows_lds) in LDS.
+__device__ __forceinline__ void predict_row_merge(const PredArgs &a, i64 row, int n, double xn, const i32 *col_ptr,
+                                                  const i32 *col_k, const double *col_val)
+{
+    ArgMaxQ am;
+    am.init();
+    i32 q0 = 0, q1 = 0, q2 = 0, q3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    { const i32 d = a.row_idx[row]; q0 = col_ptr[d]; e0 = col_ptr[d + 1]; v0 = a.row_val[row]; }
+    if (n > 1) { const i32 d = a.row_idx[a.N + row]; q1 = col_ptr[d]; e1 = col_ptr[d + 1]; v1 = a.row_val[a.N + row]; }
+    if (n > 2) { const i32 d = a.row_idx[2 * a.N + row]; q2 = col_ptr[d]; e2 = col_ptr[d + 1]; v2 = a.row_val[2 * a.N + row]; }
+    if (n > 3) { const i32 d = a.row_idx[3 * a.N + row]; q3 = col_ptr[d]; e3 = col_ptr[d + 1]; v3 = a.row_val[3 * a.N + row]; }
+    const i32 none = 0x7fffffff;
+    i32 h0 = q0 < e0 ? col_k[q0] : none, h1 = q1 < e1 ? col_k[q1] : none;
+    i32 h2 = q2 < e2 ? col_k[q2] : none, h3 = q3 < e3 ? col_k[q3] : none;
+    while (true) {
+        i32 cid = h0 < h1 ? h0 : h1;
+        const i32 m23 = h2 < h3 ? h2 : h3;
+        cid = cid < m23 ? cid : m23;
+        if (cid == none) break;
+        double dot = 0.0;
+        bool first = true;
+        if (h0 == cid) { const double t = col_val[q0] * v0; dot = t; first = false; q0++; h0 = q0 < e0 ? col_k[q0] : none; }
+        if (h1 == cid) { const double t = col_val[q1] * v1; dot = first ? t : dot + t; first = false; q1++; h1 = q1 < e1 ? col_k[q1] : none; }
+        if (h2 == cid) { const double t = col_val[q2] * v2; dot = first ? t : dot + t; first = false; q2++; h2 = q2 < e2 ? col_k[q2] : none; }
+        if (h3 == cid) { const double t = col_val[q3] * v3; dot = first ? t : dot + t; first = false; q3++; h3 = q3 < e3 ? col_k[q3] : none; }
+        am.push(dot, cid, xn, a.normed != 0);                       // :177-179
+    }
+    finish_predict(a, row, am.result(xn, a.normed != 0));
+}
+
+__device__ __forceinline__ bool predict_row_head(const PredArgs &a, i64 row, int &n, double &xn)
+{
+    n = a.row_nnz[row];
+    if (n == 0) { a.labels[row] = -1; a.confs[row] = 0.0; return false; }   // :168-172 (conf uninitialised there)
+    double x2 = 0.0;
+    for (int e = 0; e < n; e++) { const double v = a.row_val[(i64)e * a.N + row]; x2 += v * v; }
+    xn = sqrt(x2);
+    return true;
+}
+
+__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a)
+{
+    const i64 row = (i64)blockIdx.x * PRED_BLOCK + threadIdx.x;
+    if (row >= a.N) return;
+    int n;
+    double xn;
+    if (!predict_row_head(a, row, n, xn)) return;
+    if (n <= 4) predict_row_merge(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
+    else predict_row_generic(a, row, n, xn);
 }
 
 // Dense fallback: every centre, sparse row against the dense (normalised) centre matrix.
