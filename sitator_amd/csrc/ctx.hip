@@ -27,8 +27,8 @@ extern "C" int sit_create(const double *cell, const double *cell_inv, int device
     *out = c;
     if (hipSetDevice(device) != hipSuccess) { c->msg = "hipSetDevice failed"; return SIT_ERR_HIP; }
     HIP_TRY(c, hipStreamCreate(&c->stream));
-    HIP_TRY(c, hipEventCreate(&c->ev0));
-    HIP_TRY(c, hipEventCreate(&c->ev1));
+    for (int i = 0; i < T_N; i++) { HIP_TRY(c, hipEventCreate(&c->tev0[i])); HIP_TRY(c, hipEventCreate(&c->tev1[i])); }
+    HIP_TRY(c, hipHostMalloc(&c->h_pinned, 256));
     HIP_TRY(c, hipMalloc((void **)&c->d_err, sizeof(u64)));
     HIP_TRY(c, hipMalloc((void **)&c->d_scal, sizeof(u64) * 16));
     HIP_TRY(c, hipMalloc((void **)&c->d_fit_K, sizeof(i64)));
@@ -46,8 +46,8 @@ extern "C" void sit_destroy(sit_ctx *c)
                     c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scal, c->d_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     fitfast_free(c);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < T_N; i++) { if (c->tev0[i]) (void)hipEventDestroy(c->tev0[i]); if (c->tev1[i]) (void)hipEventDestroy(c->tev1[i]); }
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -57,6 +57,8 @@ extern "C" const char *sit_last_message(sit_ctx *c) { return c ? c->msg.c_str() 
 extern "C" int sit_timers(sit_ctx *c, double *ms, int n)
 {
     if (!c || !ms) return SIT_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    for (int i = 0; i < T_N; i++) stage_timer_resolve(c, i);
     for (int i = 0; i < n; i++) ms[i] = i < T_N ? c->timers[i] : 0.0;
     return SIT_OK;
 }

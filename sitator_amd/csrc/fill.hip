@@ -340,19 +340,22 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         else rc = launch_fill_v1(c, p);
         if (rc) return rc;
         timer.stop();
-        u64 hkey = 0, hs[4] = {0, 0, 0, 0};
-        HIP_TRY(c, hipMemcpyAsync(&hkey, c->d_err, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(hs, c->d_scal, 32, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (n_all_zero) *n_all_zero = (i64)hs[0];
-        c->fallback_frames = (i64)hs[2];
+        // the assignment is enqueued behind the fill without waiting for the fill's error word: one host
+        // synchronisation per call (if the fill did report an error the assignment is simply discarded)
         c->rows_valid = store;
         c->assign_valid = false;
+        if (assign && (rc = sit_predict_internal(c, p->predict_threshold))) return rc;
+        u64 *hb = (u64 *)c->h_pinned;          // [0] error key, [1..4] scalars
+        HIP_TRY(c, hipMemcpyAsync(hb, c->d_err, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(hb + 1, c->d_scal, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const u64 hkey = hb[0], hs[4] = {hb[1], hb[2], hb[3], hb[4]};
+        if (n_all_zero) *n_all_zero = (i64)hs[0];
+        c->fallback_frames = (i64)hs[2];
         const int kind = decode_error(c, hkey, err);
-        if (kind != SIT_OK) return kind;
-        if (v2 && hs[3]) { c->msg = "landmark row wider than the pruning bound (internal error)"; return SIT_ERR_CAPACITY; }
-        if (!assign) return SIT_OK;
-        return sit_predict_internal(c, p->predict_threshold);
+        if (kind != SIT_OK) { c->assign_valid = false; return kind; }
+        if (v2 && hs[3]) { c->assign_valid = false; c->msg = "landmark row wider than the pruning bound (internal error)"; return SIT_ERR_CAPACITY; }
+        return SIT_OK;
     }
     return SIT_ERR_CAPACITY;
 }

@@ -29,7 +29,9 @@ enum { T_FILL = 0, T_FIT = 1, T_PREDICT = 2, T_GRAM = 3, T_CENTERS = 4, T_OCC = 
 struct sit_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t tev0[T_N] = {nullptr}, tev1[T_N] = {nullptr};   // per-stage event pairs
+    bool tpending[T_N] = {false};                              // recorded, not yet read
+    void *h_pinned = nullptr;                                  // small pinned read-back buffer (256 bytes)
     std::string msg;
     double timers[T_N] = {0};
     Pbc pbc;
@@ -152,16 +154,29 @@ static inline int ensure_scratch(sit_ctx *c, i64 bytes)
     return SIT_OK;
 }
 
+// HIP-event time of a stage on the context's stream.  stop() only records: the elapsed time is read when the timers
+// are queried (sit_timers) or the slot is reused, so timing a stage costs no host synchronisation.
+static inline void stage_timer_resolve(sit_ctx *c, int slot)
+{
+    if (!c->tpending[slot]) return;
+    (void)hipEventSynchronize(c->tev1[slot]);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->tev0[slot], c->tev1[slot]);
+    c->timers[slot] = ms;
+    c->tpending[slot] = false;
+}
+
 struct StageTimer {
     sit_ctx *c; int slot;
-    StageTimer(sit_ctx *c_, int s) : c(c_), slot(s) { (void)hipEventRecord(c->ev0, c->stream); }
+    StageTimer(sit_ctx *c_, int s) : c(c_), slot(s)
+    {
+        stage_timer_resolve(c, slot);
+        (void)hipEventRecord(c->tev0[slot], c->stream);
+    }
     void stop()
     {
-        (void)hipEventRecord(c->ev1, c->stream);
-        (void)hipEventSynchronize(c->ev1);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-        c->timers[slot] = ms;
+        (void)hipEventRecord(c->tev1[slot], c->stream);
+        c->tpending[slot] = true;
     }
 };
 
