@@ -24,6 +24,7 @@ extern "C" int sit_create(const double *cell, const double *cell_inv, int device
     for (int i = 0; i < 9; i++) c->pbc.ci[i] = cell_inv[i];
     for (int j = 0; j < 3; j++)
         c->pbc.cen[j] = (0.5 * cell[0 + j] + 0.5 * cell[3 + j]) + 0.5 * cell[6 + j];
+    { const char *ff = getenv("SITATOR_FIT"); c->fit_use_fast = !(ff && ff[0] == 's'); }   // serial = ordered single-workgroup stream
     *out = c;
     if (hipSetDevice(device) != hipSuccess) { c->msg = "hipSetDevice failed"; return SIT_ERR_HIP; }
     HIP_TRY(c, hipStreamCreate(&c->stream));
@@ -257,8 +258,6 @@ extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const 
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
             if (i != j && (c->pbc.cm[3 * i + j] != 0.0 || c->pbc.ci[3 * i + j] != 0.0)) c->cell_diagonal = false;
-    const char *ff = getenv("SITATOR_FIT");
-    c->fit_use_fast = !(ff && ff[0] == 's');
     const char *fk = getenv("SITATOR_FILL_KERNEL");
     c->fill_kernel = (fk && fk[0] == '1') ? 1 : 2;
     c->tight_valid = false;

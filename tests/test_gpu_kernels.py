@@ -269,3 +269,49 @@ def test_site_centres_are_reproducible_bit_for_bit():
         out.append((np.asarray(st.site_network.centers).copy(), st.traj.copy()))
     assert np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("seed,D,N,maxnnz", [(0, 96, 20000, 3), (1, 400, 30000, 6), (2, 48, 12000, 12)])
+def test_speculative_fit_on_random_sparse_rows(oracle, seed, D, N, maxnnz):
+    """Stress of the exact parallel fit on data unlike a trajectory: random sparse rows found thousands of
+    clusters (state reallocation), supports grow constantly (growth log), wide rows / crowded dimensions hit the
+    capacity fall-backs.  Centres must equal the oracle's ordered stream."""
+    from sitator_amd import DotProdClassifier
+    rng = np.random.default_rng(seed)
+    X = np.zeros((N, D))
+    proto = rng.integers(0, D, size=(max(D * 3, 300), maxnnz))
+    for i in range(N):
+        p = proto[rng.integers(len(proto))]
+        k = int(rng.integers(1, maxnnz + 1))
+        dims = np.unique(p[:k])
+        X[i, dims] = rng.uniform(0.05, 1.0, size=len(dims))
+    clf = DotProdClassifier(threshold=0.6, min_samples=1)
+    clf.fit_centers(X)
+    exp = oracle.fit_centers(X, 0.6)
+    assert clf.cluster_centers.shape == exp.shape
+    np.testing.assert_allclose(clf.cluster_centers, exp, rtol=1e-12, atol=1e-300)
+
+
+def test_speculative_fit_grows_its_state_past_the_first_allocation():
+    """More than 2048 clusters: the sparse clustering state is exported, reallocated and re-imported mid-stream.
+    Checked against the ordered single-workgroup stream (itself checked against the oracle above)."""
+    import os
+    from sitator_amd import DotProdClassifier
+    rng = np.random.default_rng(7)
+    D, N = 600, 40000
+    X = np.zeros((N, D))
+    proto = rng.integers(0, D, size=(5000, 4))
+    for i in range(N):
+        dims = np.unique(proto[rng.integers(len(proto))][:int(rng.integers(1, 5))])
+        X[i, dims] = rng.uniform(0.05, 1.0, size=len(dims))
+    clf = DotProdClassifier(threshold=0.7, min_samples=1)
+    clf.fit_centers(X)
+    os.environ["SITATOR_FIT"] = "serial"
+    try:
+        ser = DotProdClassifier(threshold=0.7, min_samples=1)
+        ser.fit_centers(X)
+    finally:
+        os.environ.pop("SITATOR_FIT", None)
+    assert len(clf.cluster_centers) > 2100
+    assert clf.cluster_centers.shape == ser.cluster_centers.shape
+    np.testing.assert_allclose(clf.cluster_centers, ser.cluster_centers, rtol=1e-12, atol=1e-300)
