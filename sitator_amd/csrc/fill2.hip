@@ -100,10 +100,10 @@ __device__ __forceinline__ int bin_of(const Pbc &P, double px, double py, double
 
 // squared shift-and-wrap distance of static v from the ion (helpers.pyx:99-103,176 before the sqrt)
 template <int CELL>
-__device__ __forceinline__ double dist2_to(const Pbc &P, const double *fsx, const double *fsy, const double *fsz,
-                                           int v, double ox, double oy, double oz)
+__device__ __forceinline__ double dist2_to(const Pbc &P, const double *fs, int v, double ox, double oy, double oz)
 {
-    double qx = fsx[v] + ox, qy = fsy[v] + oy, qz = fsz[v] + oz;
+    // statics are parked x,y,z interleaved: one address, ds_read2_b64 + ds_read_b64
+    double qx = fs[3 * v] + ox, qy = fs[3 * v + 1] + oy, qz = fs[3 * v + 2] + oz;
     wrapc<CELL>(P, qx, qy, qz);
     const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
     return (dx * dx + dy * dy) + dz * dz;
@@ -147,8 +147,7 @@ __device__ __forceinline__ void load_row(LmkRow &r, const i32 *verts, const doub
 // Stage 1: does any vertex lie provably beyond the cut-off?  Same distances as the reference, compared
 // squared against hi2 = (rz * vcd)^2 * (1 + 1e-14); a "true" here implies the component is exactly 0.
 template <int CELL>
-__device__ __forceinline__ bool screen_landmark(const Fill2Args &a, int k, const double *fsx, const double *fsy,
-                                                const double *fsz, const i32 *lmap, double ox, double oy, double oz)
+__device__ __forceinline__ bool screen_landmark(const Fill2Args &a, int k, const double *fs, const i32 *lmap, double ox, double oy, double oz)
 {
     if (a.V <= 8) {
         // branch-free over the (padded) row: the wave leaves only with its slowest lane anyway, and without
@@ -161,7 +160,7 @@ __device__ __forceinline__ bool screen_landmark(const Fill2Args &a, int k, const
             const bool valid = r.v[h] >= 0;
             i32 v = valid ? r.v[h] : 0;
             if (lmap) v = lmap[v];
-            beyond |= valid && dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz) > r.c[h];
+            beyond |= valid && dist2_to<CELL>(a.P, fs, v, ox, oy, oz) > r.c[h];
         }
         if (a.V > 4) {
 #pragma unroll
@@ -169,7 +168,7 @@ __device__ __forceinline__ bool screen_landmark(const Fill2Args &a, int k, const
                 const bool valid = r.v[h] >= 0;
                 i32 v = valid ? r.v[h] : 0;
                 if (lmap) v = lmap[v];
-                beyond |= valid && dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz) > r.c[h];
+                beyond |= valid && dist2_to<CELL>(a.P, fs, v, ox, oy, oz) > r.c[h];
             }
         }
         return beyond;
@@ -180,17 +179,16 @@ __device__ __forceinline__ bool screen_landmark(const Fill2Args &a, int k, const
         i32 v = vk[h];
         if (v < 0) break;
         if (lmap) v = lmap[v];
-        if (dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz) > hk[h]) return true;
+        if (dist2_to<CELL>(a.P, fs, v, ox, oy, oz) > hk[h]) return true;
     }
     return false;
 }
 
 // one vertex of landmark/helpers.pyx:186-205; returns false when the vertex is beyond the cut-off
 template <int CELL>
-__device__ __forceinline__ bool eval_vertex(const Fill2Args &a, i32 v, double dkh, const double *fsx, const double *fsy,
-                                            const double *fsz, double ox, double oy, double oz, double &acc)
+__device__ __forceinline__ bool eval_vertex(const Fill2Args &a, i32 v, double dkh, const double *fs, double ox, double oy, double oz, double &acc)
 {
-    const double dist = sqrt(dist2_to<CELL>(a.P, fsx, fsy, fsz, v, ox, oy, oz));
+    const double dist = sqrt(dist2_to<CELL>(a.P, fs, v, ox, oy, oz));
     double tt = dist / dkh;
     if (tt > a.rz) return false;
     tt = 1.0 / (1.0 + exp(a.steepness * (tt - a.midpoint)));
@@ -200,8 +198,7 @@ __device__ __forceinline__ bool eval_vertex(const Fill2Args &a, i32 v, double dk
 
 // Stage 2: one landmark component, landmark/helpers.pyx:186-212 (and :174-178 for the distances).
 template <int CELL>
-__device__ __forceinline__ double eval_landmark(const Fill2Args &a, int k, const double *fsx, const double *fsy,
-                                                const double *fsz, const i32 *lmap, double ox, double oy, double oz)
+__device__ __forceinline__ double eval_landmark(const Fill2Args &a, int k, const double *fs, const i32 *lmap, double ox, double oy, double oz)
 {
     double acc = 1.0;
     int nv = 0;
@@ -214,7 +211,7 @@ __device__ __forceinline__ double eval_landmark(const Fill2Args &a, int k, const
             if (v < 0) break;
             nv++;
             if (lmap) v = lmap[v];
-            if (!eval_vertex<CELL>(a, v, r.c[h], fsx, fsy, fsz, ox, oy, oz, acc)) return 0.0;
+            if (!eval_vertex<CELL>(a, v, r.c[h], fs, ox, oy, oz, acc)) return 0.0;
         }
         return nth_root(acc, nv);
     }
@@ -225,7 +222,7 @@ __device__ __forceinline__ double eval_landmark(const Fill2Args &a, int k, const
         if (v < 0) break;
         nv++;
         if (lmap) v = lmap[v];
-        if (!eval_vertex<CELL>(a, v, dk[h], fsx, fsy, fsz, ox, oy, oz, acc)) return 0.0;
+        if (!eval_vertex<CELL>(a, v, dk[h], fs, ox, oy, oz, acc)) return 0.0;
     }
     return nth_root(acc, nv);
 }
@@ -278,8 +275,7 @@ __device__ __forceinline__ void vp_fetch(VpItem<LG, LL> &it, int i, int items, c
 // landmark/helpers.pyx:186-212 for the survivors listed in surv[]
 template <int CELL, int LG, int LL>
 __device__ __forceinline__ void eval_vp(const Fill2Args &a, int nsurv, const i32 *tk, const unsigned char *tion,
-                                        const unsigned short *surv, double *tval, unsigned char *tnv, const double *sx,
-                                        const double *sy, const double *sz, i64 f0, bool dyn, double ox, double oy,
+                                        const unsigned short *surv, double *tval, unsigned char *tnv, const double *sxyz, i64 f0, bool dyn, double ox, double oy,
                                         double oz, int fl, int lane)
 {
     constexpr int L = 1 << LL, R = 1 << (LG - LL);
@@ -303,7 +299,7 @@ __device__ __forceinline__ void eval_vp(const Fill2Args &a, int nsurv, const i32
                 mine++;
                 i32 v = cur.v[r];
                 if (dyn) v = a.lattice_map[(f0 + tfl) * a.S + v];
-                const double dist = sqrt(dist2_to<CELL>(a.P, sx + tfl * a.S, sy + tfl * a.S, sz + tfl * a.S, v, tox, toy, toz));
+                const double dist = sqrt(dist2_to<CELL>(a.P, sxyz + 3 * tfl * a.S, v, tox, toy, toz));
                 const double tt = dist / cur.c[r];
                 if (tt > a.rz) zero = true;
                 else ci[r] = 1.0 / (1.0 + exp(a.steepness * (tt - a.midpoint)));
@@ -348,10 +344,8 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = h.S, M = h.M;
     const int fpb = h.fpb;
-    double *sx = (double *)smem;
-    double *sy = sx + fpb * S;
-    double *sz = sy + fpb * S;
-    double *mx = sz + fpb * S;
+    double *sxyz = (double *)smem;                              // [fpb][S][3] wrapped statics
+    double *mx = sxyz + 3 * fpb * S;
     double *my = mx + fpb * M;
     double *mz = my + fpb * M;
     double *tval_all = mz + fpb * M;                            // [4][WTASK]
@@ -371,15 +365,17 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
     if (tid < fpb) fmax[tid] = 0ull;
     __syncthreads();
     // ---- phase 1: stream the frames, wrap (Step 0), static-lattice check (helpers.pyx:57-80) ----
+    const double *fbase = h.frames + f0 * h.A * 3;              // this workgroup's frames (uniform)
     for (int t = tid; t < nf * SM; t += F2_THREADS) {
-        const int fl = t / SM;
+        int fl = 0;
+        for (int q = 1; q < nf; q++) fl += t >= q * SM;         // at most 8 frames per workgroup: no division
         const int r = t - fl * SM;
-        const i64 atom = r < S ? h.static_idx[r] : h.mobile_idx[r - S];
-        const double *p = h.frames + ((f0 + fl) * h.A + atom) * 3;
+        const int atom = r < S ? h.static_idx[r] : h.mobile_idx[r - S];
+        const double *p = fbase + (unsigned)(fl * (int)h.A + atom) * 3u;
         double x = p[0], y = p[1], z = p[2];
         wrapc<CELL>(P, x, y, z);
         if (r < S) {
-            sx[fl * S + r] = x; sy[fl * S + r] = y; sz[fl * S + r] = z;
+            { double *d = sxyz + 3 * (fl * S + r); d[0] = x; d[1] = y; d[2] = z; }
             if (!dyn) {
                 // PBCCalculator.distances(ref, atom) (util/PBCCalculator.pyx:64-103), squared; the sqrt is
                 // taken only inside the rounding band around static_movement_threshold^2
@@ -437,7 +433,8 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
         const i32 *list = nullptr;
         if (lane < nic) {
             const int ion = ic0 + lane;
-            fl = ion / M; j = ion - fl * M;
+            for (int q = 1; q < nf; q++) fl += ion >= q * M;
+            j = ion - fl * M;
             const double px = mx[fl * M + j], py = my[fl * M + j], pz = mz[fl * M + j];
             ox = P.cen[0] - px; oy = P.cen[1] - py; oz = P.cen[2] - pz;
             if (fmax[fl] != 0ull) {
@@ -484,7 +481,7 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
                     bool alive = false;
                     if (t < ntasks) {
                         const i32 *lmap = dyn ? a.lattice_map + (f0 + tfl) * S : nullptr;
-                        alive = !screen_landmark<CELL>(a, tk[t], sx + tfl * S, sy + tfl * S, sz + tfl * S, lmap, tox, toy, toz);
+                        alive = !screen_landmark<CELL>(a, tk[t], sxyz + 3 * tfl * S, lmap, tox, toy, toz);
                         if (!alive) tval[t] = 0.0;
                     }
                     const unsigned long long m = __ballot(alive);
@@ -500,7 +497,7 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
             }
             // 2e-2: full evaluation of the survivors
             if constexpr (LG != 0) {
-                eval_vp<CELL, LG, (F2_LL < LG ? F2_LL : LG)>(a, nsurv, tk, tion, surv, tval, tnv, sx, sy, sz, f0, dyn, ox, oy, oz, fl, lane);
+                eval_vp<CELL, LG, (F2_LL < LG ? F2_LL : LG)>(a, nsurv, tk, tion, surv, tval, tnv, sxyz, f0, dyn, ox, oy, oz, fl, lane);
             } else {
                 for (int q0 = 0; q0 < nsurv; q0 += 64) {
                     const int q = q0 + lane;
@@ -510,7 +507,7 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
                     const int tfl = __shfl(fl, ii);
                     if (q < nsurv) {
                         const i32 *lmap = dyn ? a.lattice_map + (f0 + tfl) * S : nullptr;
-                        tval[t] = eval_landmark<CELL>(a, tk[t], sx + tfl * S, sy + tfl * S, sz + tfl * S, lmap, tox, toy, toz);
+                        tval[t] = eval_landmark<CELL>(a, tk[t], sxyz + 3 * tfl * S, lmap, tox, toy, toz);
                     }
                 }
             }
@@ -597,7 +594,7 @@ size_t fill2_lds_bytes(i64 S, i64 M, int fpb)
 int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, double threshold)
 {
     const i64 S = c->S, M = c->M;
-    SIT_REQUIRE(c, c->D * c->V < (1LL << 31) && c->F * S < (1LL << 40), "sit_fill: sizes too large");
+    SIT_REQUIRE(c, c->D * c->V < (1LL << 31) && c->F * S < (1LL << 40) && c->A < (1LL << 27), "sit_fill: sizes too large");
     Fill2Args a;
     a.P = c->pbc; a.frames = c->d_frames; a.static_idx = c->d_static_idx; a.mobile_idx = c->d_mobile_idx;
     a.ref_static = c->d_ref_static; a.verts = c->d_verts; a.vcd = c->d_vcd; a.hi2 = c->d_hi2;
