@@ -55,15 +55,6 @@ __device__ __forceinline__ void finish_predict(const PredArgs &a, i64 row, Best 
     a.confs[row] = conf;
 }
 
-// value of centre cid in column d, or "absent"
-__device__ __forceinline__ bool col_find(const PredArgs &a, i32 d, i32 cid, double &val)
-{
-    const i32 lo = a.col_ptr[d], hi = a.col_ptr[d + 1];
-    for (i32 q = lo; q < hi; q++)
-        if (a.col_k[q] == cid) { val = a.col_val[q]; return true; }
-    return false;
-}
-
 // Running argmax of fabs(dot_k) / xn over centres visited in ASCENDING id (numpy argmax: first maximum, NaN first).
 // Dividing by the same xn is monotonic, so the quotient of a later centre can only be STRICTLY greater if its
 // |dot| is greater; when it is greater by more than a few ulps the quotient is certainly greater and no division
@@ -95,26 +86,39 @@ struct ArgMaxQ {
     }
 };
 
-// rows with more than four entries: owner scan over the global CSC (centres come in no particular order)
+// Rows with more than four entries.  Candidate centres are enumerated from the CSC columns of the row's dimensions;
+// the (row entry e, column entry) pair that sees a centre FIRST (no earlier row dimension holds it) owns it and
+// computes its dot product.  Both the ownership test and the dot product read the DENSE centre matrix: the loads
+// are independent of each other, and summing c[k][d_e] * x_e over the row's entries in ascending dimension order
+// is the reference's dense dot product with its exact zeros left out (a stored 0.0 contributes +0.0).
+// Centres come in no particular order, hence the index-aware best_merge.
 __device__ void predict_row_generic(const PredArgs &a, i64 row, int n, double xn)
 {
     Best b = best_empty();
     for (int e = 0; e < n; e++) {
         const i32 d = a.row_idx[(i64)e * a.N + row];
-        const double v = a.row_val[(i64)e * a.N + row];
         const i32 lo = a.col_ptr[d], hi = a.col_ptr[d + 1];
         for (i32 q = lo; q < hi; q++) {
             const i32 cid = a.col_k[q];
+            const double *crow = a.dense + (i64)cid * a.D;
             bool owner = true;
-            double tmp;
-            for (int e2 = 0; e2 < e && owner; e2++)
-                if (col_find(a, a.row_idx[(i64)e2 * a.N + row], cid, tmp)) owner = false;
+            for (int e2 = 0; e2 < e; e2++) {
+                const double cv = crow[a.row_idx[(i64)e2 * a.N + row]];
+                if (cv != 0.0) { owner = false; break; }                 // NaN != 0: an earlier dimension holds it
+            }
             if (!owner) continue;
-            double dot = a.col_val[q] * v;
-            for (int e3 = e + 1; e3 < n; e3++)
-                if (col_find(a, a.row_idx[(i64)e3 * a.N + row], cid, tmp)) dot += tmp * a.row_val[(i64)e3 * a.N + row];
-            if (a.normed) dot /= xn;                                   // :177-178
-            b = best_merge(b, best_of(fabs(dot), cid));                // :179
+            double dot = 0.0;
+            bool first = true;
+            for (int e3 = e; e3 < n; e3++) {
+                const double cv = crow[a.row_idx[(i64)e3 * a.N + row]];
+                if (cv != 0.0) {                                         // exact zeros add nothing
+                    const double t = cv * a.row_val[(i64)e3 * a.N + row];
+                    dot = first ? t : dot + t;
+                    first = false;
+                }
+            }
+            if (a.normed) dot /= xn;                                     // :177-178
+            b = best_merge(b, best_of(fabs(dot), cid));                  // :179
         }
     }
     finish_predict(a, row, b);
