@@ -20,7 +20,6 @@
 
 #include "sit_internal.h"
 
-#define F2_THREADS 256
 #define F2_IW 32           // ions per wave chunk
 #define F2_WTASK 128       // tasks per wave batch
 #ifndef F2_LL
@@ -338,8 +337,11 @@ __device__ __forceinline__ void eval_vp(const Fill2Args &a, int nsurv, const i32
     }
 }
 
-template <int CELL, int LG>      // LG: log2 of the padded vertices per landmark for the vertex-parallel passes (0: generic)
-__global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsPtr full)
+// CELL: diagonal cell or not.  LG: log2 of the padded vertices per landmark (0: generic lane-per-task passes).
+// NW: waves per workgroup, 4 or 8 (8 where a frame's statics fill so much LDS that only two workgroups fit a CU:
+// the same LDS then feeds twice the waves).
+template <int CELL, int LG, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void k_fill2(Fill2Head h, Fill2ArgsPtr full)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = h.S, M = h.M;
@@ -349,11 +351,11 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
     double *my = mx + fpb * M;
     double *mz = my + fpb * M;
     double *tval_all = mz + fpb * M;                            // [4][WTASK]
-    u64 *fmax = (u64 *)(tval_all + 4 * F2_WTASK);               // [fpb] beyond-delta flags
+    u64 *fmax = (u64 *)(tval_all + NW * F2_WTASK);              // [fpb] beyond-delta flags
     i32 *tk_all = (i32 *)(fmax + fpb);                          // [4][WTASK]
-    unsigned short *surv_all = (unsigned short *)(tk_all + 4 * F2_WTASK);   // [4][WTASK]
-    unsigned char *tion_all = (unsigned char *)(surv_all + 4 * F2_WTASK);   // [4][WTASK]
-    unsigned char *tnv_all = tion_all + 4 * F2_WTASK;                       // [4][WTASK] vertices per task
+    unsigned short *surv_all = (unsigned short *)(tk_all + NW * F2_WTASK);  // [NW][WTASK]
+    unsigned char *tion_all = (unsigned char *)(surv_all + NW * F2_WTASK);  // [NW][WTASK]
+    unsigned char *tnv_all = tion_all + NW * F2_WTASK;                      // [NW][WTASK] vertices per task
     const Pbc &P = h.P;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const i64 f0 = (i64)blockIdx.x * fpb;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
     __syncthreads();
     // ---- phase 1: stream the frames, wrap (Step 0), static-lattice check (helpers.pyx:57-80) ----
     const double *fbase = h.frames + f0 * h.A * 3;              // this workgroup's frames (uniform)
-    for (int t = tid; t < nf * SM; t += F2_THREADS) {
+    for (int t = tid; t < nf * SM; t += NW * 64) {
         int fl = 0;
         for (int q = 1; q < nf; q++) fl += t >= q * SM;         // at most 8 frames per workgroup: no division
         const int r = t - fl * SM;
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(F2_THREADS, 4) void k_fill2(Fill2Head h, Fill2ArgsP
     unsigned char *tnv = tnv_all + wave * F2_WTASK;
     const bool store = a.row_val != nullptr;
     const int nions = nf * M;
-    for (int ic0 = wave * F2_IW; ic0 < nions; ic0 += 4 * F2_IW) {
+    for (int ic0 = wave * F2_IW; ic0 < nions; ic0 += NW * F2_IW) {
         const int nic = (nions - ic0) < F2_IW ? (nions - ic0) : F2_IW;
         // 2a: lanes < nic own one ion: its offset (helpers.pyx:100) and candidate list
         int fl = 0, j = 0, cnt = 0;
@@ -579,15 +581,15 @@ int fill2_sample_dmax(sit_ctx *c, std::vector<double> &out)
     return SIT_OK;
 }
 
-size_t fill2_lds_bytes(i64 S, i64 M, int fpb)
+size_t fill2_lds_bytes(i64 S, i64 M, int fpb, int nw)
 {
     size_t b = (size_t)fpb * (size_t)(S + M) * 24;
-    b += (size_t)4 * F2_WTASK * 8;      // tval
+    b += (size_t)nw * F2_WTASK * 8;     // tval
     b += (size_t)fpb * 8;               // fmax
-    b += (size_t)4 * F2_WTASK * 4;      // tk
-    b += (size_t)4 * F2_WTASK * 2;      // surv
-    b += (size_t)4 * F2_WTASK;          // tion
-    b += (size_t)4 * F2_WTASK;          // tnv
+    b += (size_t)nw * F2_WTASK * 4;     // tk
+    b += (size_t)nw * F2_WTASK * 2;     // surv
+    b += (size_t)nw * F2_WTASK;         // tion
+    b += (size_t)nw * F2_WTASK;         // tnv
     return (b + 31) & ~(size_t)15;
 }
 
@@ -613,11 +615,16 @@ int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, 
     a.delta2 = c->tight_delta >= 0 ? c->tight_delta * c->tight_delta : -1.0;
     a.thr2_lo = c->static_thr * c->static_thr * (1.0 - 1e-14);
     a.thr2_hi = c->static_thr * c->static_thr * (1.0 + 1e-14);
-    // frames per workgroup: about IC ions, within the LDS budget
-    i64 fpb = (4 * F2_IW) / M; if (fpb < 1) fpb = 1; if (fpb > 8) fpb = 8;
-    while (fpb > 1 && fill2_lds_bytes(S, M, (int)fpb) > 64 * 1024) fpb--;
+    // frames per workgroup: about one 32-ion chunk per wave, within the LDS budget
+    int nw = 4;
+    i64 fpb = (nw * F2_IW) / M; if (fpb < 1) fpb = 1; if (fpb > 8) fpb = 8;
+    while (fpb > 1 && fill2_lds_bytes(S, M, (int)fpb, nw) > 64 * 1024) fpb--;
+    // a big frame leaves room for two or three 4-wave workgroups per CU (160 KB LDS): eight waves per workgroup on the
+    // same statics restore the 16 waves per CU, provided the frame has ions for them
+    if (fpb == 1 && fill2_lds_bytes(S, M, 1, 4) > 40 * 1024 && M >= 6 * F2_IW && fill2_lds_bytes(S, M, 1, 8) <= 79 * 1024) nw = 8;
+    { const char *e = getenv("SITATOR_FILL_WAVES"); if (e && (atoi(e) == 4 || atoi(e) == 8)) nw = atoi(e); }
     a.fpb = (int)fpb; c->last_fpb = (int)fpb;
-    const size_t lds = fill2_lds_bytes(S, M, (int)fpb);
+    const size_t lds = fill2_lds_bytes(S, M, (int)fpb, nw);
     SIT_REQUIRE(c, lds <= 158 * 1024, "sit_fill: one frame's atoms do not fit in LDS");
     const unsigned grid = (unsigned)((c->F + fpb - 1) / fpb);
     Fill2Head h;
@@ -630,10 +637,15 @@ int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, 
     const Fill2ArgsPtr full = (Fill2ArgsPtr)c->d_fill_args;
     const bool diag = c->cell_diagonal;
     const int lg = c->Vp == 8 ? 3 : (c->Vp == 4 ? 2 : 0);
-#define F2_LAUNCH(CELL, LGV)                                                                                               \
-    do {                                                                                                               \
-        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill2<CELL, LGV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        k_fill2<CELL, LGV><<<dim3(grid), dim3(F2_THREADS), lds, c->stream>>>(h, full);                                  \
+#define F2_LAUNCH(CELL, LGV)                                                                                                   \
+    do {                                                                                                                   \
+        if (nw == 8) {                                                                                                     \
+            HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill2<CELL, LGV, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            k_fill2<CELL, LGV, 8><<<dim3(grid), dim3(512), lds, c->stream>>>(h, full);                                     \
+        } else {                                                                                                           \
+            HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill2<CELL, LGV, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            k_fill2<CELL, LGV, 4><<<dim3(grid), dim3(256), lds, c->stream>>>(h, full);                                     \
+        }                                                                                                                  \
     } while (0)
     if (diag) { if (lg == 3) F2_LAUNCH(1, 3); else if (lg == 2) F2_LAUNCH(1, 2); else F2_LAUNCH(1, 0); }
     else { if (lg == 3) F2_LAUNCH(0, 3); else if (lg == 2) F2_LAUNCH(0, 2); else F2_LAUNCH(0, 0); }
