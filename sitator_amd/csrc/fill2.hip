@@ -370,7 +370,7 @@ __global__ __launch_bounds__(NW * 64, 4) void k_fill2(Fill2Head h, Fill2ArgsPtr 
     const double *fbase = h.frames + f0 * h.A * 3;              // this workgroup's frames (uniform)
     for (int t = tid; t < nf * SM; t += NW * 64) {
         int fl = 0;
-        for (int q = 1; q < nf; q++) fl += t >= q * SM;         // at most 8 frames per workgroup: no division
+        for (int q = 1; q < nf; q++) fl += t >= q * SM;         // at most 32 frames per workgroup: no division
         const int r = t - fl * SM;
         const int atom = r < S ? h.static_idx[r] : h.mobile_idx[r - S];
         const double *p = fbase + (unsigned)(fl * (int)h.A + atom) * 3u;
@@ -596,7 +596,7 @@ size_t fill2_lds_bytes(i64 S, i64 M, int fpb, int nw)
 int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, double threshold)
 {
     const i64 S = c->S, M = c->M;
-    SIT_REQUIRE(c, c->D * c->V < (1LL << 31) && c->F * S < (1LL << 40) && c->A < (1LL << 27), "sit_fill: sizes too large");
+    SIT_REQUIRE(c, c->D * c->V < (1LL << 31) && c->F * S < (1LL << 40) && c->A < (1LL << 25), "sit_fill: sizes too large");
     Fill2Args a;
     a.P = c->pbc; a.frames = c->d_frames; a.static_idx = c->d_static_idx; a.mobile_idx = c->d_mobile_idx;
     a.ref_static = c->d_ref_static; a.verts = c->d_verts; a.vcd = c->d_vcd; a.hi2 = c->d_hi2;
@@ -617,7 +617,7 @@ int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, 
     a.thr2_hi = c->static_thr * c->static_thr * (1.0 + 1e-14);
     // frames per workgroup: about one 32-ion chunk per wave, within the LDS budget
     int nw = 4;
-    i64 fpb = (nw * F2_IW) / M; if (fpb < 1) fpb = 1; if (fpb > 8) fpb = 8;
+    i64 fpb = (nw * F2_IW) / M; if (fpb < 1) fpb = 1; if (fpb > 32) fpb = 32;
     while (fpb > 1 && fill2_lds_bytes(S, M, (int)fpb, nw) > 64 * 1024) fpb--;
     // a big frame leaves room for two or three 4-wave workgroups per CU (160 KB LDS): eight waves per workgroup on the
     // same statics restore the 16 waves per CU, provided the frame has ions for them
