@@ -315,3 +315,41 @@ def test_speculative_fit_grows_its_state_past_the_first_allocation():
     assert len(clf.cluster_centers) > 2100
     assert clf.cluster_centers.shape == ser.cluster_centers.shape
     np.testing.assert_allclose(clf.cluster_centers, ser.cluster_centers, rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.parametrize("cfg,M,F", [("C2", 64, 120), ("C5", 160, 30), ("C1b", 4, 300)])
+def test_eight_wave_workgroups_give_the_same_rows(cfg, M, F):
+    """The fill kernel's 8-waves-per-workgroup build (chosen automatically for big frames) against the 4-wave one:
+    identical rows, bit for bit, also with dynamic lattice mapping."""
+    from sitator_amd import synth
+    host = synth.config_host(cfg)
+    out = {}
+    for waves in ("4", "8"):
+        os.environ["SITATOR_FILL_WAVES"] = waves
+        try:
+            ctx, *_ = _setup(host, M, F, seed=21)
+            for dyn in (False, True):
+                rc, nz, err = ctx.fill(dynamic_lattice_mapping=dyn, check_for_zeros=False)
+                assert rc == 0
+                out[(waves, dyn)] = (ctx.rows_dense(), nz)
+        finally:
+            os.environ.pop("SITATOR_FILL_WAVES", None)
+    for dyn in (False, True):
+        assert out[("4", dyn)][1] == out[("8", dyn)][1]
+        assert np.array_equal(out[("4", dyn)][0], out[("8", dyn)][0])
+
+
+def test_big_frames_pick_eight_waves_and_match_oracle(oracle):
+    """C4 (2048 statics per frame): the launcher picks 8 waves per workgroup by itself; rows against the oracle."""
+    from sitator_amd import synth
+    host = synth.config_host("C4")
+    ctx, frames, sm, mm, ref = _setup(host, 256, 6, seed=5)
+    rc, nz, err = ctx.fill(check_for_zeros=False)
+    assert rc == 0
+    verts = np.array([v for v in host.vertices], dtype=np.int64)
+    vcd = np.array([oracle.distances(host.cell, host.centers[k], ref[sm][verts[k]]) for k in range(len(verts))])
+    exp, _ = oracle.fill(host.cell, oracle.wrap_points(host.cell, frames), np.where(sm)[0], np.where(mm)[0], ref[sm],
+                         verts, vcd, check_for_zeros=False)
+    got = ctx.rows_dense()
+    assert np.array_equal(got != 0, exp != 0)
+    np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
