@@ -617,12 +617,16 @@ int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, 
     a.thr2_hi = c->static_thr * c->static_thr * (1.0 + 1e-14);
     // frames per workgroup: about one 32-ion chunk per wave, within the LDS budget
     int nw = 4;
-    i64 fpb = (nw * F2_IW) / M; if (fpb < 1) fpb = 1; if (fpb > 32) fpb = 32;
-    while (fpb > 1 && fill2_lds_bytes(S, M, (int)fpb, nw) > 64 * 1024) fpb--;
+    auto frames_per_group = [&](int waves) {
+        i64 f = (waves * F2_IW) / M; if (f < 1) f = 1; if (f > 32) f = 32;
+        while (f > 1 && fill2_lds_bytes(S, M, (int)f, waves) > (waves == 4 ? 64 : 79) * 1024) f--;
+        return f;
+    };
+    i64 fpb = frames_per_group(4);
     // a big frame leaves room for two or three 4-wave workgroups per CU (160 KB LDS): eight waves per workgroup on the
     // same statics restore the 16 waves per CU, provided the frame has ions for them
     if (fpb == 1 && fill2_lds_bytes(S, M, 1, 4) > 40 * 1024 && M >= 6 * F2_IW && fill2_lds_bytes(S, M, 1, 8) <= 79 * 1024) nw = 8;
-    { const char *e = getenv("SITATOR_FILL_WAVES"); if (e && (atoi(e) == 4 || atoi(e) == 8)) nw = atoi(e); }
+    { const char *e = getenv("SITATOR_FILL_WAVES"); if (e && (atoi(e) == 4 || atoi(e) == 8)) { nw = atoi(e); fpb = frames_per_group(nw); } }
     a.fpb = (int)fpb; c->last_fpb = (int)fpb;
     const size_t lds = fill2_lds_bytes(S, M, (int)fpb, nw);
     SIT_REQUIRE(c, lds <= 158 * 1024, "sit_fill: one frame's atoms do not fit in LDS");
