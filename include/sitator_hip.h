@@ -108,13 +108,14 @@ typedef struct sit_fill_params {
     int32_t relaxed_lattice_checks;    /* helpers.pyx:87       */
     int32_t check_for_zeros;           /* helpers.pyx:116-120  */
     int32_t store_rows;                /* keep the sparse rows on the device (fit / mcl)   */
-    int32_t assign;                    /* fuse DotProdClassifier.predict (needs centres)   */
+    int32_t assign;                    /* run DotProdClassifier.predict behind the fill in the same call (needs centres) */
     int32_t predict_normed;            /* util/DotProdClassifier.pyx:155-161               */
     double  predict_threshold;         /* util/DotProdClassifier.pyx:184                   */
 } sit_fill_params;
 
 /* One streaming pass over the resident frames: wrap, static-lattice check, landmark vector
- * per (frame, ion), optional fused assignment.  n_all_zero = self.n_all_zero_lvecs.
+ * per (frame, ion); with `assign` the site assignment is enqueued behind it without a host round trip.
+ * n_all_zero = self.n_all_zero_lvecs.
  * On a domain error returns its status and fills *err.                                    */
 int sit_fill(sit_ctx *ctx, const sit_fill_params *p, int64_t *n_all_zero, sit_error *err);
 
