@@ -126,34 +126,41 @@ __device__ int ff_decide(const FFState &s, const FFRows &r, i64 row, double thre
 }
 
 // ---- lane-per-row helpers: no dependent chains of global loads -------------------------------------------
-// First eight support entries of a centre (or of one of its versions) in registers, the rest behind pointers.
-struct Sup8 {
-    i32 ix[8];
-    double vv[8];
+// First NS support entries of a centre (or of one of its versions) in registers, the rest behind pointers.
+// NS = 8 for narrow landmark bases (C2: supports of ~8), 16 for wide ones (FCC-like: ragged rows of 5-13 entries).
+template <int NS>
+struct Sup {
+    i32 ix[NS];
+    double vv[NS];
     int sn;
     const i32 *pix;
     const double *pvv;
 };
 
-__device__ __forceinline__ void sup_load(Sup8 &S, const i32 *ix, const double *vv, int sn)
+template <int NS>
+__device__ __forceinline__ void sup_load(Sup<NS> &S, const i32 *ix, const double *vv, int sn)
 {
     // rows of cs_idx / vs_idx are 256-byte aligned, rows of cs_val / vs_val 512-byte aligned
-    const int4 a = *(const int4 *)ix, b = *(const int4 *)(ix + 4);
-    const double2 v0 = *(const double2 *)vv, v1 = *(const double2 *)(vv + 2), v2 = *(const double2 *)(vv + 4), v3 = *(const double2 *)(vv + 6);
-    S.ix[0] = a.x; S.ix[1] = a.y; S.ix[2] = a.z; S.ix[3] = a.w; S.ix[4] = b.x; S.ix[5] = b.y; S.ix[6] = b.z; S.ix[7] = b.w;
-    S.vv[0] = v0.x; S.vv[1] = v0.y; S.vv[2] = v1.x; S.vv[3] = v1.y; S.vv[4] = v2.x; S.vv[5] = v2.y; S.vv[6] = v3.x; S.vv[7] = v3.y;
+#pragma unroll
+    for (int q = 0; q < NS; q += 4) {
+        const int4 a = *(const int4 *)(ix + q);
+        const double2 v0 = *(const double2 *)(vv + q), v1 = *(const double2 *)(vv + q + 2);
+        S.ix[q] = a.x; S.ix[q + 1] = a.y; S.ix[q + 2] = a.z; S.ix[q + 3] = a.w;
+        S.vv[q] = v0.x; S.vv[q + 1] = v0.y; S.vv[q + 2] = v1.x; S.vv[q + 3] = v1.y;
+    }
     S.sn = sn; S.pix = ix; S.pvv = vv;
 }
 
 // value of the support at dimension d; hit = false when d is outside it
-__device__ __forceinline__ double sup_at(const Sup8 &S, i32 d, bool &hit)
+template <int NS>
+__device__ __forceinline__ double sup_at(const Sup<NS> &S, i32 d, bool &hit)
 {
     double cv = 0.0;
     hit = false;
 #pragma unroll
-    for (int q = 0; q < 8; q++) if (q < S.sn && S.ix[q] == d) { cv = S.vv[q]; hit = true; }
-    if (!hit && S.sn > 8 && d > S.ix[7])
-        for (int q = 8; q < S.sn; q++) {
+    for (int q = 0; q < NS; q++) if (q < S.sn && S.ix[q] == d) { cv = S.vv[q]; hit = true; }
+    if (!hit && S.sn > NS && d > S.ix[NS - 1])
+        for (int q = NS; q < S.sn; q++) {
             const i32 t = S.pix[q];
             if (t == d) { cv = S.pvv[q]; hit = true; break; }
             if (t > d) break;
@@ -162,40 +169,44 @@ __device__ __forceinline__ double sup_at(const Sup8 &S, i32 d, bool &hit)
 }
 
 // norm of the support (:288): ascending sum of squares
-__device__ __forceinline__ double sup_norm(const Sup8 &S)
+template <int NS>
+__device__ __forceinline__ double sup_norm(const Sup<NS> &S)
 {
     double s2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; q++) if (q < S.sn) s2 += S.vv[q] * S.vv[q];
-    for (int q = 8; q < S.sn; q++) { const double v = S.pvv[q]; s2 += v * v; }
+    for (int q = 0; q < NS; q++) if (q < S.sn) s2 += S.vv[q] * S.vv[q];
+    for (int q = NS; q < S.sn; q++) { const double v = S.pvv[q]; s2 += v * v; }
     return sqrt(s2);
 }
 
-// A row's entries: the first four in registers.
-struct Row4 {
+// A row's entries: the first NR in registers.
+template <int NR>
+struct Row {
     int n;
-    i32 i[4];
-    double v[4];
+    i32 i[NR];
+    double v[NR];
 };
 
-__device__ __forceinline__ void row_load(Row4 &R, const FFRows &r, i64 row)
+template <int NR>
+__device__ __forceinline__ void row_load(Row<NR> &R, const FFRows &r, i64 row)
 {
     R.n = r.nnz[row];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
+    for (int e = 0; e < NR; e++) {
         R.i[e] = 0; R.v[e] = 0.0;
-        if (e < r.width) { R.i[e] = r.idx[(i64)e * r.stride + row]; R.v[e] = r.val[(i64)e * r.stride + row]; }
+        if (e < r.width && (e < 4 || e < R.n)) { R.i[e] = r.idx[(i64)e * r.stride + row]; R.v[e] = r.val[(i64)e * r.stride + row]; }
     }
 }
 
 // cos numerator: dot of the row with a support, ascending dimension order (:238)
-__device__ __forceinline__ double row_dot(const Row4 &R, const FFRows &r, i64 row, const Sup8 &S)
+template <int NR, int NS>
+__device__ __forceinline__ double row_dot(const Row<NR> &R, const FFRows &r, i64 row, const Sup<NS> &S)
 {
     double dot = 0.0;
 #pragma unroll
-    for (int e = 0; e < 4; e++)
+    for (int e = 0; e < NR; e++)
         if (e < R.n) { bool hit; const double cv = sup_at(S, R.i[e], hit); if (hit) dot += cv * R.v[e]; }
-    for (int e = 4; e < R.n; e++) {
+    for (int e = NR; e < R.n; e++) {
         bool hit;
         const double cv = sup_at(S, r.idx[(i64)e * r.stride + row], hit);
         if (hit) dot += cv * r.val[(i64)e * r.stride + row];
@@ -253,6 +264,7 @@ struct OvSet {
 // ---- A: speculate ---------------------------------------------------------------------------------
 // ff_decide for a lane per row: the overlap set lives in registers / LDS and supports are fetched with wide
 // loads, so that a row costs a handful of memory round trips instead of a hundred dependent ones.
+template <int NR, int NS>
 __global__ __launch_bounds__(256) void k_ff_speculate(FFState s, FFRows r, FFBatch b, i64 row0, int nb, double threshold)
 {
     __shared__ i32 ovx[(FF_OC - 8) * 256];
@@ -260,13 +272,13 @@ __global__ __launch_bounds__(256) void k_ff_speculate(FFState s, FFRows r, FFBat
     if (j >= nb) return;
     const int K = *s.K;
     const i64 row = row0 + j;
-    Row4 R;
+    Row<NR> R;
     row_load(R, r, row);
     const int n = R.n;
     double x2 = 0.0;
 #pragma unroll
-    for (int e = 0; e < 4; e++) if (e < n) x2 += R.v[e] * R.v[e];
-    for (int e = 4; e < n; e++) { const double v = r.val[(i64)e * r.stride + row]; x2 += v * v; }
+    for (int e = 0; e < NR; e++) if (e < n) x2 += R.v[e] * R.v[e];
+    for (int e = NR; e < n; e++) { const double v = r.val[(i64)e * r.stride + row]; x2 += v * v; }
     const double xn = sqrt(x2);
     OvSet ov;
     ov.init(ovx + threadIdx.x);
@@ -276,10 +288,9 @@ __global__ __launch_bounds__(256) void k_ff_speculate(FFState s, FFRows r, FFBat
         bool brk = false;
         for (int e = 0; e < n && !brk; e++) {
             i32 d = R.i[0];
-            if (e == 1) d = R.i[1];
-            if (e == 2) d = R.i[2];
-            if (e == 3) d = R.i[3];
-            if (e > 3) d = r.idx[(i64)e * r.stride + row];
+#pragma unroll
+            for (int q = 1; q < NR; q++) if (e == q) d = R.i[q];
+            if (e >= NR) d = r.idx[(i64)e * r.stride + row];
             const int m = s.dc_n[d];
             if (m > FF_DC) { brk = true; break; }
             const i32 *dl = s.dc_list + (i64)d * FF_DC;
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(256) void k_ff_speculate(FFState s, FFRows r, FFBat
             Best best = best_empty();
             for (int p = 0; p < nov; p++) {
                 const i32 c = ov.at(p);
-                Sup8 S;
+                Sup<NS> S;
                 sup_load(S, s.cs_idx + (i64)c * FF_CS, s.cs_val + (i64)c * FF_CS, s.cs_n[c]);
                 double dot = row_dot(R, r, row, S);
                 dot /= s.c_nrm[c];                            // :239
@@ -384,15 +395,17 @@ struct Walker {
     }
     // Row jj (all arguments wave-uniform) joins this centre: running-mean update (:283-288), then the new state
     // is published as version jj.  false = a capacity was hit (the walk is void from jj on).
-    // WIDE = rows may hold more than four entries (the rest is read from memory).  The narrow instance has no
-    // load in it: on gfx9 stores and loads share vmcnt, so a single load anywhere in the join loop would make
-    // every join wait for the previous join's version stores.
-    template <bool WIDE>
+    // MODE 0: rows of at most four entries, all in registers.  MODE 1: up to twelve, entries 4..11 staged in LDS by
+    // group().  MODE 2: anything, entries beyond the fourth read from memory.  Modes 0 and 1 have no global load in
+    // them: on gfx9 stores and loads share vmcnt, so a single load anywhere in the join loop would make every join
+    // wait for the previous join's version stores.
+    template <int MODE>
     __device__ __forceinline__ bool join(const FFRows &r, const FFBatch &b, i64 row, int jj, int n, i64 w,
-                                         i32 qi0, i32 qi1, i32 qi2, i32 qi3, double qv0, double qv1, double qv2, double qv3)
+                                         i32 qi0, i32 qi1, i32 qi2, i32 qi3, double qv0, double qv1, double qv2, double qv3,
+                                         const i32 *xi, const double *xv)
     {
-#define ROW_IDX(e) ((e) == 0 ? qi0 : (e) == 1 ? qi1 : (e) == 2 ? qi2 : (!WIDE || (e) == 3) ? qi3 : r.idx[(i64)(e) * r.stride + row])
-#define ROW_VAL(e) ((e) == 0 ? qv0 : (e) == 1 ? qv1 : (e) == 2 ? qv2 : (!WIDE || (e) == 3) ? qv3 : r.val[(i64)(e) * r.stride + row])
+#define ROW_IDX(e) ((e) == 0 ? qi0 : (e) == 1 ? qi1 : (e) == 2 ? qi2 : (MODE == 0 || (e) == 3) ? qi3 : MODE == 1 ? xi[(e) - 4] : r.idx[(i64)(e) * r.stride + row])
+#define ROW_VAL(e) ((e) == 0 ? qv0 : (e) == 1 ? qv1 : (e) == 2 ? qv2 : (MODE == 0 || (e) == 3) ? qv3 : MODE == 1 ? xv[(e) - 4] : r.val[(i64)(e) * r.stride + row])
         const double fo = cnt, fn = cnt + (double)w;          // exact: integers below 2^53
         val *= fo;
         for (int e = 0; e < n; e++) {
@@ -428,7 +441,8 @@ struct Walker {
     }
 
     // One group of <= 64 joining rows, ascending by lane.
-    __device__ __forceinline__ bool group(const FFRows &r, const FFBatch &b, i64 row0, int j, bool isjoin)
+    // xi / xv: wave-private LDS staging, [64][8] each, for row entries 4..11
+    __device__ __forceinline__ bool group(const FFRows &r, const FFBatch &b, i64 row0, int j, bool isjoin, i32 *xi, double *xv)
     {
         FF_T(t0);
         int n = 0;
@@ -450,21 +464,38 @@ struct Walker {
         asm volatile("" :: "v"(n), "v"(w), "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
         FF_T(t1);
         FF_ACC(1, t1 - t0);
-        if (__ballot(n > 4) == 0) {
+        const unsigned long long over4 = __ballot(n > 4), over12 = __ballot(n > 12);
+        if (over4 == 0) {
             while (jm) {
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)jm) - 1);
                 jm &= jm - 1;
                 const int jj = bc_i(j, src);
-                if (!join<false>(r, b, row0 + jj, jj, bc_i(n, src), bc_l(w, src), bc_i(i0, src), bc_i(i1, src), bc_i(i2, src),
-                                 bc_i(i3, src), bc_d(v0, src), bc_d(v1, src), bc_d(v2, src), bc_d(v3, src))) return false;
+                if (!join<0>(r, b, row0 + jj, jj, bc_i(n, src), bc_l(w, src), bc_i(i0, src), bc_i(i1, src), bc_i(i2, src),
+                             bc_i(i3, src), bc_d(v0, src), bc_d(v1, src), bc_d(v2, src), bc_d(v3, src), nullptr, nullptr)) return false;
+            }
+        } else if (over12 == 0) {
+            // stage entries 4..11 of every joining row in LDS (one trip to memory for the whole group)
+            if (isjoin)
+                for (int e = 4; e < n; e++) {
+                    xi[lane * 8 + e - 4] = r.idx[(i64)e * r.stride + row0 + j];
+                    xv[lane * 8 + e - 4] = r.val[(i64)e * r.stride + row0 + j];
+                }
+            __builtin_amdgcn_s_waitcnt(0);                      // vmcnt(0) expcnt(0) lgkmcnt(0): staged before the loop
+            __builtin_amdgcn_wave_barrier();
+            while (jm) {
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)jm) - 1);
+                jm &= jm - 1;
+                const int jj = bc_i(j, src);
+                if (!join<1>(r, b, row0 + jj, jj, bc_i(n, src), bc_l(w, src), bc_i(i0, src), bc_i(i1, src), bc_i(i2, src),
+                             bc_i(i3, src), bc_d(v0, src), bc_d(v1, src), bc_d(v2, src), bc_d(v3, src), xi + src * 8, xv + src * 8)) return false;
             }
         } else {
             while (jm) {
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)jm) - 1);
                 jm &= jm - 1;
                 const int jj = bc_i(j, src);
-                if (!join<true>(r, b, row0 + jj, jj, bc_i(n, src), bc_l(w, src), bc_i(i0, src), bc_i(i1, src), bc_i(i2, src),
-                                bc_i(i3, src), bc_d(v0, src), bc_d(v1, src), bc_d(v2, src), bc_d(v3, src))) return false;
+                if (!join<2>(r, b, row0 + jj, jj, bc_i(n, src), bc_l(w, src), bc_i(i0, src), bc_i(i1, src), bc_i(i2, src),
+                             bc_i(i3, src), bc_d(v0, src), bc_d(v1, src), bc_d(v2, src), bc_d(v3, src), nullptr, nullptr)) return false;
             }
         }
         FF_T(t2);
@@ -480,6 +511,8 @@ struct Walker {
 __global__ __launch_bounds__(256) void k_ff_walk(FFState s, FFState o, FFRows r, FFBatch b, i64 row0, int nb)
 {
     __shared__ i32 ent[FF_LCAP];
+    __shared__ i32 xi[64 * 8];
+    __shared__ double xv[64 * 8];
     {   // the batch ends before the first row that founds a cluster (speculation ran just before)
         const int fn = *b.first_new;
         if (fn < nb) nb = fn;
@@ -506,7 +539,7 @@ __global__ __launch_bounds__(256) void k_ff_walk(FFState s, FFState o, FFRows r,
             filled += __popcll(jm);
             if (dead || !jm) continue;
             if (j0 > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;   // void rows
-            dead = !wk.group(r, b, row0, j, isjoin);
+            dead = !wk.group(r, b, row0, j, isjoin, xi, xv);
         }
         // joins past the cut of the batch are not listed: step C never looks past the cut either
         for (int t = filled + lane; t < n_ent; t += 64) b.lent[lo + t] = 0x7fffffff;
@@ -539,7 +572,7 @@ __global__ __launch_bounds__(256) void k_ff_walk(FFState s, FFState o, FFRows r,
         const int nvalid = __popcll(__ballot(valid));      // sorted by row: the valid entries are a prefix
         if (nvalid == 0) break;
         if (bc_i(j, 0) > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        if (!wk.group(r, b, row0, j, valid)) return;
+        if (!wk.group(r, b, row0, j, valid, xi, xv)) return;
         if (nvalid < 64) break;
     }
     wk.store(o);
@@ -574,6 +607,7 @@ __global__ __launch_bounds__(256) void k_ff_scatter(FFBatch b, int nb)
 }
 
 // ---- C: verify ---------------------------------------------------------------------------------------
+template <int NR, int NS>
 __global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFRows r, FFBatch b, i64 row0, int nb, double threshold)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -585,7 +619,7 @@ __global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFRows r, FFBatch 
     const int K = *s.K;
     const int m = b.ov_n[j];
     const i64 row = row0 + j;
-    Row4 R;
+    Row<NR> R;
     row_load(R, r, row);
     const int n = R.n;
     const double xn = b.xn[j];
@@ -601,7 +635,7 @@ __global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFRows r, FFBatch 
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (jl[mid] < j) lo = mid + 1; else hi = mid; }
             if (lo > 0) pj = jl[lo - 1];
         }
-        Sup8 S;
+        Sup<NS> S;
         double nrm;
         if (pj < 0) {
             sup_load(S, s.cs_idx + (i64)cc * FF_CS, s.cs_val + (i64)cc * FF_CS, s.cs_n[cc]);
@@ -892,6 +926,9 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
     i64 pos = 0;
     int B = 256;
     i32 K = 0;
+    // wide landmark bases (ragged rows, supports beyond eight entries): the lane-per-row kernels keep 8 row entries
+    // and 16 support entries in registers instead of 4 and 8
+    const bool wide = width > 6 && (c->W_tight > 8 || (c->W_tight == 0 && width > 12));
     HIP_TRY(c, hipMemcpyAsync(&K, f->st.K, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const i32 big2[3] = {0x7fffffff, 0x7fffffff, 0};     // first_new, first_bad, log_n
@@ -930,12 +967,14 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
             HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 12, hipMemcpyHostToDevice, c->stream));
         }
         const int nb = (int)((nrows - pos) < B ? (nrows - pos) : B);
-        k_ff_speculate<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
+        if (wide) k_ff_speculate<8, 16><<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
+        else k_ff_speculate<4, 8><<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
         if (K > 0) {
             k_ff_list_offsets<<<dim3(1), dim3(256), 0, c->stream>>>(f->st, f->bt);
             k_ff_scatter<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->bt, nb);
             k_ff_walk<<<dim3((unsigned)K), dim3(256), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, nb);
-            k_ff_verify<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
+            if (wide) k_ff_verify<8, 16><<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
+            else k_ff_verify<4, 8><<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
         }
         HIP_TRY(c, hipGetLastError());
         { int rc = readback(); if (rc) return rc; }
