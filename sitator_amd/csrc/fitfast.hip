@@ -692,6 +692,8 @@ __global__ void k_ff_apply_growth(FFState s, FFBatch b)
 // One thread, `count` rows in order, same arithmetic.  Stops (status) when a capacity is exceeded.
 __global__ void k_ff_serial(FFState s, FFRows r, FFBatch b, i64 row0, int count, double threshold, i32 *scratch_ov)
 {
+    __shared__ i32 ovl[FF_OC];        // overlap list of the row being decided (LDS: the insertion sort is latency-bound)
+    (void)scratch_ov;
     if (threadIdx.x || blockIdx.x) return;
     int K = *s.K;
     int processed = 0;
@@ -701,7 +703,7 @@ __global__ void k_ff_serial(FFState s, FFRows r, FFBatch b, i64 row0, int count,
         const i64 w = r.weights ? r.weights[row] : 1;
         int nov;
         double xn;
-        int dec = ff_decide(s, r, row, threshold, K, scratch_ov, 1, nov, xn);
+        int dec = ff_decide(s, r, row, threshold, K, ovl, 1, nov, xn);
         if (dec == FF_BREAK) { s.flags[0] = 1; break; }
         if (dec == FF_NEW) {                                          // :250-260
             if (K >= s.Kcap || n > FF_CS) { s.flags[0] = 1; break; }
