@@ -17,6 +17,7 @@
 //   * diagonal cells skip the exactly-zero terms of the 3x3 products (x*a + y*0 + z*0 == x*a).
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "sit_internal.h"
 
@@ -598,6 +599,7 @@ int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, 
     const i64 S = c->S, M = c->M;
     SIT_REQUIRE(c, c->D * c->V < (1LL << 31) && c->F * S < (1LL << 40) && c->A < (1LL << 25), "sit_fill: sizes too large");
     Fill2Args a;
+    memset(&a, 0, sizeof(a));          // padding bytes too: the block is compared with its last upload
     a.P = c->pbc; a.frames = c->d_frames; a.static_idx = c->d_static_idx; a.mobile_idx = c->d_mobile_idx;
     a.ref_static = c->d_ref_static; a.verts = c->d_verts; a.vcd = c->d_vcd; a.hi2 = c->d_hi2;
     a.t_off = c->d_tbin_off; a.t_list = c->d_tbin_list; a.l_off = c->d_bin_off; a.l_list = c->d_bin_list;
@@ -636,8 +638,16 @@ int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, 
     h.frame_dmax = a.frame_dmax; h.err = a.err; h.scal = a.scal; h.F = a.F; h.A = a.A; h.frame0 = a.frame0;
     h.S = a.S; h.M = a.M; h.fpb = a.fpb; h.dyn = a.lattice_map != nullptr; h.debug_stop = a.debug_stop;
     h.delta2 = a.delta2; h.thr2_lo = a.thr2_lo; h.thr2_hi = a.thr2_hi; h.static_thr = a.static_thr;
-    if (!c->d_fill_args) { int rc = dev_alloc(c, &c->d_fill_args, (i64)sizeof(Fill2Args)); if (rc) return rc; }
-    HIP_TRY(c, hipMemcpyAsync(c->d_fill_args, &a, sizeof(Fill2Args), hipMemcpyHostToDevice, c->stream));
+    if (!c->d_fill_args) {
+        int rc = dev_alloc(c, &c->d_fill_args, (i64)sizeof(Fill2Args));
+        if (rc) return rc;
+        c->fill_args_host.clear();
+    }
+    if (c->fill_args_host.size() != sizeof(Fill2Args) || memcmp(c->fill_args_host.data(), &a, sizeof(Fill2Args)) != 0) {
+        // the device copy is refreshed only when an argument changed (repeated passes over the same residency)
+        c->fill_args_host.assign((const char *)&a, (const char *)&a + sizeof(Fill2Args));
+        HIP_TRY(c, hipMemcpyAsync(c->d_fill_args, c->fill_args_host.data(), sizeof(Fill2Args), hipMemcpyHostToDevice, c->stream));
+    }
     const Fill2ArgsPtr full = (Fill2ArgsPtr)c->d_fill_args;
     const bool diag = c->cell_diagonal;
     const int lg = c->Vp == 8 ? 3 : (c->Vp == 4 ? 2 : 0);

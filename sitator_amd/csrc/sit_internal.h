@@ -52,6 +52,7 @@ struct sit_ctx {
     // tight table: built for the static displacement actually present (fill2.hip)
     int tG[3] = {1, 1, 1};
     i32 *d_tbin_off = nullptr, *d_tbin_list = nullptr;
+    std::vector<char> fill_args_host; // last uploaded copy of that block
     char *d_fill_args = nullptr;     // device copy of the fill kernel's argument block (read with scalar loads)
     i64 W_tight = 0;
     double tight_delta = 0, tight_mean_candidates = 0;
