@@ -384,6 +384,65 @@ def next_tier_cases(ref):
     print("next_tier_known_answers %.1f KB" % (os.path.getsize(path) / 1024.0))
 
 
+def merge_cases(ref):
+    """Golden outputs of MergeSitesByDynamics on site trajectories of the pipeline
+    goldens.  The reference's constructor reads an undefined global ``iterlimit`` (dynamics/MergeSitesByDynamics.py:54);
+    the harness defines that name in the module before constructing - nothing of the reference is edited."""
+    import ase
+    import sitator.dynamics
+    from sitator import SiteNetwork, SiteTrajectory
+    from sitator.dynamics import JumpAnalysis
+    sys.modules["sitator.dynamics.MergeSitesByDynamics"].iterlimit = 100
+    MergeSitesByDynamics = sitator.dynamics.MergeSitesByDynamics
+    blob = {}
+    names = []
+    variants = [
+        ("noop", dict(distance_threshold=1.0), "n_ij", None),
+        ("t25", dict(distance_threshold=2.5), "n_ij", None),
+        ("t45_inflation", dict(distance_threshold=4.5, markov_parameters={"inflation": 1.3}), "n_ij", None),
+        ("lagbiased", dict(distance_threshold=3.0), "jump_lag_biased", dict(jump_lag_sigma=15.0, distance_sigma=1.5)),
+        ("t8_loose", dict(distance_threshold=8.0, post_check_thresh_factor=0.5, markov_parameters={"inflation": 1.2}), "n_ij", None),
+    ]
+    for name, tag in (("c1_hex_scgrid", "dotprod"), ("c1b_tri_bcctet", "mcl"), ("bcc_ortho", "dotprod")):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=True)
+        lab, cen, cell = z[tag + "/labels"], z[tag + "/site_centers"], z["cell"]
+        sm, mm, refp = z["static_mask"], z["mobile_mask"], z["ref_positions"]
+        at = ase.Atoms(positions=refp, numbers=np.where(mm, 3, 8), cell=cell)
+        names.append(name)
+        blob[name + "/labels"] = lab
+        blob[name + "/centers"] = cen
+        blob[name + "/cell"] = cell
+        blob[name + "/static_mask"] = sm
+        blob[name + "/mobile_mask"] = mm
+        blob[name + "/ref_positions"] = refp
+        for vname, kw, conn, jlp in variants:
+            sn = SiteNetwork(at, sm, mm)
+            sn.centers = cen.copy()
+            st = SiteTrajectory(sn, lab.copy())
+            key = "%s/%s" % (name, vname)
+            kwargs = dict(kw)
+            if conn == "jump_lag_biased":
+                kwargs["connectivity_matrix_generator"] = MergeSitesByDynamics.connectivity_jump_lag_biased(**jlp)
+            blob[key + "/params"] = json.dumps({"kw": kw, "connectivity": conn, "jump_lag_params": jlp})
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                JumpAnalysis().run(st)
+                try:
+                    out = MergeSitesByDynamics(check_types=False, **kwargs).run(st)
+                    blob[key + "/error"] = ""
+                    blob[key + "/centers"] = np.asarray(out.site_network.centers)
+                    blob[key + "/traj"] = out.traj.copy()
+                    print("merge", key, len(cen), "->", out.site_network.n_sites)
+                except Exception as e:                       # noqa: BLE001 - the class name is the golden
+                    blob[key + "/error"] = type(e).__name__
+                    print("merge", key, type(e).__name__)
+    blob["names"] = np.array(names)
+    blob["variants"] = np.array([v[0] for v in variants])
+    path = os.path.join(GOLDEN, "merge_known_answers.npz")
+    np.savez_compressed(path, **blob)
+    print("merge_known_answers %.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
 def main():
     if not ref_build.available():
         print("reference not present; fixtures can only be generated in the development container")
@@ -392,11 +451,16 @@ def main():
     os.makedirs(GOLDEN, exist_ok=True)
     if "--next-only" in sys.argv:
         next_tier_cases(ref)
+        merge_cases(ref)
+        return 0
+    if "--merge-only" in sys.argv:
+        merge_cases(ref)
         return 0
     pbc_cases(ref)
     dotprod_cases(ref)
     pipeline_cases(ref)
     next_tier_cases(ref)
+    merge_cases(ref)
     return 0
 
 

@@ -473,3 +473,72 @@ def recenter(arr, masses, factors, add=None):
     if add is not None:
         arr += add
     return arr
+
+
+def merge_sites_by_dynamics(cell, centers, traj, n_mobile, jump_stats=None, connectivity="n_ij",
+                            distance_threshold=1.0, post_check_thresh_factor=1.5, markov_parameters=None,
+                            vertices=None, weighted_spatial_average=True, occupancies=None,
+                            jump_lag_params=None):
+    """dynamics/MergeSitesByDynamics.py:109-153 + network/merging.py:46-131 with check_types=False.
+
+    Returns (new_centers, new_traj, translation, new_vertices).  ``jump_stats``: output of ``jump_analysis`` (computed
+    here when None, as :113-115 do).  ``connectivity``: "n_ij" (:61-66) or "jump_lag_biased" (:69-107)."""
+    cell = np.asarray(cell, dtype=np.float64)
+    centers = np.asarray(centers, dtype=np.float64)
+    traj = np.asarray(traj)
+    K = len(centers)
+    if jump_stats is None:
+        jump_stats = jump_analysis(traj, K)
+    if connectivity == "n_ij":
+        cm = np.array(jump_stats["n_ij"], dtype=np.float64)
+    else:
+        jp = dict(jump_lag_coeff=1.0, jump_lag_sigma=20.0, jump_lag_cutoff=np.inf, distance_coeff=0.5, distance_sigma=1.0)
+        jp.update(jump_lag_params or {})
+        jl = np.array(jump_stats["jump_lag"], dtype=np.float64)
+        jl -= 1.0
+        jl /= jp["jump_lag_sigma"]
+        np.square(jl, out=jl)
+        jl *= -0.5
+        np.exp(jl, out=jl)
+        jl[np.asarray(jump_stats["jump_lag"]) > jp["jump_lag_cutoff"]] = 0.
+        dmat = np.zeros((K, K))                                    # util/PBCCalculator.pyx:43-61
+        for i in range(K - 1):
+            dmat[i, i + 1:] = distances(cell, centers[i], centers[i + 1:])
+            dmat[i + 1:, i] = dmat[i, i + 1:]
+        dmat /= jp["distance_sigma"]
+        np.square(dmat, out=dmat)
+        dmat *= -0.5
+        np.exp(dmat, out=dmat)
+        cm = (np.asarray(jump_stats["p_ij"]) + jp["jump_lag_coeff"] * jl) * (jp["distance_coeff"] * dmat + (1 - jp["distance_coeff"]))
+    for i in range(K):                                            # :139-147
+        rest = centers[i + 1:]
+        d = distances(cell, centers[i], rest) if len(rest) else np.zeros(0)
+        far = np.where(d > distance_threshold)[0] + i + 1
+        cm[i, far] = 0
+        cm[far, i] = 0
+    clusters = markov_clustering(cm, **(markov_parameters or {}))    # :153
+    # network/merging.py:57-131
+    new_n = len(clusters)
+    if new_n < n_mobile:
+        raise OracleError("InsufficientSitesError", n_sites=new_n, n_mobile=n_mobile)
+    max_dist = post_check_thresh_factor * distance_threshold
+    translation = np.full(K, -1, dtype=np.int64)
+    new_centers = np.empty((new_n, 3))
+    new_verts = []
+    for s, cl in enumerate(clusters):
+        mask = list(cl)
+        assert not np.any(translation[mask] != -1)
+        translation[mask] = s
+        pts = centers[mask]
+        if max_dist is not None and len(pts) > 1:
+            if not np.all(distances(cell, pts[0], pts[1:]) <= max_dist):
+                raise OracleError("MergedSitesTooDistantError", max_distance=max_dist)
+        if weighted_spatial_average:                              # (sic, :94-98)
+            new_centers[s] = average(cell, pts)
+        else:
+            new_centers[s] = average(cell, pts, np.asarray(occupancies)[mask])
+        if vertices is not None:
+            new_verts.append(sorted(set().union(*[set(vertices[i]) for i in mask])))
+    new_traj = translation[traj]
+    new_traj[traj == -1] = -1
+    return new_centers, new_traj, translation, (new_verts if vertices is not None else None)

@@ -13,7 +13,8 @@ from .site_trajectory import SiteTrajectory  # noqa: F401
 from .pbc import PBCCalculator  # noqa: F401
 from .dotprod_classifier import DotProdClassifier, LandmarkVectors  # noqa: F401
 from .landmark import LandmarkAnalysis  # noqa: F401
-from .dynamics import JumpAnalysis, SmoothSiteTrajectory  # noqa: F401
+from .dynamics import JumpAnalysis, MergeSitesByDynamics, SmoothSiteTrajectory  # noqa: F401
+from .merging import MergeSites, MergeSitesError, MergedSitesTooDistantError  # noqa: F401
 from .recenter import RecenterTrajectory  # noqa: F401
 
 __version__ = "0.1.0"

@@ -3,11 +3,16 @@ device-resident site assignments:
 
 * ``JumpAnalysis``  (reference ``sitator/dynamics/JumpAnalysis.py:11-135``)
 * ``SmoothSiteTrajectory``  (reference ``sitator/dynamics/SmoothSiteTrajectory.pyx:13-111``)
+* ``MergeSitesByDynamics``  (reference ``sitator/dynamics/MergeSitesByDynamics.py:12-153``; host logic over the jump
+  statistics, distances and averages through the device-backed ``PBCCalculator``)
 """
 import logging
 
 import numpy as np
 
+from .markov import markov_clustering
+from .merging import MergeSites
+from .pbc import PBCCalculator
 from .site_trajectory import SiteTrajectory
 
 logger = logging.getLogger(__name__)
@@ -114,3 +119,85 @@ class SmoothSiteTrajectory(object):
                 new._sn = newsn
         new.site_network.clear_attributes()
         return new
+
+
+class MergeSitesByDynamics(MergeSites):
+    """Merges sites that exchange particles, by Markov clustering of a connectivity matrix from the jump statistics
+    (reference ``dynamics/MergeSitesByDynamics.py``).
+
+    ``distance_threshold``: connectivity between sites further apart than this (Angstrom) is zeroed;
+    ``post_check_thresh_factor``: merged sites further apart than factor x threshold raise
+    ``MergedSitesTooDistantError``; ``markov_parameters``: ``inflation`` / ``expansion`` / ``pruning_threshold`` for
+    ``markov_clustering``.  The reference's constructor reads an undefined ``iterlimit`` (:54, a ``NameError`` there);
+    here it is an ordinary keyword that, as in the reference's body, is stored and not used."""
+
+    def __init__(self, connectivity_matrix_generator=None, distance_threshold=1.0, post_check_thresh_factor=1.5,
+                 check_types=True, markov_parameters={}, iterlimit=100):
+        super(MergeSitesByDynamics, self).__init__(
+            maximum_merge_distance=post_check_thresh_factor * distance_threshold, check_types=check_types)
+        if connectivity_matrix_generator is None:
+            connectivity_matrix_generator = MergeSitesByDynamics.connectivity_n_ij
+        assert callable(connectivity_matrix_generator)
+        self.connectivity_matrix_generator = connectivity_matrix_generator
+        self.distance_threshold = distance_threshold
+        self.post_check_thresh_factor = post_check_thresh_factor
+        self.check_types = check_types
+        self.iterlimit = iterlimit
+        self.markov_parameters = markov_parameters
+
+    # -- connectivity matrix generators (:59-107)
+    @staticmethod
+    def connectivity_n_ij(sn):
+        """``n_ij`` itself as connectivity."""
+        return sn.n_ij
+
+    @staticmethod
+    def connectivity_jump_lag_biased(jump_lag_coeff=1.0, jump_lag_sigma=20.0, jump_lag_cutoff=np.inf,
+                                     distance_coeff=0.5, distance_sigma=1.0):
+        """``p_ij`` biased by Gaussians of the jump lag and of the distance between the sites (:69-107)."""
+        def cfunc(sn):
+            jl = np.array(sn.jump_lag, dtype=np.float64)
+            jl -= 1.0                                   # the minimum lag is one frame
+            jl /= jump_lag_sigma
+            np.square(jl, out=jl)
+            jl *= -0.5
+            np.exp(jl, out=jl)                          # -inf -> 0
+            jl[np.asarray(sn.jump_lag) > jump_lag_cutoff] = 0.
+            pbccalc = PBCCalculator(np.asarray(sn.structure.cell, dtype=np.float64))
+            dmat = pbccalc.pairwise_distances(np.asarray(sn.centers))
+            dmat /= distance_sigma
+            np.square(dmat, out=dmat)
+            dmat *= -0.5
+            np.exp(dmat, out=dmat)
+            return (np.asarray(sn.p_ij) + jump_lag_coeff * jl) * (distance_coeff * dmat + (1 - distance_coeff))
+        return cfunc
+
+    def _get_sites_to_merge(self, st):
+        sn = st.site_network
+        if not sn.has_attribute("n_ij"):                # :113-115
+            JumpAnalysis().run(st)
+        pbcc = PBCCalculator(np.asarray(sn.structure.cell, dtype=np.float64))
+        connectivity_matrix = np.array(self.connectivity_matrix_generator(sn), dtype=np.float64, copy=True)
+        n_sites_before = sn.n_sites
+        assert n_sites_before == connectivity_matrix.shape[0]
+        centers_before = np.asarray(sn.centers)
+        # diagnostic only (:127-146): strong fluxes over the distance cut-off are reported, not kept
+        no_diag_graph = connectivity_matrix.astype(np.float64, copy=True)
+        np.fill_diagonal(no_diag_graph, np.nan)
+        with np.errstate(invalid="ignore"):
+            edge_threshold = np.nanmean(no_diag_graph) + 3 * np.nanstd(no_diag_graph)
+        n_alarming_ignored_edges = 0
+        for i in range(n_sites_before):
+            rest = centers_before[i + 1:]
+            dists = pbcc.distances(centers_before[i], rest) if len(rest) else np.zeros(0)
+            js_too_far = np.where(dists > self.distance_threshold)[0] + i + 1
+            if np.any(connectivity_matrix[i, js_too_far] > edge_threshold) or \
+               np.any(connectivity_matrix[js_too_far, i] > edge_threshold):
+                n_alarming_ignored_edges += 1
+            connectivity_matrix[i, js_too_far] = 0
+            connectivity_matrix[js_too_far, i] = 0
+        if n_alarming_ignored_edges > 0:
+            logger.warning("  At least %i site pairs with high (z-score > 3) fluxes were over the given distance cutoff.\n"
+                           "  This may or may not be a problem; but if `distance_threshold` is low, consider raising it."
+                           % n_alarming_ignored_edges)
+        return markov_clustering(connectivity_matrix, **self.markov_parameters)   # :153

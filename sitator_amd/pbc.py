@@ -45,3 +45,18 @@ class PBCCalculator(object):
         """PBC-aware (optionally weighted) mean of a compact cloud of points."""
         assert points.ndim == 2 and points.shape[1] == 3
         return self._ctx.average(points, weights)
+
+    def pairwise_distances(self, pts, out=None):
+        """Pairwise shift-and-wrap distance matrix of ``pts`` with itself (:43-61): row i holds the distances
+        from point i, mirrored into column i."""
+        pts = np.asarray(pts, dtype=np.float64)
+        n = len(pts)
+        if out is None:
+            out = np.empty((n, n), dtype=pts.dtype)
+        for i in range(n - 1):
+            out[i, i] = 0
+            out[i, i + 1:] = self._ctx.distances(pts[i], pts[i + 1:])
+            out[i + 1:, i] = out[i, i + 1:]
+        if n:
+            out[n - 1, n - 1] = 0
+        return out

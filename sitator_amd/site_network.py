@@ -58,6 +58,7 @@ class SiteNetwork(object):
         assert len(self.static_structure) == self.n_static
         self._centers = None
         self._vertices = None
+        self._types = None
         self._site_attrs = {}
         self._edge_attrs = {}
 
@@ -139,6 +140,7 @@ class SiteNetwork(object):
         if value.ndim != 2 or value.shape[1] != 3:
             raise ValueError("`centers` must be a list of points")
         self._vertices = None          # new centres invalidate everything derived from the old
+        self._types = None
         self._site_attrs = {}
         self._edge_attrs = {}
         self._centers = value
@@ -157,6 +159,30 @@ class SiteNetwork(object):
     def number_of_vertices(self):
         return None if self._vertices is None else [len(v) for v in self._vertices]
 
+    # -- site types (reference SiteNetwork.py:233-256)
+    @property
+    def site_types(self):
+        if self._types is None:
+            return None
+        view = self._types.view()
+        view.flags.writeable = False
+        return view
+
+    @site_types.setter
+    def site_types(self, value):
+        value = np.asarray(value)
+        if not value.shape == (len(self._centers),):
+            raise ValueError("Wrong # of types %s; expected %i" % (value.shape, len(self._centers)))
+        self._types = value
+
+    @property
+    def n_types(self):
+        return len(np.unique(self.site_types))
+
+    @property
+    def types(self):
+        return np.unique(self.site_types)
+
     @property
     def site_ids(self):
         return np.arange(self.n_sites)
@@ -167,6 +193,8 @@ class SiteNetwork(object):
             new.centers = self._centers.copy()
         if self._vertices is not None:
             new.vertices = [list(v) for v in self._vertices]
+        if self._types is not None:
+            new.site_types = self._types.copy()
         for k, v in self._site_attrs.items():
             new.add_site_attribute(k, v.copy())
         for k, v in self._edge_attrs.items():

@@ -100,3 +100,57 @@ def test_gpu_recenter_matches_reference():
     p2 = z()["rc/frames"].copy()
     RecenterTrajectory().run(at, sm, p2, masses=z()["rc/masses"])
     np.testing.assert_allclose(p2, z()["rc/out_masses"], rtol=0, atol=1e-10)
+
+
+# ---- MergeSitesByDynamics: goldens from the true reference ---------------------------
+
+def _merge_cases():
+    z = G.load("merge_known_answers")
+    return [(str(n), str(v)) for n in z["names"] for v in z["variants"]]
+
+
+@pytest.mark.parametrize("name,variant", _merge_cases())
+def test_oracle_merge_sites_matches_reference(oracle, name, variant):
+    import json
+    z = G.load("merge_known_answers")
+    key = "%s/%s" % (name, variant)
+    p = json.loads(str(z[key + "/params"]))
+    kw = dict(p["kw"])
+    try:
+        cen, traj, _, _ = oracle.merge_sites_by_dynamics(
+            z[name + "/cell"], z[name + "/centers"], z[name + "/labels"], int(z[name + "/mobile_mask"].sum()),
+            connectivity=p["connectivity"], jump_lag_params=p["jump_lag_params"], **kw)
+        err = ""
+    except oracle.OracleError as e:
+        err = e.kind
+    assert err == str(z[key + "/error"])
+    if not err:
+        assert np.array_equal(traj, z[key + "/traj"])
+        np.testing.assert_allclose(cen, z[key + "/centers"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,variant", _merge_cases())
+def test_gpu_merge_sites_matches_reference(name, variant):
+    import json
+    from sitator_amd import (MergeSitesByDynamics, MergedSitesTooDistantError, SiteNetwork, SiteTrajectory, Structure,
+                             errors)
+    z = G.load("merge_known_answers")
+    key = "%s/%s" % (name, variant)
+    p = json.loads(str(z[key + "/params"]))
+    kw = dict(p["kw"])
+    if p["connectivity"] == "jump_lag_biased":
+        kw["connectivity_matrix_generator"] = MergeSitesByDynamics.connectivity_jump_lag_biased(**p["jump_lag_params"])
+    sn = SiteNetwork(Structure(z[name + "/ref_positions"], z[name + "/cell"]), z[name + "/static_mask"], z[name + "/mobile_mask"])
+    sn.centers = z[name + "/centers"].copy()
+    st = SiteTrajectory(sn, z[name + "/labels"].copy())
+    try:
+        out = MergeSitesByDynamics(check_types=False, **kw).run(st)
+        err = ""
+    except (MergedSitesTooDistantError, errors.InsufficientSitesError) as e:
+        err = type(e).__name__
+    assert err == str(z[key + "/error"])
+    if not err:
+        assert np.array_equal(out.traj, z[key + "/traj"])
+        np.testing.assert_allclose(np.asarray(out.site_network.centers), z[key + "/centers"], rtol=1e-6, atol=1e-9)
+        assert out.site_network.n_sites == len(z[key + "/centers"])
