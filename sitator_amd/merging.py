@@ -1,6 +1,9 @@
-"""Merging of sites (reference ``sitator/network/merging.py``): the base class turns groups of sites into one site
-each - new centre by ``PBCCalculator.average``, union of the vertices, translated ``SiteTrajectory``.  Which sites
-are grouped is decided by a subclass (``sitator_amd.dynamics.MergeSitesByDynamics``)."""
+"""Site merging: groups of sites become one site each, and the ``SiteTrajectory`` is re-expressed over the merged
+network.  Behavioural mirror of the reference's ``sitator/network/merging.py`` (same class names, keyword arguments,
+exceptions and results; citations below are to that file) written around three small steps - translation table,
+geometry of the merged sites, relabelled trajectory.  Which sites form a group is a subclass's decision
+(``sitator_amd.dynamics.MergeSitesByDynamics``).  Distances and periodic averages run through the device-backed
+``PBCCalculator``."""
 import abc
 import logging
 
@@ -21,13 +24,26 @@ class MergedSitesTooDistantError(MergeSitesError):
     pass
 
 
-class MergeSites(abc.ABC):
-    """Abstract base class for merging sites (``network/merging.py:18-145``).
+def _translation_table(groups, n_sites):
+    """old site index -> merged site index (-1: the site is in no group).  A site named by two groups is the
+    "more than one new site" degeneracy the reference refuses (:77-81)."""
+    table = np.full(n_sites, -1, dtype=np.int64)
+    for new_index, members in enumerate(groups):
+        members = np.fromiter(members, dtype=np.int64)
+        if (table[members] >= 0).any():
+            raise ValueError("Site merging tried to merge site(s) into more than one new site. This shouldn't happen.")
+        table[members] = new_index
+    return table
 
-    ``check_types``: only sites of the same type may be merged (needs ``site_types``); ``maximum_merge_distance``:
-    merged sites further apart than this raise ``MergedSitesTooDistantError``; ``set_merged_into``: record the
-    translation table as site attribute ``merged_into`` of the ORIGINAL network; ``weighted_spatial_average``: as in
-    the reference, ``True`` takes the plain average of the merged centres and ``False`` the occupancy-weighted one."""
+
+class MergeSites(abc.ABC):
+    """Base class of the site-merging steps.
+
+    Parameters (as in the reference, :34-42): ``check_types`` - merge only sites of one type and carry the type over
+    (needs ``site_types``); ``maximum_merge_distance`` - a group whose members lie further than this from its first
+    member raises ``MergedSitesTooDistantError``; ``set_merged_into`` - store the translation table on the ORIGINAL
+    network as site attribute ``merged_into``; ``weighted_spatial_average`` - kept with the reference's meaning
+    (:94-98): ``True`` = plain periodic mean of the members' centres, ``False`` = mean weighted by ``occupancies``."""
 
     def __init__(self, check_types=True, maximum_merge_distance=None, set_merged_into=False,
                  weighted_spatial_average=True):
@@ -36,70 +52,55 @@ class MergeSites(abc.ABC):
         self.set_merged_into = set_merged_into
         self.weighted_spatial_average = weighted_spatial_average
 
-    def run(self, st, **kwargs):
-        """Takes a ``SiteTrajectory`` and returns a new one over the merged sites (:46-131)."""
-        sn = st.site_network
-        if self.check_types and sn.site_types is None:
-            raise ValueError("Cannot run a check_types=True MergeSites on a SiteTrajectory without type information.")
-        pbcc = PBCCalculator(np.asarray(sn.structure.cell, dtype=np.float64))
-        site_centers = np.asarray(sn.centers)
-        site_types = sn.site_types if self.check_types else None
-
-        clusters = self._get_sites_to_merge(st, **kwargs)
-
-        new_n_sites = len(clusters)
-        logger.info("After merging %i sites there will be %i sites for %i mobile particles"
-                    % (len(site_centers), new_n_sites, sn.n_mobile))
-        if new_n_sites < sn.n_mobile:
-            raise InsufficientSitesError(verb="Merging", n_sites=new_n_sites, n_mobile=sn.n_mobile)
-
-        new_types = np.empty(new_n_sites, dtype=np.int64) if self.check_types else None
-        merge_verts = sn.vertices is not None
-        new_verts = []
-        new_centers = np.empty((new_n_sites, 3), dtype=site_centers.dtype)
-        translation = np.full(sn.n_sites, -1, dtype=np.int64)
-        for newsite in range(new_n_sites):
-            mask = list(clusters[newsite])
-            if np.any(translation[mask] != -1):
-                raise ValueError("Site merging tried to merge site(s) into more than one new site. This shouldn't happen.")
-            translation[mask] = newsite
-            to_merge = site_centers[mask]
-            if self.maximum_merge_distance is not None:
-                dists = pbcc.distances(to_merge[0], to_merge[1:]) if len(to_merge) > 1 else np.zeros(0)
-                if not np.all(dists <= self.maximum_merge_distance):
-                    raise MergedSitesTooDistantError(
-                        "Markov clustering tried to merge sites more than %.2f apart. Lower your distance_threshold?"
-                        % self.maximum_merge_distance)
-            if self.weighted_spatial_average:                     # (sic, :94-98)
-                new_centers[newsite] = pbcc.average(to_merge)
-            else:
-                new_centers[newsite] = pbcc.average(to_merge, weights=np.asarray(sn.occupancies)[mask])
-            if self.check_types:
-                assert np.all(site_types[mask] == site_types[mask][0])
-                new_types[newsite] = site_types[mask][0]
-            if merge_verts:
-                new_verts.append(set.union(*[set(sn.vertices[i]) for i in mask]))
-
-        newsn = sn.copy()
-        newsn.centers = new_centers
-        if self.check_types:
-            newsn.site_types = new_types
-        if merge_verts:
-            newsn.vertices = new_verts
-
-        traj = st.traj
-        newtraj = translation[traj]
-        newtraj[traj == SiteTrajectory.SITE_UNKNOWN] = SiteTrajectory.SITE_UNKNOWN
-        # confidences are not propagated through a transform that may invalidate them (:118-120)
-        newst = SiteTrajectory(newsn, newtraj, confidences=None)
-        if st.real_trajectory is not None:
-            newst.set_real_traj(st.real_trajectory)
-        if self.set_merged_into:
-            if sn.has_attribute("merged_into"):
-                sn.remove_attribute("merged_into")
-            sn.add_site_attribute("merged_into", translation)
-        return newst
-
     @abc.abstractmethod
     def _get_sites_to_merge(self, st, **kwargs):
-        """Groups of site indices to merge: no overlap, every site in at most one group (:133-145)."""
+        """Disjoint groups (iterables of site indices) that become one site each."""
+
+    # -- pieces of run() ----------------------------------------------------------------------------------
+    def _merged_center(self, pbc, network, members):
+        pts = np.asarray(network.centers)[members]
+        limit = self.maximum_merge_distance
+        if limit is not None and len(pts) > 1 and (pbc.distances(pts[0], pts[1:]) > limit).any():   # :84-88
+            raise MergedSitesTooDistantError(
+                "Markov clustering tried to merge sites more than %.2f apart. Lower your distance_threshold?" % limit)
+        if self.weighted_spatial_average:
+            return pbc.average(pts)
+        return pbc.average(pts, weights=np.asarray(network.occupancies)[members])
+
+    def run(self, st, **kwargs):
+        """``SiteTrajectory`` in, ``SiteTrajectory`` over the merged sites out (:46-131)."""
+        old = st.site_network
+        if self.check_types and old.site_types is None:
+            raise ValueError("Cannot run a check_types=True MergeSites on a SiteTrajectory without type information.")
+
+        groups = [list(g) for g in self._get_sites_to_merge(st, **kwargs)]
+        logger.info("After merging %i sites there will be %i sites for %i mobile particles"
+                    % (old.n_sites, len(groups), old.n_mobile))
+        if len(groups) < old.n_mobile:                                                    # :63-68
+            raise InsufficientSitesError(verb="Merging", n_sites=len(groups), n_mobile=old.n_mobile)
+
+        table = _translation_table(groups, old.n_sites)
+        pbc = PBCCalculator(np.asarray(old.structure.cell, dtype=np.float64))
+        merged = old.copy()
+        merged.centers = np.array([self._merged_center(pbc, old, g) for g in groups],
+                                  dtype=np.asarray(old.centers).dtype).reshape(len(groups), 3)
+        if self.check_types:
+            kinds = np.asarray(old.site_types)
+            for g in groups:
+                assert (kinds[g] == kinds[g[0]]).all()
+            merged.site_types = np.array([kinds[g[0]] for g in groups], dtype=np.int64)
+        if old.vertices is not None:                                                      # union of the polyhedra
+            merged.vertices = [set().union(*(set(old.vertices[i]) for i in g)) for g in groups]
+
+        labels = st.traj
+        unknown = labels == SiteTrajectory.SITE_UNKNOWN
+        relabelled = np.where(unknown, SiteTrajectory.SITE_UNKNOWN, table[np.where(unknown, 0, labels)])
+        # confidences describe the old assignment and are dropped (:118-120)
+        out = SiteTrajectory(merged, relabelled.astype(np.int64), confidences=None)
+        if st.real_trajectory is not None:
+            out.set_real_traj(st.real_trajectory)
+        if self.set_merged_into:
+            if old.has_attribute("merged_into"):
+                old.remove_attribute("merged_into")
+            old.add_site_attribute("merged_into", table)
+        return out
