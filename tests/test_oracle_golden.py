@@ -108,3 +108,21 @@ def test_pipeline(oracle, name, tag):
     assert oracle.jumps(o["labels"], unknown_as_jump=True) == [tuple(r) for r in exp["jumps_unknown"]]
     if "site_vertices" in exp:
         assert o["site_vertices"] == G.vertices_of(exp["site_vertices"])
+
+
+@pytest.mark.parametrize("n,seed", [(700, 0), (1500, 1)])
+def test_sparse_markov_clustering_equals_dense(oracle, n, seed):
+    """The product's scipy.sparse iteration (graphs of >= 600 landmarks) gives the groups of the dense iteration
+    (the oracle's restatement of util/mcl.py), in the same order."""
+    from sitator_amd import markov
+    rng = np.random.default_rng(seed)
+    A = np.zeros((n, n))
+    for i in range(n):
+        nb = rng.integers(max(0, i - 6), min(n, i + 7), size=8)
+        A[i, nb] = rng.uniform(0.05, 1, size=8)
+    A = np.maximum(A, A.T)
+    np.fill_diagonal(A, 1.0)
+    for inflation in (2, 4):
+        mine = markov.markov_clustering(A, inflation=inflation)
+        ref = oracle.markov_clustering(A, inflation=inflation)
+        assert [tuple(g) for g in mine] == [tuple(int(x) for x in g) for g in ref]
