@@ -159,6 +159,11 @@ int sit_get_assignments(sit_ctx *ctx, int64_t *labels, double *confs, int64_t *c
 int sit_gram(sit_ctx *ctx, double *G, int64_t *seen);
 /* argmax_n |X[n] . c| with first-max tie-break (:80-83): index, the dot, and |X[n]|.     */
 int sit_best_match(sit_ctx *ctx, const double *c, int64_t *row, double *dot, double *norm);
+/* The same for G centres with DISJOINT supports in one pass over the rows (the mcl plugin's landmark groups
+ * partition the landmarks, :71-87): group_of_dim[d] = centre holding dimension d (-1: none), c[d] = that centre's
+ * value at d.  rows/dots/norms: [G].                                                      */
+int sit_best_match_groups(sit_ctx *ctx, const int32_t *group_of_dim, const double *c, int64_t G,
+                          int64_t *rows, double *dots, double *norms);
 /* sums[k] = sum_n w_n X[n], wsum[k] = sum_n w_n, w_n = (label==k) * (conf or 1) (:117-122) */
 int sit_weighted_row_sums(sit_ctx *ctx, int weighted, int64_t K, double *sums, double *wsum);
 

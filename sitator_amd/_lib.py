@@ -63,6 +63,7 @@ SIGNATURES = {
     "sit_get_assignments": (C.c_int, [_vp, _ip, _dp, _ip]),
     "sit_gram": (C.c_int, [_vp, _dp, _ip]),
     "sit_best_match": (C.c_int, [_vp, _dp, _ip, _dp, _dp]),
+    "sit_best_match_groups": (C.c_int, [_vp, C.POINTER(C.c_int32), _dp, i64, _ip, _dp, _dp]),
     "sit_weighted_row_sums": (C.c_int, [_vp, C.c_int, i64, _dp, _dp]),
     "sit_site_anchors": (C.c_int, [_vp, C.c_int, i64, _dp, _ip, _dp]),
     "sit_site_sums": (C.c_int, [_vp, C.c_int, i64, _dp, _dp]),
@@ -323,6 +324,18 @@ class HipContext(object):
         nrm = C.c_double(0)
         self._check(self.lib.sit_best_match(self._h, _d(c), C.byref(row), C.byref(dot), C.byref(nrm)))
         return row.value, dot.value, nrm.value
+
+    def best_match_groups(self, group_of_dim, cvec, G):
+        """``best_match`` for ``G`` centres with disjoint supports in one pass: (rows, dots, norms), each ``[G]``."""
+        grp = np.ascontiguousarray(group_of_dim, dtype=np.int32)
+        cvec = _f64(cvec)
+        assert grp.shape == (self.D,) and cvec.shape == (self.D,)
+        rows = np.empty(G, dtype=np.int64)
+        dots = np.empty(G)
+        nrms = np.empty(G)
+        self._check(self.lib.sit_best_match_groups(self._h, grp.ctypes.data_as(C.POINTER(C.c_int32)), _d(cvec), G,
+                                                   _i(rows), _d(dots), _d(nrms)))
+        return rows, dots, nrms
 
     def weighted_row_sums(self, K, weighted=True):
         sums = np.empty((K, self.D))

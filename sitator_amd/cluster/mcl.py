@@ -31,20 +31,21 @@ def cov2corr(A):
     return ((A.T / d).T) / d
 
 
-def _global_best_match(X, center):
-    """argmax_n |X[n] . center| over all ranks: (|dot|, norm of that row) (:80-87)."""
-    row, dot, nrm = X.ctx.best_match(center)
+def _global_best_matches(X, group_of_dim, cvec, n_groups):
+    """Per landmark group: max_n |X[n] . c_g| and the norm of the first row reaching it, over all ranks (:80-87).
+    The groups partition the landmarks, so one pass over the rows serves every centre."""
+    rows, dots, nrms = X.ctx.best_match_groups(group_of_dim, cvec, n_groups)
     if X.comm.size > 1:
-        grow = row + X.ctx.frame0 * X.ctx.M
-        allv = X.comm.allgather(np.array([dot, float(grow), nrm]))
-        best = 0
-        for r in range(1, X.comm.size):          # ranks are in row order: first maximum / first NaN
-            if np.isnan(allv[best, 0]):
-                break
-            if np.isnan(allv[r, 0]) or allv[r, 0] > allv[best, 0]:
-                best = r
-        dot, nrm = allv[best, 0], allv[best, 2]
-    return dot, nrm
+        allv = X.comm.allgather(np.stack([dots, nrms], axis=1))          # [size, G, 2], ranks in row order
+        for g in range(n_groups):
+            best = 0
+            for r in range(1, X.comm.size):                              # first maximum / first NaN
+                if np.isnan(allv[best, g, 0]):
+                    break
+                if np.isnan(allv[r, g, 0]) or allv[r, g, 0] > allv[best, g, 0]:
+                    best = r
+            dots[g], nrms[g] = allv[best, g, 0], allv[best, g, 1]
+    return dots, nrms
 
 
 def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, verbose):
@@ -81,9 +82,17 @@ def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, ver
         else:
             _, vec = eigsh(cov[group][:, group], k=1)                  # :78
             centers[i, group] = vec.T
-        best_dot, best_norm = _global_best_match(X, centers[i])
-        good[i] = (best_dot / best_norm >= good_site_normed_threshold) and (best_dot >= good_site_project_thresh)
-        centers[i] /= best_dot
+    group_of_dim = np.full(n_lmk, -1, dtype=np.int32)
+    cvec = np.zeros(n_lmk)
+    for i, group in enumerate(groups):
+        group_of_dim[group] = i
+        cvec[group] = centers[i, group]
+    best_dots, best_norms = _global_best_matches(X, group_of_dim, cvec, len(groups)) if len(groups) else ([], [])
+    for i in range(len(groups)):
+        best_dot, best_norm = best_dots[i], best_norms[i]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            good[i] = (best_dot / best_norm >= good_site_normed_threshold) and (best_dot >= good_site_project_thresh)
+            centers[i] /= best_dot
     logger.debug("Kept %i/%i landmark clusters as good sites" % (np.sum(good), len(good)))
 
     groups = [g for i, g in enumerate(groups) if good[i]]

@@ -700,6 +700,93 @@ extern "C" int sit_best_match(sit_ctx *c, const double *cvec, i64 *row_out, doub
     return SIT_OK;
 }
 
+// ---- best match of many centres with disjoint supports, one pass over the rows ---------------------------
+// A row entry belongs to at most one centre (its dimension's group).  The first entry of a group in the row owns
+// that (row, group) pair and sums the pair's terms in ascending dimension order - the dense dot product X[n] . c_g
+// with its exact zeros left out.  pass 0: per group the largest |dot| (as an ordered u64 key, NaN on top);
+// pass 1: the first row that reaches it.
+__global__ __launch_bounds__(256) void k_best_match_groups(const i32 *nnz, const i32 *idx, const double *val, i64 N,
+                                                           const i32 *grp, const double *cvec, u64 *keymax, u64 *rowmin,
+                                                           i64 row_offset, int pass)
+{
+    const i64 row = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (row >= N) return;
+    const int n = nnz[row];
+    for (int e = 0; e < n; e++) {
+        const i32 g = grp[idx[(i64)e * N + row]];
+        if (g < 0) continue;
+        bool owner = true;
+        for (int e2 = 0; e2 < e; e2++) if (grp[idx[(i64)e2 * N + row]] == g) { owner = false; break; }
+        if (!owner) continue;
+        double dot = 0.0;
+        for (int e3 = e; e3 < n; e3++) {
+            const i32 d = idx[(i64)e3 * N + row];
+            if (grp[d] == g) dot += val[(i64)e3 * N + row] * cvec[d];
+        }
+        const double v = fabs(dot);
+        const u64 key = isnan(v) ? ~0ull : (u64)__double_as_longlong(v);
+        if (pass == 0) atomicMax((unsigned long long *)&keymax[g], (unsigned long long)key);
+        else if (key == keymax[g]) atomicMin((unsigned long long *)&rowmin[g], (unsigned long long)(row_offset + row));
+    }
+}
+
+// per group: |dot| and norm of its best row (row index local to this context)
+__global__ void k_group_row_dot_norm(const i32 *nnz, const i32 *idx, const double *val, i64 N, const i32 *grp,
+                                     const double *cvec, const u64 *keymax, const u64 *rowmin, i64 row_offset, i64 G,
+                                     i64 *rows, double *dots, double *norms)
+{
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    // no row overlaps the group (or every dot is +0): the dense argmax of a zero vector is row 0
+    i64 row = (keymax[g] == 0ull || rowmin[g] == ~0ull) ? 0 : (i64)rowmin[g] - row_offset;
+    double dot = 0.0, x2 = 0.0;
+    if (N > 0) {
+        const int n = nnz[row];
+        for (int e = 0; e < n; e++) {
+            const double v = val[(i64)e * N + row];
+            const i32 d = idx[(i64)e * N + row];
+            if (grp[d] == (i32)g) dot += v * cvec[d];
+            x2 += v * v;
+        }
+    }
+    rows[g] = row; dots[g] = fabs(dot); norms[g] = sqrt(x2);
+}
+
+extern "C" int sit_best_match_groups(sit_ctx *c, const int32_t *group_of_dim, const double *cvec, i64 G, i64 *rows,
+                                     double *dots, double *norms)
+{
+    if (!c || !group_of_dim || !cvec || !rows || !dots || !norms) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->rows_valid && G > 0, "sit_best_match_groups: no landmark rows on the device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (i64 d = 0; d < c->D; d++)
+        SIT_REQUIRE(c, group_of_dim[d] >= -1 && group_of_dim[d] < G, "sit_best_match_groups: group index out of range");
+    int rc = ensure_scratch(c, c->D * 12 + G * (16 + 24) + 64);
+    if (rc) return rc;
+    double *dc = (double *)c->d_scratch;
+    u64 *keymax = (u64 *)(dc + c->D), *rowmin = keymax + G;
+    i64 *drows = (i64 *)(rowmin + G);
+    double *ddots = (double *)(drows + G), *dnorms = ddots + G;
+    i32 *dg = (i32 *)(dnorms + G);
+    HIP_TRY(c, hipMemcpyAsync(dc, cvec, (size_t)c->D * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dg, group_of_dim, (size_t)c->D * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(keymax, 0, (size_t)G * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(rowmin, 0xFF, (size_t)G * 8, c->stream));
+    if (c->N > 0) {
+        const unsigned nb = (unsigned)((c->N + 255) / 256);
+        for (int pass = 0; pass < 2; pass++)
+            k_best_match_groups<<<dim3(nb), dim3(256), 0, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, dg, dc,
+                                                                     keymax, rowmin, 0, pass);
+    }
+    k_group_row_dot_norm<<<dim3((unsigned)((G + 63) / 64)), dim3(64), 0, c->stream>>>(
+        c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, dg, dc, keymax, rowmin, 0, G, drows, ddots, dnorms);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(rows, drows, (size_t)G * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dots, ddots, (size_t)G * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(norms, dnorms, (size_t)G * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
 __global__ void k_weighted_row_sums(const i32 *nnz, const i32 *idx, const double *val, const i64 *labels,
                                     const double *confs, i64 N, i64 D, i64 K, int weighted, double *sums, double *wsum)
 {

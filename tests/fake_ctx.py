@@ -207,6 +207,15 @@ class FakeContext(object):
         row = _argmax_np(proj)
         return row, float(np.abs(np.dot(self.X[row], c))), float(np.linalg.norm(self.X[row]))
 
+    def best_match_groups(self, group_of_dim, cvec, G):
+        rows = np.zeros(G, dtype=np.int64)
+        dots = np.zeros(G)
+        nrms = np.zeros(G)
+        for g in range(G):
+            c = np.where(np.asarray(group_of_dim) == g, cvec, 0.0)
+            rows[g], dots[g], nrms[g] = self.best_match(c)
+        return rows, dots, nrms
+
     def weighted_row_sums(self, K, weighted=True):
         sums = np.zeros((K, self.D))
         wsum = np.zeros(K)
