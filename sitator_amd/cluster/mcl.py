@@ -48,8 +48,18 @@ def _global_best_matches(X, group_of_dim, cvec, n_groups):
     return dots, nrms
 
 
-def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, verbose):
+def _top_eigenvector(block):
+    """Eigenvector of the largest-magnitude eigenvalue of a symmetric block, as ``eigsh(block, k=1)`` returns it
+    (:78; the sign is arbitrary there too and cancels in everything downstream).  The blocks are a handful of
+    landmarks wide, so LAPACK's dense ``eigh`` does it without loading ARPACK; big blocks keep ``eigsh``."""
+    if len(block) <= 96:
+        w, v = np.linalg.eigh(block)
+        return v[:, [int(np.argmax(np.abs(w)))]]
     from scipy.sparse.linalg import eigsh
+    return eigsh(block, k=1)[1]
+
+
+def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, verbose):
     params = dict(DEFAULT_PARAMS)
     params.update(clustering_params)
     X = _as_device_rows(landmark_vectors)
@@ -80,8 +90,7 @@ def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, ver
         if len(group) == 1:
             centers[i, group] = 1.0
         else:
-            _, vec = eigsh(cov[group][:, group], k=1)                  # :78
-            centers[i, group] = vec.T
+            centers[i, group] = _top_eigenvector(cov[group][:, group]).T   # :78
     group_of_dim = np.full(n_lmk, -1, dtype=np.int32)
     cvec = np.zeros(n_lmk)
     for i, group in enumerate(groups):
