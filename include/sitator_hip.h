@@ -196,6 +196,10 @@ int sit_set_assignments(sit_ctx *ctx, const int64_t *labels, const double *confs
  * carry the forward-filled state across frame shards.                                     */
 int sit_jump_sources(sit_ctx *ctx, int unknown_as_jump, const int64_t *last_known_in,
                      int64_t *from, int64_t *last_known_out);
+/* The same scan reported as compact records {frame, mobile atom, from site, to site} (in no particular order; at most
+ * max_records are written, *n_records is the number found - call again with a larger buffer if it is larger).     */
+int sit_jump_list(sit_ctx *ctx, int unknown_as_jump, const int64_t *last_known_in, int64_t max_records,
+                  int64_t *records, int64_t *n_records, int64_t *last_known_out);
 
 /* ---- the steps either side of the path ------------------------------ */
 

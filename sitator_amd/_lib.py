@@ -70,6 +70,7 @@ SIGNATURES = {
     "sit_check_occupancy": (C.c_int, [_vp, i64, i64, _ip, _ip, _ip, C.POINTER(SitError)]),
     "sit_set_assignments": (C.c_int, [_vp, _ip, _dp, i64, i64, i64]),
     "sit_jump_sources": (C.c_int, [_vp, C.c_int, _ip, _ip, _ip]),
+    "sit_jump_list": (C.c_int, [_vp, C.c_int, _ip, i64, _ip, _ip, _ip]),
     "sit_jump_analysis": (C.c_int, [_vp, i64, _ip, _ip, _dp, _dp, _ip, _ip, _ip, _ip, _ip]),
     "sit_assign_last_known": (C.c_int, [_vp, i64, _ip, _ip, _ip, _i32p, _ip, _ip, _ip]),
     "sit_running_mode": (C.c_int, [_vp, i64, i64, i64, C.c_int, _ip]),
@@ -380,6 +381,24 @@ class HipContext(object):
         self._check(self.lib.sit_jump_sources(self._h, int(unknown_as_jump), None if lin is None else _i(lin),
                                               _i(src), _i(last_out)))
         return src, last_out
+
+    def jump_list(self, unknown_as_jump=False, last_known_in=None):
+        """Jumps as an ``[n, 4]`` array of (frame, mobile atom, from site, to site), frame-major, and the last known
+        site of every ion after this context's frames."""
+        last_out = np.empty(self.M, dtype=np.int64)
+        lin = None if last_known_in is None else _i64(last_known_in)
+        cap = 1 << 16
+        while True:
+            rec = np.empty((cap, 4), dtype=np.int64)
+            n = i64(0)
+            self._check(self.lib.sit_jump_list(self._h, int(unknown_as_jump), None if lin is None else _i(lin), cap,
+                                               _i(rec), C.byref(n), _i(last_out)))
+            if n.value <= cap:
+                break
+            cap = int(n.value)
+        rec = rec[:n.value]
+        order = np.lexsort((rec[:, 1], rec[:, 0]))
+        return rec[order], last_out
 
     def jump_analysis(self, K, last_known_in=None, time_at_current_in=None):
         n_ij = np.empty((K, K)); tsum = np.empty((K, K)); tn = np.empty((K, K), dtype=np.int64)

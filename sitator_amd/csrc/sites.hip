@@ -275,32 +275,79 @@ extern "C" int sit_set_assignments(sit_ctx *c, const i64 *labels, const double *
 
 #define JUMP_NONE ((i64)0x8000000000000000ull)
 
-// One lane per ion walks the frames in order (the forward fill is a running state); loads are
-// issued eight frames ahead of the dependent logic so that HBM latency overlaps.
-__global__ void k_jump_sources(const i64 *labels, i64 F, i64 M, int unknown_as_jump, const i64 *last_in,
-                               i64 *from, i64 *last_out)
+// Jump detection (SiteTrajectory.py:307-329) is a forward fill of the last known site per ion - a scan.  Frames are
+// cut into chunks of JCH: (1) every (chunk, ion) finds the last known label inside its chunk, (2) one lane per ion
+// chains those through the chunks (a few hundred steps), (3) every (chunk, ion) replays its chunk from the carried-in
+// state and reports the jumps - as a full [F, M] source array and/or as compact records.
+#define JCH 256
+#define JUMP_SENTINEL ((i64)0x8000000000000001ull)
+
+__global__ __launch_bounds__(64) void k_jump_chunk_last(const i64 *labels, i64 F, i64 M, int unknown_as_jump, i64 *chunk_last)
+{
+    const i64 c = blockIdx.x, j = (i64)blockIdx.y * 64 + threadIdx.x;
+    if (j >= M) return;
+    const i64 f0 = c * JCH, f1 = f0 + JCH < F ? f0 + JCH : F;
+    i64 last = JUMP_SENTINEL;
+    for (i64 f = f0; f < f1; f++) {
+        const i64 cur = labels[f * M + j];
+        if (unknown_as_jump || cur != -1) last = cur;
+    }
+    chunk_last[c * M + j] = last;
+}
+
+__global__ void k_jump_chunk_carry(const i64 *labels, i64 F, i64 M, i64 nch, const i64 *last_in, const i64 *chunk_last,
+                                   i64 *carry, i64 *last_out)
 {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
-    i64 last;
-    i64 f = 0;
-    if (last_in) last = last_in[j];
-    else { last = F > 0 ? labels[j] : -1; if (F > 0) from[j] = JUMP_NONE; f = 1; }
-    for (; f < F; f += 8) {
-        i64 cur[8];
-        const int nb = (int)((F - f) < 8 ? (F - f) : 8);
-#pragma unroll
-        for (int q = 0; q < 8; q++) cur[q] = q < nb ? labels[(f + q) * M + j] : -1;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if (q >= nb) break;
-            const bool known = unknown_as_jump ? true : (cur[q] != -1);
-            const bool jumped = (cur[q] != last) && known;
-            from[(f + q) * M + j] = jumped ? last : JUMP_NONE;
-            if (known) last = cur[q];
-        }
+    i64 last = last_in ? last_in[j] : (F > 0 ? labels[j] : -1);       // last_known = traj[0] (:312)
+    for (i64 c = 0; c < nch; c++) {
+        carry[c * M + j] = last;
+        const i64 cl = chunk_last[c * M + j];
+        if (cl != JUMP_SENTINEL) last = cl;
     }
     if (last_out) last_out[j] = last;
+}
+
+__global__ __launch_bounds__(64) void k_jump_emit(const i64 *labels, i64 F, i64 M, int unknown_as_jump, int has_last_in,
+                                                  const i64 *carry, i64 *from, i64 *rec, unsigned long long *counter,
+                                                  i64 max_rec)
+{
+    const i64 c = blockIdx.x, j = (i64)blockIdx.y * 64 + threadIdx.x;
+    if (j >= M) return;
+    const i64 f0 = c * JCH, f1 = f0 + JCH < F ? f0 + JCH : F;
+    i64 last = carry[c * M + j];
+    for (i64 f = f0; f < f1; f++) {
+        const i64 cur = labels[f * M + j];
+        if (f == 0 && !has_last_in) { if (from) from[j] = JUMP_NONE; continue; }   // frame 0 only defines the state
+        const bool known = unknown_as_jump ? true : (cur != -1);
+        const bool jumped = (cur != last) && known;
+        if (from) from[f * M + j] = jumped ? last : JUMP_NONE;
+        if (rec && jumped) {
+            const unsigned long long slot = atomicAdd(counter, 1ull);
+            if ((i64)slot < max_rec) { rec[4 * slot] = f; rec[4 * slot + 1] = j; rec[4 * slot + 2] = last; rec[4 * slot + 3] = cur; }
+        }
+        if (known) last = cur;
+    }
+}
+
+static int jump_scan(sit_ctx *c, int unknown_as_jump, const i64 *last_known_in, i64 *dfrom, i64 *drec, i64 max_rec,
+                     unsigned long long *dcounter, i64 *dlast_out, i64 *dwork)
+{
+    const i64 M = c->M, F = c->F;
+    const i64 nch = (F + JCH - 1) / JCH;
+    i64 *din = dwork, *dchunk = din + M, *dcarry = dchunk + nch * M;
+    if (last_known_in) HIP_TRY(c, hipMemcpyAsync(din, last_known_in, (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
+    if (dcounter) HIP_TRY(c, hipMemsetAsync(dcounter, 0, 8, c->stream));
+    const unsigned gy = (unsigned)((M + 63) / 64);
+    if (nch > 0) k_jump_chunk_last<<<dim3((unsigned)nch, gy), dim3(64), 0, c->stream>>>(c->d_labels, F, M, unknown_as_jump, dchunk);
+    k_jump_chunk_carry<<<dim3(gy), dim3(64), 0, c->stream>>>(c->d_labels, F, M, nch, last_known_in ? din : nullptr, dchunk,
+                                                            dcarry, dlast_out);
+    if (nch > 0) k_jump_emit<<<dim3((unsigned)nch, gy), dim3(64), 0, c->stream>>>(c->d_labels, F, M, unknown_as_jump,
+                                                                               last_known_in != nullptr, dcarry, dfrom, drec,
+                                                                               dcounter, max_rec);
+    HIP_TRY(c, hipGetLastError());
+    return SIT_OK;
 }
 
 extern "C" int sit_jump_sources(sit_ctx *c, int unknown_as_jump, const i64 *last_known_in, i64 *from, i64 *last_known_out)
@@ -308,16 +355,39 @@ extern "C" int sit_jump_sources(sit_ctx *c, int unknown_as_jump, const i64 *last
     if (!c || !from) return SIT_ERR_INVALID;
     SIT_REQUIRE(c, c->assign_valid, "sit_jump_sources: assignments needed");
     HIP_TRY(c, hipSetDevice(c->device));
-    const i64 N = c->N, M = c->M;
-    int rc = ensure_scratch(c, (N + 2 * M) * 8);
+    const i64 N = c->N, M = c->M, nch = (c->F + JCH - 1) / JCH;
+    int rc = ensure_scratch(c, (N + 2 * M + 2 * nch * M + 8) * 8);
     if (rc) return rc;
-    i64 *dfrom = (i64 *)c->d_scratch, *din = dfrom + N, *dout = din + M;
-    if (last_known_in) HIP_TRY(c, hipMemcpyAsync(din, last_known_in, (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
-    k_jump_sources<<<dim3((unsigned)((M + 63) / 64)), dim3(64), 0, c->stream>>>(
-        c->d_labels, c->F, M, unknown_as_jump, last_known_in ? din : nullptr, dfrom, dout);
-    HIP_TRY(c, hipGetLastError());
+    i64 *dfrom = (i64 *)c->d_scratch, *dout = dfrom + N, *dwork = dout + M;
+    if ((rc = jump_scan(c, unknown_as_jump, last_known_in, dfrom, nullptr, 0, nullptr, dout, dwork))) return rc;
     if (N > 0) HIP_TRY(c, hipMemcpyAsync(from, dfrom, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
     if (last_known_out) HIP_TRY(c, hipMemcpyAsync(last_known_out, dout, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+extern "C" int sit_jump_list(sit_ctx *c, int unknown_as_jump, const i64 *last_known_in, i64 max_records, i64 *records,
+                             i64 *n_records, i64 *last_known_out)
+{
+    if (!c || !n_records || (max_records > 0 && !records)) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->assign_valid && max_records >= 0, "sit_jump_list: assignments needed");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 M = c->M, nch = (c->F + JCH - 1) / JCH;
+    int rc = ensure_scratch(c, (4 * max_records + 2 * M + 2 * nch * M + 16) * 8);
+    if (rc) return rc;
+    i64 *drec = (i64 *)c->d_scratch, *dout = drec + 4 * max_records;
+    unsigned long long *dcount = (unsigned long long *)(dout + M);
+    i64 *dwork = (i64 *)(dcount + 1);
+    if ((rc = jump_scan(c, unknown_as_jump, last_known_in, nullptr, drec, max_records, dcount, dout, dwork))) return rc;
+    unsigned long long n = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n, dcount, 8, hipMemcpyDeviceToHost, c->stream));
+    if (last_known_out) HIP_TRY(c, hipMemcpyAsync(last_known_out, dout, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_records = (i64)n;
+    const i64 got = (i64)n < max_records ? (i64)n : max_records;
+    if (got > 0) {
+        HIP_TRY(c, hipMemcpyAsync(records, drec, (size_t)got * 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     return SIT_OK;
 }

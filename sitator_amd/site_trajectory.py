@@ -217,16 +217,15 @@ class SiteTrajectory(object):
             last_in = None
             for r in range(comm.size):
                 if comm.rank == r:
-                    src, last_out = ctx.jump_sources(unknown_as_jump, last_in)
+                    rec, last_out = ctx.jump_list(unknown_as_jump, last_in)
                 else:
                     last_out = np.zeros(self._sn.n_mobile, dtype=np.int64)
                 last_out = comm.bcast(last_out, root=r)
                 if comm.rank == r + 1:
                     last_in = last_out
         else:
-            src, _ = ctx.jump_sources(unknown_as_jump, None)
-        f, a = np.nonzero(src != ctx.JUMP_NONE)
-        return f, a, src[f, a], self._traj[f, a]
+            rec, _ = ctx.jump_list(unknown_as_jump, None)
+        return rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3]
 
     def jumps(self, **kwargs):
         """Yield ``(frame, mobile_atom, from_site, to_site)`` for every jump (reference :307-329)."""

@@ -288,6 +288,12 @@ class FakeContext(object):
             last[known] = traj[f, known]
         return src, last
 
+    def jump_list(self, unknown_as_jump=False, last_known_in=None):
+        src, last = self.jump_sources(unknown_as_jump, last_known_in)
+        f, a = np.nonzero(src != self.JUMP_NONE)
+        traj = self._labels.reshape(self.F, self.M)
+        return np.stack([f, a, src[f, a], traj[f, a]], axis=1).astype(np.int64).reshape(-1, 4), last
+
     def timers(self):
         return {}
 
