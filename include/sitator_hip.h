@@ -238,7 +238,10 @@ int sit_timers(sit_ctx *ctx, double *ms, int n);
  * candidates per bin (loose), [2] longest tight list, [3] mean candidates per bin (tight),
  * [4] delta (sampled static displacement bound, A), [5] frames of the last fill that exceeded
  * delta, [6..8] loose grid, [9..11] tight grid, [12] frames per workgroup of the last fill,
- * [13] verified batches / [14] serially applied rows / [15] re-walks of the last speculative fit. */
+ * [13] verified batches / [14] serially applied rows / [15] re-walks of the last speculative fit,
+ * [16] generation of the fill kernel the last sit_fill launched (1, 2 or 3), [17] ions per wave chunk and
+ * [18] waves per workgroup of that launch, [19] / [20] largest per-bin vertex union of the loose / tight
+ * records, [21] / [22] their sizes in 4-byte words.                                                    */
 int sit_info(sit_ctx *ctx, double *out, int n);
 int sit_synchronize(sit_ctx *ctx);
 

@@ -1,0 +1,55 @@
+"""Fill-kernel timing sweep on the GPU box: generations 2 and 3, launch shapes of generation 3, phase ablation.
+usage: python3 scratch/sweep_fill3.py [config] [frames]"""
+import os, sys, itertools
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tests.test_gpu_kernels import _setup
+from sitator_amd import synth
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+host = synth.config_host(cfg)
+M = synth.CONFIG_MOBILE[cfg]
+
+
+def run(ctx, reps=5, **env):
+    for k, v in env.items():
+        os.environ[k] = str(v)
+    try:
+        ts = []
+        for _ in range(reps):
+            rc, nz, err = ctx.fill(check_for_zeros=False)
+            assert rc == 0, (rc, ctx.message())
+            ts.append(ctx.timers()["fill"])
+        info = ctx.info()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    return min(ts), float(np.median(ts)), info
+
+
+ctx3, *_ = _setup(host, M, F, seed=2, kernel="3")
+ctx2, *_ = _setup(host, M, F, seed=2, kernel="2")
+t3 = run(ctx3)
+t2 = run(ctx2)
+print("%s F=%d  gen2 min %.4f med %.4f ms | gen3 min %.4f med %.4f ms (kernel %d iw %d nw %d fpb %d) unionmax %d/%d recwords %d/%d" % (
+    cfg, F, t2[0], t2[1], t3[0], t3[1], t3[2]["fill_kernel"], t3[2]["ions_per_wave"], t3[2]["waves_per_workgroup"],
+    t3[2]["frames_per_workgroup"], t3[2]["union_max_loose"], t3[2]["union_max_tight"], t3[2]["record_words_loose"],
+    t3[2]["record_words_tight"]), flush=True)
+a = ctx2.rows_dense(0, min(ctx2.N, 64 * 200)); b = ctx3.rows_dense(0, min(ctx3.N, 64 * 200))
+print("pattern equal", bool(np.array_equal(a != 0, b != 0)), "max rel diff", float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-300))), flush=True)
+for stop in (1, 3, 4):
+    t = run(ctx3, SITATOR_DEBUG_STOP=stop)
+    print("  gen3 debug_stop=%d: %.4f ms" % (stop, t[0]), flush=True)
+for nw, iw, fpb, scap in [(4, 32, 2, 384), (4, 32, 2, 640), (4, 16, 1, 320), (4, 16, 1, 384), (4, 24, 3, 448), (8, 32, 4, 384),
+                          (8, 16, 2, 320), (4, 32, 4, 640), (8, 32, 4, 640), (4, 28, 0, 512), (4, 21, 1, 384), (4, 32, 1, 640)]:
+    if M * max(fpb, 1) < iw:
+        continue
+    env = dict(SITATOR_FILL_WAVES=nw, SITATOR_FILL_IW=iw, SITATOR_FILL_SCAP=scap)
+    if fpb:
+        env["SITATOR_FILL_FPB"] = fpb
+    try:
+        t = run(ctx3, **env)
+        print("  nw %d iw %2d fpb %d scap %3d: min %.4f med %.4f ms (fpb used %d)" % (nw, iw, fpb, scap, t[0], t[1], t[2]["frames_per_workgroup"]), flush=True)
+    except AssertionError as e:
+        print("  nw %d iw %d fpb %d scap %d: failed %s" % (nw, iw, fpb, scap, e), flush=True)

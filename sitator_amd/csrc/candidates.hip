@@ -226,3 +226,106 @@ int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32
     *mean = (double)total / (double)nb;
     return SIT_OK;
 }
+
+// ---- per-bin RECORDS for the third-generation fill kernel (fill3.hip) --------------------------------------------
+// The candidate landmarks of a bin share vertices (in a simple-cubic host every static atom belongs to eight
+// landmarks), and the reference itself computes ONE distance per (ion, static atom) (landmark/helpers.pyx:174-178).
+// A record lists, for its bin, the candidate landmarks, the UNION of their vertices (in order of first appearance)
+// and, per (landmark, vertex), the position of that vertex in the union.  The kernel evaluates one squared distance
+// per (ion, union entry) and the landmark tasks gather from that small per-ion table.
+//
+// Layout in 4-byte words (records start on even words, so the slot bytes of a landmark can be fetched as 8 bytes):
+//   w0            = nL | nS << 16
+//   w[1 .. nL]    = landmark ids, ascending
+//   then          ceil(nS / 2) words of u16 static ids (the union)
+//   then (even-word aligned)  nL * Vp slot bytes (padded vertices: slot 0)
+namespace {
+
+__device__ __forceinline__ int rec_words(int nL, int nS, int Vp)
+{
+    int w = 1 + nL + (nS + 1) / 2;
+    w += w & 1;
+    w += nL * Vp / 4;
+    return w + (w & 1);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_rec_pass(const i32 *off, const i32 *list, const i32 *verts, int Vp, i64 nb,
+                                                  i32 *rsz, i32 *rec, i32 *stats)
+{
+    const i64 b = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb) return;
+    const i32 lo = off[b];
+    int nL = off[b + 1] - lo;
+    bool bad = nL > 255 || nL * Vp > 2040;
+    if (bad) nL = 0;
+    const i32 *lk = list + lo;
+    i32 *r = FILL ? rec + rsz[b] : nullptr;
+    unsigned short *st = nullptr;
+    unsigned char *sl = nullptr;
+    if (FILL) {
+        // sizes are known from the count pass: recompute nS by difference is not possible, so recount below
+        for (int c = 0; c < nL; c++) r[1 + c] = lk[c];
+        st = (unsigned short *)(r + 1 + nL);
+    }
+    int nS = 0;
+    // pass over the (landmark, vertex) sequence; an element is "new" if no earlier element has the same static id
+    for (int e = 0; e < nL * Vp; e++) {
+        const i32 v = verts[(i64)lk[e / Vp] * Vp + (e % Vp)];
+        if (v < 0) continue;
+        bool seen = false;
+        for (int q = 0; q < e && !seen; q++) seen = verts[(i64)lk[q / Vp] * Vp + (q % Vp)] == v;
+        if (!seen) {
+            if (FILL && nS < 255) st[nS] = (unsigned short)v;
+            nS++;
+        }
+    }
+    if (nS > 255) { bad = true; }
+    if (!FILL) {
+        if (bad) { atomicOr(&stats[3], 1); rsz[b + 1] = 2; return; }
+        rsz[b + 1] = rec_words(nL, nS, Vp);
+        atomicMax(&stats[4], nS);
+        return;
+    }
+    if (bad) { r[0] = 0; r[1] = 0; return; }
+    r[0] = nL | (nS << 16);
+    int w = 1 + nL + (nS + 1) / 2;
+    w += w & 1;
+    sl = (unsigned char *)(r + w);
+    for (int e = 0; e < nL * Vp; e++) {
+        const i32 v = verts[(i64)lk[e / Vp] * Vp + (e % Vp)];
+        int s = 0;
+        if (v >= 0) for (s = 0; s < nS && st[s] != (unsigned short)v; s++) {}
+        sl[e] = (unsigned char)s;
+    }
+}
+
+}  // namespace
+
+// Records of the table (d_off, d_list) with nb bins.  *ok = false when some bin does not fit a record (more than 255
+// landmarks / union entries, or static ids beyond 16 bits): the caller then keeps the second-generation kernel.
+int sit_build_records(sit_ctx *c, const i32 *d_off, const i32 *d_list, i64 nb, i32 **d_roff, i32 **d_rec, i64 *words,
+                      int *maxS, bool *ok)
+{
+    *ok = false;
+    if (c->S >= 65536 || c->Vp > 8) return SIT_OK;
+    int rc;
+    if ((rc = dev_alloc(c, d_roff, nb + 8))) return rc;
+    i32 *stats = *d_roff + nb + 1;
+    HIP_TRY(c, hipMemsetAsync(*d_roff, 0, (size_t)(nb + 8) * 4, c->stream));
+    const unsigned grid = (unsigned)((nb + 255) / 256);
+    k_rec_pass<false><<<dim3(grid), dim3(256), 0, c->stream>>>(d_off, d_list, c->d_verts, (int)c->Vp, nb, *d_roff, nullptr, stats);
+    k_cand_scan<<<dim3(1), dim3(1024), 0, c->stream>>>(*d_roff, nb, stats);
+    HIP_TRY(c, hipGetLastError());
+    i32 hs[5] = {0, 0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(hs, stats, 20, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const i64 total = (i64)hs[1] + ((i64)hs[2] << 31);
+    if (hs[3] || total > 1500000000LL) return SIT_OK;
+    if ((rc = dev_alloc(c, d_rec, total + 2))) return rc;
+    k_rec_pass<true><<<dim3(grid), dim3(256), 0, c->stream>>>(d_off, d_list, c->d_verts, (int)c->Vp, nb, *d_roff, *d_rec, stats);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *words = total; *maxS = hs[4]; *ok = true;
+    return SIT_OK;
+}

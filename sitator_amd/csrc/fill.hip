@@ -267,6 +267,11 @@ static int ensure_tight_table(sit_ctx *c)
     if (c->W_tight > 128) {  // F2_WTASK: an ion's tasks must fit one wave batch -> loose table for everything
         delta = -1.0;
     }
+    c->trec_ok = false;
+    if (delta >= 0 && c->fill_kernel == 3 && c->lrec_ok) {
+        const i64 nb = (i64)c->tG[0] * c->tG[1] * c->tG[2];
+        if ((rc = sit_build_records(c, c->d_tbin_off, c->d_tbin_list, nb, &c->d_troff, &c->d_trec, &c->trec_words, &c->trec_maxS, &c->trec_ok))) return rc;
+    }
     c->tight_delta = delta;
     c->tight_valid = true;
     return SIT_OK;
@@ -307,7 +312,7 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
     HIP_TRY(c, hipSetDevice(c->device));
     if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
     const i64 N = c->N, W = c->W;
-    const bool v2 = c->fill_kernel == 2 && c->W <= 128;   // F2_WTASK
+    const bool v2 = c->fill_kernel >= 2 && c->W <= 128;   // F2_WTASK
     bool assign = p->assign != 0;
     bool store = true;   // rows feed the predict kernel (wave-level fusion: see DESIGN.md)
     if (assign) SIT_REQUIRE(c, c->K > 0 && c->d_col_ptr, "sit_fill: assign requested but no centres set");
@@ -336,8 +341,9 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         }
         StageTimer timer(c, T_FILL);
         if (p->dynamic_lattice_mapping && (rc = launch_lattice_map(c, p))) return rc;
-        if (v2) rc = fill2_launch(c, p, store, assign, p->predict_threshold);
-        else rc = launch_fill_v1(c, p);
+        if (v2 && fill3_eligible(c)) rc = fill3_launch(c, p, store);
+        else if (v2) { c->last_kernel = 2; rc = fill2_launch(c, p, store, assign, p->predict_threshold); }
+        else { c->last_kernel = 1; rc = launch_fill_v1(c, p); }
         if (rc) return rc;
         timer.stop();
         // the assignment is enqueued behind the fill without waiting for the fill's error word: one host

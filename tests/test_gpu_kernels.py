@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _setup(host, M, F, seed, kernel="2", mutate=None):
+def _setup(host, M, F, seed, kernel="3", mutate=None):
     from sitator_amd import _lib, synth
     frames, sm, mm, ref = synth.make_trajectory(host, M, F, seed=seed)
     if mutate is not None:
@@ -33,18 +33,60 @@ def _setup(host, M, F, seed, kernel="2", mutate=None):
 
 @pytest.mark.parametrize("cfg,M,F", [("C2", 64, 200), ("C1b", 4, 500), ("C5", 160, 40)])
 def test_fill_generations_agree(cfg, M, F):
-    """v1 evaluates pow(acc, 1/n) with the library pow, v2 with square-root chains for n = 1, 2, 4, 8:
-    same sparsity pattern, values within a few ulp."""
+    """v1 evaluates pow(acc, 1/n) with the library pow, v2 with square-root chains for n = 1, 2, 4, 8, v3 also
+    replaces the library exp by a table-driven one (<= 0.52 ulp): same sparsity pattern, values within a few ulp."""
     from sitator_amd import synth
     host = synth.config_host(cfg)
     out = []
-    for kern in ("1", "2"):
+    for kern in ("1", "2", "3"):
         ctx, *_ = _setup(host, M, F, seed=77, kernel=kern)
         rc, nz, err = ctx.fill()
         assert rc == 0
+        assert ctx.info()["fill_kernel"] == int(kern), "the requested kernel generation did not run"
         out.append(ctx.rows_dense())
-    assert np.array_equal(out[0] != 0, out[1] != 0)
-    np.testing.assert_allclose(out[1], out[0], rtol=1e-14, atol=0)
+    for other in out[1:]:
+        assert np.array_equal(out[0] != 0, other != 0)
+        np.testing.assert_allclose(other, out[0], rtol=2e-14, atol=0)
+
+
+@pytest.mark.parametrize("cfg,M,F,dyn", [("C2", 64, 150, False), ("C2", 64, 60, True), ("C1b", 4, 400, True),
+                                         ("C5", 160, 30, False), ("C3", 448, 8, False)])
+def test_third_generation_rows_match_oracle(oracle, cfg, M, F, dyn):
+    """k_fill3 (one distance per (ion, static) pair, custom sqrt / division / exp) against the oracle's dense rows,
+    with and without dynamic lattice mapping; the zero pattern must be identical."""
+    from sitator_amd import synth
+    host = synth.config_host(cfg)
+    ctx, frames, sm, mm, ref = _setup(host, M, F, seed=19, kernel="3")
+    rc, nz, err = ctx.fill(dynamic_lattice_mapping=dyn, check_for_zeros=False)
+    assert rc == 0
+    assert ctx.info()["fill_kernel"] == 3
+    verts, vcd = oracle.site_vertex_distances(host.cell, host.centers, host.vertices, ref[sm])
+    exp, nz_exp = oracle.fill(host.cell, oracle.wrap_points(host.cell, frames), np.where(sm)[0], np.where(mm)[0],
+                              ref[sm], verts, vcd, check_for_zeros=False, dynamic_lattice_mapping=dyn)
+    got = ctx.rows_dense()
+    assert nz == nz_exp
+    assert np.array_equal(got != 0, exp != 0)
+    np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("iw,fpb,scap", [("16", "1", "320"), ("32", "2", "640"), ("7", "3", "64"), ("32", "4", "128")])
+def test_third_generation_launch_shapes_agree(iw, fpb, scap):
+    """Ions per wave chunk, frames per workgroup and the static-task capacity only change how the work is cut into
+    wave batches: rows are identical bit for bit."""
+    from sitator_amd import synth
+    host = synth.config_host("C2")
+    ctx, *_ = _setup(host, 64, 90, seed=23, kernel="3")
+    assert ctx.fill()[0] == 0
+    base = ctx.rows_dense()
+    os.environ["SITATOR_FILL_IW"], os.environ["SITATOR_FILL_FPB"], os.environ["SITATOR_FILL_SCAP"] = iw, fpb, scap
+    try:
+        assert ctx.fill()[0] == 0
+        assert ctx.info()["ions_per_wave"] == int(iw)
+        got = ctx.rows_dense()
+    finally:
+        for k in ("SITATOR_FILL_IW", "SITATOR_FILL_FPB", "SITATOR_FILL_SCAP"):
+            os.environ.pop(k, None)
+    assert np.array_equal(base, got)
 
 
 def test_fused_assign_equals_fill_then_predict(oracle):
