@@ -239,9 +239,8 @@ int sit_timers(sit_ctx *ctx, double *ms, int n);
  * [4] delta (sampled static displacement bound, A), [5] frames of the last fill that exceeded
  * delta, [6..8] loose grid, [9..11] tight grid, [12] frames per workgroup of the last fill,
  * [13] verified batches / [14] serially applied rows / [15] re-walks of the last speculative fit,
- * [16] generation of the fill kernel the last sit_fill launched (1, 2 or 3), [17] ions per wave chunk and
- * [18] waves per workgroup of that launch, [19] / [20] largest per-bin vertex union of the loose / tight
- * records, [21] / [22] their sizes in 4-byte words.                                                    */
+ * [16] generation of the fill kernel the last sit_fill launched (1, 2 or 3), [17] survivor slots per wave and
+ * [18] waves per workgroup of that launch.                                                              */
 int sit_info(sit_ctx *ctx, double *out, int n);
 int sit_synchronize(sit_ctx *ctx);
 

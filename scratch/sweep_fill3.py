@@ -32,24 +32,24 @@ ctx3, *_ = _setup(host, M, F, seed=2, kernel="3")
 ctx2, *_ = _setup(host, M, F, seed=2, kernel="2")
 t3 = run(ctx3)
 t2 = run(ctx2)
-print("%s F=%d  gen2 min %.4f med %.4f ms | gen3 min %.4f med %.4f ms (kernel %d iw %d nw %d fpb %d) unionmax %d/%d recwords %d/%d" % (
-    cfg, F, t2[0], t2[1], t3[0], t3[1], t3[2]["fill_kernel"], t3[2]["ions_per_wave"], t3[2]["waves_per_workgroup"],
-    t3[2]["frames_per_workgroup"], t3[2]["union_max_loose"], t3[2]["union_max_tight"], t3[2]["record_words_loose"],
-    t3[2]["record_words_tight"]), flush=True)
+print("%s F=%d  gen2 min %.4f med %.4f ms | gen3 min %.4f med %.4f ms (kernel %d rcap %d nw %d fpb %d)" % (
+    cfg, F, t2[0], t2[1], t3[0], t3[1], t3[2]["fill_kernel"], t3[2]["survivors_per_wave"], t3[2]["waves_per_workgroup"],
+    t3[2]["frames_per_workgroup"]), flush=True)
 a = ctx2.rows_dense(0, min(ctx2.N, 64 * 200)); b = ctx3.rows_dense(0, min(ctx3.N, 64 * 200))
 print("pattern equal", bool(np.array_equal(a != 0, b != 0)), "max rel diff", float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-300))), flush=True)
-for stop in (1, 3, 4):
+t = run(ctx3, reps=1, SITATOR_DEBUG_STOP=9)
+cs = t[2]["census"]; ni = F * M
+print("  census: landmark tasks/ion %.2f survivors/ion %.2f ions/batch %.2f" % (cs[1] / ni, cs[2] / ni, ni / max(cs[3], 1)), flush=True)
+for stop in (1, 4):
     t = run(ctx3, SITATOR_DEBUG_STOP=stop)
     print("  gen3 debug_stop=%d: %.4f ms" % (stop, t[0]), flush=True)
-for nw, iw, fpb, scap in [(4, 32, 2, 384), (4, 32, 2, 640), (4, 16, 1, 320), (4, 16, 1, 384), (4, 24, 3, 448), (8, 32, 4, 384),
-                          (8, 16, 2, 320), (4, 32, 4, 640), (8, 32, 4, 640), (4, 28, 0, 512), (4, 21, 1, 384), (4, 32, 1, 640)]:
-    if M * max(fpb, 1) < iw:
-        continue
-    env = dict(SITATOR_FILL_WAVES=nw, SITATOR_FILL_IW=iw, SITATOR_FILL_SCAP=scap)
-    if fpb:
-        env["SITATOR_FILL_FPB"] = fpb
+shapes = [(4, 1, 48), (4, 1, 40), (4, 1, 32), (4, 1, 64), (8, 1, 24), (8, 2, 48), (4, 2, 64), (16, 4, 48)]
+if len(sys.argv) > 3:
+    shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[3:]]
+for nw, fpb, rcap in shapes:
+    env = dict(SITATOR_FILL_WAVES=nw, SITATOR_FILL_FPB=fpb, SITATOR_FILL_RCAP=rcap)
     try:
         t = run(ctx3, **env)
-        print("  nw %d iw %2d fpb %d scap %3d: min %.4f med %.4f ms (fpb used %d)" % (nw, iw, fpb, scap, t[0], t[1], t[2]["frames_per_workgroup"]), flush=True)
+        print("  nw %2d fpb %d rcap %2d: min %.4f med %.4f ms" % (nw, fpb, rcap, t[0], t[1]), flush=True)
     except AssertionError as e:
-        print("  nw %d iw %d fpb %d scap %d: failed %s" % (nw, iw, fpb, scap, e), flush=True)
+        print("  nw %d fpb %d rcap %d: failed %s" % (nw, fpb, rcap, e), flush=True)

@@ -441,8 +441,8 @@ class HipContext(object):
         return dict(zip(["fill", "fit", "predict", "gram", "site_centers", "occupancy", "h2d"], t))
 
     def info(self):
-        v = np.zeros(24)
-        self.lib.sit_info(self._h, _d(v), 24)
+        v = np.zeros(28)
+        self.lib.sit_info(self._h, _d(v), 28)
         keys = ["row_width", "mean_candidates_loose", "tight_width", "mean_candidates_tight", "delta",
                 "fallback_frames"]
         out = dict(zip(keys, v[:6]))
@@ -450,9 +450,8 @@ class HipContext(object):
         out["grid_tight"] = [int(x) for x in v[9:12]]
         out["frames_per_workgroup"] = int(v[12])
         out["fit_batches"], out["fit_serial_rows"], out["fit_rewalks"] = int(v[13]), int(v[14]), int(v[15])
-        out["fill_kernel"], out["ions_per_wave"], out["waves_per_workgroup"] = int(v[16]), int(v[17]), int(v[18])
-        out["union_max_loose"], out["union_max_tight"] = int(v[19]), int(v[20])
-        out["record_words_loose"], out["record_words_tight"] = int(v[21]), int(v[22])
+        out["fill_kernel"], out["survivors_per_wave"], out["waves_per_workgroup"] = int(v[16]), int(v[17]), int(v[18])
+        out["census"] = [float(x) for x in v[24:28]]
         return out
 
     def synchronize(self):

@@ -16,7 +16,7 @@
 //
 // One workgroup per landmark walks the bins of the box around the landmark's tightest vertex:
 // pass 1 counts the landmarks per bin, a scan turns the counts into offsets, pass 2 repeats the
-// tests and scatters, pass 3 sorts every bin's (short) list.
+// tests and scatters (with each entry's critical vertex), pass 3 sorts every bin's (short) list.
 #include <algorithm>
 #include <cmath>
 
@@ -34,7 +34,7 @@ struct CandArgs {
     double rz, displacement, rb;
     i32 *cnt;                  // [nb + 1] counts, then offsets
     i32 *cursor;               // [nb]
-    i32 *list;
+    i32 *list;                 // scatter pass: landmark | critical vertex << 24 (split off after the sort)
 };
 
 __device__ __forceinline__ void matvec_d(const double *m, const double *v, double *o)
@@ -61,6 +61,26 @@ __device__ bool within_periodic(const CandArgs &a, const double *d, double T)
                 if (r[0] * r[0] + r[1] * r[1] + r[2] * r[2] <= T2) return true;
             }
     return false;
+}
+
+// squared periodic distance min_L |d + L|^2, searched over the images that can be closer than T
+__device__ double periodic_dist2(const CandArgs &a, const double *d, double T)
+{
+    double f[3];
+    matvec_d(a.ci, d, f);
+    int n[3];
+    for (int i = 0; i < 3; i++) { f[i] -= floor(f[i] + 0.5); n[i] = (int)floor(T / a.h[i] + 0.5); }
+    double best = 1e300;
+    for (int ia = -n[0]; ia <= n[0]; ia++)
+        for (int ib = -n[1]; ib <= n[1]; ib++)
+            for (int ig = -n[2]; ig <= n[2]; ig++) {
+                const double ff[3] = {f[0] + ia, f[1] + ib, f[2] + ig};
+                double r[3];
+                matvec_d(a.cm, ff, r);
+                const double r2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+                best = r2 < best ? r2 : best;
+            }
+    return best;
 }
 
 __device__ __forceinline__ double bound_of(const CandArgs &a, i64 k, i64 h)
@@ -117,7 +137,22 @@ __global__ __launch_bounds__(256) void k_cand_pass(CandArgs a)
         if (!ok) continue;
         const i64 b = ((i64)bx * a.G[1] + by) * a.G[2] + bz;
         if (!FILL) atomicAdd(&a.cnt[b + 1], 1);
-        else a.list[a.cnt[b] + atomicAdd(&a.cursor[b], 1)] = (i32)k;
+        else {
+            // the CRITICAL vertex of (bin, landmark): the one with the least room between the bin centre's distance
+            // and its bound - the vertex most likely to put an ion of this bin beyond the cut-off (fill3.hip tests
+            // it first).  Any choice is correct; this one is the cheapest on average.
+            int crit = 0;
+            double room = 1e300;
+            if (a.D < (1LL << 24))
+                for (i64 h = 0; h < nv; h++) {
+                    const double *p = a.ref_static + 3 * a.verts[k * a.Vp + h];
+                    const double d[3] = {p[0] - cb[0], p[1] - cb[1], p[2] - cb[2]};
+                    const double bd = bound_of(a, k, h);
+                    const double m = bd - sqrt(periodic_dist2(a, d, bd));
+                    if (m < room) { room = m; crit = (int)h; }
+                }
+            a.list[a.cnt[b] + atomicAdd(&a.cursor[b], 1)] = (i32)k | (crit << 24);
+        }
     }
 }
 
@@ -146,18 +181,24 @@ __global__ __launch_bounds__(1024) void k_cand_scan(i32 *cnt, i64 nb, i32 *stats
     for (i64 i = lo; i < hi; i++) { acc += cnt[i]; cnt[i] = (i32)acc; }
 }
 
-// ascending k inside every bin (the scatter order is arbitrary)
-__global__ __launch_bounds__(256) void k_cand_sort(const i32 *off, i32 *list, i64 nb)
+// ascending k inside every bin (the scatter order is arbitrary); the critical vertex moves to its own array
+__global__ __launch_bounds__(256) void k_cand_sort(const i32 *off, i32 *list, unsigned char *crit, i64 nb, int packed)
 {
     const i64 b = (i64)blockIdx.x * 256 + threadIdx.x;
     if (b >= nb) return;
     i32 *l = list + off[b];
+    unsigned char *cr = crit + off[b];
     const int n = off[b + 1] - off[b];
+    const i32 km = packed ? 0xffffff : 0x7fffffff;
     for (int i = 1; i < n; i++) {
         const i32 v = l[i];
         int j = i - 1;
-        while (j >= 0 && l[j] > v) { l[j + 1] = l[j]; j--; }
+        while (j >= 0 && (l[j] & km) > (v & km)) { l[j + 1] = l[j]; j--; }
         l[j + 1] = v;
+    }
+    for (int i = 0; i < n; i++) {
+        cr[i] = packed ? (unsigned char)((unsigned)l[i] >> 24) : (unsigned char)0;
+        l[i] &= km;
     }
 }
 
@@ -165,8 +206,8 @@ __global__ __launch_bounds__(256) void k_cand_sort(const i32 *off, i32 *list, i6
 
 // Builds the table for static displacements up to `displacement` with bins of about `bin_target` Angstrom; the
 // table stays on the device (*d_off [nb+1], *d_list).  W = widest bin, mean = landmarks per bin.
-int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32 **d_off, i32 **d_list, int G_out[3],
-                         i64 *W, double *mean)
+int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32 **d_off, i32 **d_list,
+                         unsigned char **d_crit, int G_out[3], i64 *W, double *mean)
 {
     CandArgs a;
     double len[3];
@@ -216,116 +257,14 @@ int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32
     const i64 total = (i64)hs[1] + ((i64)hs[2] << 31);
     if (total > 2000000000LL) { (void)hipFree(cursor); c->msg = "candidate table too large"; return SIT_ERR_CAPACITY; }
     if ((rc = dev_alloc(c, d_list, total > 0 ? total : 1))) { (void)hipFree(cursor); return rc; }
+    if ((rc = dev_alloc(c, d_crit, total > 0 ? total : 1))) { (void)hipFree(cursor); return rc; }
     a.list = *d_list;
     k_cand_pass<true><<<dim3((unsigned)c->D), dim3(256), 0, c->stream>>>(a);
-    k_cand_sort<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(*d_off, *d_list, nb);
+    k_cand_sort<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(*d_off, *d_list, *d_crit, nb, c->D < (1LL << 24) ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     (void)hipFree(cursor);
     *W = hs[0] > 0 ? hs[0] : 1;
     *mean = (double)total / (double)nb;
-    return SIT_OK;
-}
-
-// ---- per-bin RECORDS for the third-generation fill kernel (fill3.hip) --------------------------------------------
-// The candidate landmarks of a bin share vertices (in a simple-cubic host every static atom belongs to eight
-// landmarks), and the reference itself computes ONE distance per (ion, static atom) (landmark/helpers.pyx:174-178).
-// A record lists, for its bin, the candidate landmarks, the UNION of their vertices (in order of first appearance)
-// and, per (landmark, vertex), the position of that vertex in the union.  The kernel evaluates one squared distance
-// per (ion, union entry) and the landmark tasks gather from that small per-ion table.
-//
-// Layout in 4-byte words (records start on even words, so the slot bytes of a landmark can be fetched as 8 bytes):
-//   w0            = nL | nS << 16
-//   w[1 .. nL]    = landmark ids, ascending
-//   then          ceil(nS / 2) words of u16 static ids (the union)
-//   then (even-word aligned)  nL * Vp slot bytes (padded vertices: slot 0)
-namespace {
-
-__device__ __forceinline__ int rec_words(int nL, int nS, int Vp)
-{
-    int w = 1 + nL + (nS + 1) / 2;
-    w += w & 1;
-    w += nL * Vp / 4;
-    return w + (w & 1);
-}
-
-template <bool FILL>
-__global__ __launch_bounds__(256) void k_rec_pass(const i32 *off, const i32 *list, const i32 *verts, int Vp, i64 nb,
-                                                  i32 *rsz, i32 *rec, i32 *stats)
-{
-    const i64 b = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (b >= nb) return;
-    const i32 lo = off[b];
-    int nL = off[b + 1] - lo;
-    bool bad = nL > 255 || nL * Vp > 2040;
-    if (bad) nL = 0;
-    const i32 *lk = list + lo;
-    i32 *r = FILL ? rec + rsz[b] : nullptr;
-    unsigned short *st = nullptr;
-    unsigned char *sl = nullptr;
-    if (FILL) {
-        // sizes are known from the count pass: recompute nS by difference is not possible, so recount below
-        for (int c = 0; c < nL; c++) r[1 + c] = lk[c];
-        st = (unsigned short *)(r + 1 + nL);
-    }
-    int nS = 0;
-    // pass over the (landmark, vertex) sequence; an element is "new" if no earlier element has the same static id
-    for (int e = 0; e < nL * Vp; e++) {
-        const i32 v = verts[(i64)lk[e / Vp] * Vp + (e % Vp)];
-        if (v < 0) continue;
-        bool seen = false;
-        for (int q = 0; q < e && !seen; q++) seen = verts[(i64)lk[q / Vp] * Vp + (q % Vp)] == v;
-        if (!seen) {
-            if (FILL && nS < 255) st[nS] = (unsigned short)v;
-            nS++;
-        }
-    }
-    if (nS > 255) { bad = true; }
-    if (!FILL) {
-        if (bad) { atomicOr(&stats[3], 1); rsz[b + 1] = 2; return; }
-        rsz[b + 1] = rec_words(nL, nS, Vp);
-        atomicMax(&stats[4], nS);
-        return;
-    }
-    if (bad) { r[0] = 0; r[1] = 0; return; }
-    r[0] = nL | (nS << 16);
-    int w = 1 + nL + (nS + 1) / 2;
-    w += w & 1;
-    sl = (unsigned char *)(r + w);
-    for (int e = 0; e < nL * Vp; e++) {
-        const i32 v = verts[(i64)lk[e / Vp] * Vp + (e % Vp)];
-        int s = 0;
-        if (v >= 0) for (s = 0; s < nS && st[s] != (unsigned short)v; s++) {}
-        sl[e] = (unsigned char)s;
-    }
-}
-
-}  // namespace
-
-// Records of the table (d_off, d_list) with nb bins.  *ok = false when some bin does not fit a record (more than 255
-// landmarks / union entries, or static ids beyond 16 bits): the caller then keeps the second-generation kernel.
-int sit_build_records(sit_ctx *c, const i32 *d_off, const i32 *d_list, i64 nb, i32 **d_roff, i32 **d_rec, i64 *words,
-                      int *maxS, bool *ok)
-{
-    *ok = false;
-    if (c->S >= 65536 || c->Vp > 8) return SIT_OK;
-    int rc;
-    if ((rc = dev_alloc(c, d_roff, nb + 8))) return rc;
-    i32 *stats = *d_roff + nb + 1;
-    HIP_TRY(c, hipMemsetAsync(*d_roff, 0, (size_t)(nb + 8) * 4, c->stream));
-    const unsigned grid = (unsigned)((nb + 255) / 256);
-    k_rec_pass<false><<<dim3(grid), dim3(256), 0, c->stream>>>(d_off, d_list, c->d_verts, (int)c->Vp, nb, *d_roff, nullptr, stats);
-    k_cand_scan<<<dim3(1), dim3(1024), 0, c->stream>>>(*d_roff, nb, stats);
-    HIP_TRY(c, hipGetLastError());
-    i32 hs[5] = {0, 0, 0, 0, 0};
-    HIP_TRY(c, hipMemcpyAsync(hs, stats, 20, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const i64 total = (i64)hs[1] + ((i64)hs[2] << 31);
-    if (hs[3] || total > 1500000000LL) return SIT_OK;
-    if ((rc = dev_alloc(c, d_rec, total + 2))) return rc;
-    k_rec_pass<true><<<dim3(grid), dim3(256), 0, c->stream>>>(d_off, d_list, c->d_verts, (int)c->Vp, nb, *d_roff, *d_rec, stats);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *words = total; *maxS = hs[4]; *ok = true;
     return SIT_OK;
 }

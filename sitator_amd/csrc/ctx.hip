@@ -44,7 +44,7 @@ extern "C" void sit_destroy(sit_ctx *c)
                     c->frames_owned ? c->d_frames : nullptr, c->d_static_idx, c->d_mobile_idx,
                     c->d_lattice_map, c->d_tbin_off, c->d_tbin_list, c->d_fill_args, c->d_frame_dmax, c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs,
                     c->d_counts, c->d_col_ptr, c->d_col_k, c->d_col_val, c->d_cen_dense, c->d_fit_centers,
-                    c->d_hi2p, c->d_vr, c->d_nv, c->d_exptab, c->d_lroff, c->d_lrec, c->d_troff, c->d_trec,
+                    c->d_hi2p, c->d_vr, c->d_nv, c->d_exptab, c->d_bin_crit, c->d_tbin_crit,
                     c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scal, c->d_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     fitfast_free(c);
@@ -68,13 +68,13 @@ extern "C" int sit_timers(sit_ctx *c, double *ms, int n)
 extern "C" int sit_info(sit_ctx *c, double *out, int n)
 {
     if (!c || !out) return SIT_ERR_INVALID;
-    const double v[24] = {(double)c->W, c->mean_candidates, (double)c->W_tight, c->tight_mean_candidates,
+    const double v[28] = {(double)c->W, c->mean_candidates, (double)c->W_tight, c->tight_mean_candidates,
                           c->tight_delta, (double)c->fallback_frames, (double)c->G[0], (double)c->G[1],
                           (double)c->G[2], (double)c->tG[0], (double)c->tG[1], (double)c->tG[2], (double)c->last_fpb,
                           (double)c->ff_batches, (double)c->ff_serial_rows, (double)c->ff_rewalks,
-                          (double)c->last_kernel, (double)c->last_iw, (double)c->last_nw, (double)c->lrec_maxS,
-                          (double)c->trec_maxS, (double)c->lrec_words, (double)c->trec_words, 0.0};
-    for (int i = 0; i < n; i++) out[i] = i < 24 ? v[i] : 0.0;
+                          (double)c->last_kernel, (double)c->last_iw, (double)c->last_nw, 0.0, 0.0, 0.0, 0.0, 0.0,
+                          c->census[0], c->census[1], c->census[2], c->census[3]};
+    for (int i = 0; i < n; i++) out[i] = i < 28 ? v[i] : 0.0;
     return SIT_OK;
 }
 
@@ -256,20 +256,14 @@ extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const 
     if ((rc = dev_upload(c, &c->d_vcd, vcdp.data(), D * Vp))) return rc;
     if ((rc = dev_upload(c, &c->d_hi2, hi2.data(), D * Vp))) return rc;
     // loose table: valid for any frame the static-lattice check accepts (displacement <= static_thr), 1 A bins
-    if ((rc = sit_build_candidates(c, static_thr, 1.0, &c->d_bin_off, &c->d_bin_list, c->G, &c->W, &c->mean_candidates))) return rc;
+    if ((rc = sit_build_candidates(c, static_thr, 1.0, &c->d_bin_off, &c->d_bin_list, &c->d_bin_crit, c->G, &c->W, &c->mean_candidates))) return rc;
     c->cell_diagonal = true;
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++)
             if (i != j && (c->pbc.cm[3 * i + j] != 0.0 || c->pbc.ci[3 * i + j] != 0.0)) c->cell_diagonal = false;
     const char *fk = getenv("SITATOR_FILL_KERNEL");
     c->fill_kernel = (fk && fk[0] == '1') ? 1 : ((fk && fk[0] == '2') ? 2 : 3);
-    // third-generation fill: per-bin records of the loose table (the tight table's follow in sit_fill)
     for (void **q : {(void **)&c->d_hi2p, (void **)&c->d_vr, (void **)&c->d_nv}) if (*q) { (void)hipFree(*q); *q = nullptr; }
-    c->lrec_ok = false; c->trec_ok = false;
-    if (c->fill_kernel == 3 && c->W <= 128) {
-        const i64 nb = (i64)c->G[0] * c->G[1] * c->G[2];
-        if ((rc = sit_build_records(c, c->d_bin_off, c->d_bin_list, nb, &c->d_lroff, &c->d_lrec, &c->lrec_words, &c->lrec_maxS, &c->lrec_ok))) return rc;
-    }
     c->tight_valid = false;
     c->rows_valid = false; c->assign_valid = false; c->map_valid = false;
     return SIT_OK;
@@ -296,6 +290,10 @@ static int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S
     int rc;
     if ((rc = dev_upload(c, &c->d_static_idx, s32.data(), S))) return rc;
     if ((rc = dev_upload(c, &c->d_mobile_idx, m32.data(), M))) return rc;
+    c->idx_contig = true;
+    for (i64 i = 1; i < S; i++) if (s32[(size_t)i] != s32[0] + (i32)i) c->idx_contig = false;
+    for (i64 i = 1; i < M; i++) if (m32[(size_t)i] != m32[0] + (i32)i) c->idx_contig = false;
+    c->idx_s0 = s32[0]; c->idx_m0 = m32[0];
     c->F = F; c->A = A; c->M = M; c->frame0 = frame0; c->N = F * M;
     c->rows_valid = false; c->assign_valid = false; c->map_valid = false; c->tight_valid = false;
     return SIT_OK;

@@ -263,14 +263,9 @@ static int ensure_tight_table(sit_ctx *c)
     for (double d : sample) if (d == d && d <= c->static_thr && d > mx) mx = d;
     double delta = mx * 1.15 + 0.02;
     if (delta > c->static_thr) delta = c->static_thr;
-    if ((rc = sit_build_candidates(c, delta, 0.5, &c->d_tbin_off, &c->d_tbin_list, c->tG, &c->W_tight, &c->tight_mean_candidates))) return rc;
+    if ((rc = sit_build_candidates(c, delta, 0.5, &c->d_tbin_off, &c->d_tbin_list, &c->d_tbin_crit, c->tG, &c->W_tight, &c->tight_mean_candidates))) return rc;
     if (c->W_tight > 128) {  // F2_WTASK: an ion's tasks must fit one wave batch -> loose table for everything
         delta = -1.0;
-    }
-    c->trec_ok = false;
-    if (delta >= 0 && c->fill_kernel == 3 && c->lrec_ok) {
-        const i64 nb = (i64)c->tG[0] * c->tG[1] * c->tG[2];
-        if ((rc = sit_build_records(c, c->d_tbin_off, c->d_tbin_list, nb, &c->d_troff, &c->d_trec, &c->trec_words, &c->trec_maxS, &c->trec_ok))) return rc;
     }
     c->tight_delta = delta;
     c->tight_valid = true;
@@ -353,9 +348,10 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         if (assign && (rc = sit_predict_internal(c, p->predict_threshold))) return rc;
         u64 *hb = (u64 *)c->h_pinned;          // [0] error key, [1..4] scalars
         HIP_TRY(c, hipMemcpyAsync(hb, c->d_err, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(hb + 1, c->d_scal, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(hb + 1, c->d_scal, 64, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const u64 hkey = hb[0], hs[4] = {hb[1], hb[2], hb[3], hb[4]};
+        for (int q = 0; q < 4; q++) c->census[q] = (double)hb[5 + q];
         if (n_all_zero) *n_all_zero = (i64)hs[0];
         c->fallback_frames = (i64)hs[2];
         const int kind = decode_error(c, hkey, err);

@@ -1,16 +1,17 @@
-// Landmark-vector fill, third generation (the one `sit_fill` launches by default when the tables allow it).
+// Landmark-vector fill, third generation (the one `sit_fill` launches by default for landmarks of up to 8 vertices).
 //
 // Same result as fill2.hip / fill.hip (landmark/helpers.pyx:12-212 in the reference's operation order, FP64, no
-// contraction of the reference's expressions); what changes is where the instructions go.  The second generation
-// was VALU-issue-bound at ~100 wave-instructions per ion, less than half of them arithmetic of the reference:
-//   * it computed the distance of a (ion, static atom) pair once per LANDMARK that has the atom as a vertex (and a
-//     second time for the survivors of the screening).  The reference computes it once per pair
-//     (helpers.pyx:174-178) - so does this kernel: the per-bin RECORDS (candidates.hip) list the union of the
-//     candidates' vertices, one lane evaluates one (ion, union entry) squared distance into a wave-private LDS
-//     table, and the landmark tasks only gather from it;
-//   * every list was flattened by a lane that looped over its own entries (serial in the longest list of the wave).
-//     Here a lane finds its (ion, entry) from one marker byte and a DPP max-scan, and every table address is
-//     `per-ion constant + stride * task`, so the bookkeeping per task is a handful of instructions;
+// contraction of the reference's expressions); what changes is where the instructions and the waiting go.  The second
+// generation was VALU-issue-bound at ~100 wave-instructions per ion, less than half of them arithmetic of the
+// reference, and every wave kept private task lists:
+//   * a workgroup (one frame of a 64-ion system) works through its ions 64 at a time, every stage spread over all
+//     its waves: ONE wave owns the ions (a lane each: bin, candidate list, offset vector) and writes a flat task
+//     table; all waves then take (landmark task, vertex) LANES - eight lanes per task, one squared distance each,
+//     compared against (rz * vcd)^2 - so a pass has no per-lane loops and no divergence;
+//   * the tasks whose eight lanes all pass are compacted with two ballots into a wave-private region of survivors
+//     (their squared distances, 64 bytes each); the logistic factors are then evaluated one lane per (survivor,
+//     vertex) IN PLACE, multiplied in vertex order by one lane per survivor, and that lane writes the row entry
+//     directly (its position in the row is a population count over the non-zero masks of the workgroup);
 //   * sqrt, the two divisions and exp went through the general-purpose library sequences (range scaling, special
 //     cases, a degree-11 polynomial).  The operands here have known ranges, so: sqrt = the library's own
 //     Newton sequence without the range scaling (bit-identical for normal operands), dist/vcd = multiplication
@@ -18,27 +19,26 @@
 //     random trials), 1/(1+e) = the library's sequence without scaling, exp = 128-entry hi/lo table + degree-5
 //     polynomial (max error 0.512 ulp, agrees with glibc in 99.75 % of arguments - closer to the reference's libm
 //     than the device library's exp);
-//   * the logistic factors of a landmark are multiplied in vertex order by ONE lane from an LDS staging buffer
-//     (was: partial products handed from lane to lane).
-// Kept from fill2: phase 1 (stream, wrap, static check, park statics in LDS), tight/loose tables, error keys,
-// slot-major sparse rows, exactness rules.
+//   * the frames are copied into LDS as straight runs of doubles (eight loads per thread in flight) and wrapped in
+//     place; the static-lattice check first tries the plain displacement, which bounds the periodic one.
+// LDS per workgroup is ~35 KB at 64 ions and 512 statics (16 waves per CU) and a batch costs two workgroup barriers.
+// Kept from fill2: tight/loose pruning tables, error keys, slot-major sparse rows, exactness rules.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 
 #include "sit_internal.h"
 
-#define F3_IWMAX 32        // ions per wave chunk (upper bound)
-#define F3_LCAP 128        // landmark tasks per wave batch
-#define F3_POOL 128        // survivors pooled before they are evaluated
 #define F3_EXPN 128
 
 struct Fill3Args {
+    const i32 *verts;                 // [D,Vp], -1 padded
     const double *hi2p;               // [D,Vp] squared screening bound, +inf on padding
     const double2 *vr;                // [D,Vp] {vcd, 1/vcd}
     const unsigned char *nvtab;       // [D]
-    const i32 *t_roff, *t_rec;        // tight records
-    const i32 *l_roff, *l_rec;        // loose records
+    const i32 *t_off, *t_list;        // tight table
+    const i32 *l_off, *l_list;        // loose table (static_movement_threshold)
+    const unsigned char *t_crit, *l_crit;   // critical vertex of every list entry
     const i32 *lattice_map;           // [F,S] or null
     i32 *row_nnz, *row_idx;
     double *row_val;
@@ -58,7 +58,7 @@ struct Fill3Head {
     const double2 *exptab;
     u64 *err, *scal;
     i64 F, A, frame0;
-    int S, M, fpb, dyn, debug_stop, iw, scap, force_loose;
+    int S, M, fpb, contig, debug_stop, rcap, force_loose, s0, m0;
     double delta2, thr2_lo, thr2_hi, static_thr, safe2;
 };
 typedef const Fill3Args __attribute__((address_space(4))) *Fill3ArgsPtr;
@@ -193,98 +193,142 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
     return (b0 * G1 + b1) * G2 + b2;
 }
 
-// per-wave LDS, in bytes, for a static-task capacity `scap` (multiple of 64)
-__host__ __device__ inline int f3_wave_bytes(int scap, int vp)
+// inclusive sum scan over the 64 lanes
+__device__ __forceinline__ int wave_add_scan(int x)
 {
-    return scap * 8              // d2buf
-         + F3_LCAP * 8           // tval
-         + 256 * 8               // fbuf: 64 survivors x 4 vertices
-         + F3_LCAP * 4           // tk
-         + F3_POOL * 4           // pool: landmark | nv << 24
-         + F3_IWMAX * 16         // info
-         + F3_POOL * vp * 2      // pool: d2buf positions of the vertices
-         + F3_POOL * 2           // pool: task of the survivor
-         + scap                  // static-task markers
-         + F3_LCAP;              // landmark-task markers
+#define F3_DPP(ctrl, rmask) __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false)
+    x += F3_DPP(0x111, 0xf);
+    x += F3_DPP(0x112, 0xf);
+    x += F3_DPP(0x114, 0xf);
+    x += F3_DPP(0x118, 0xf);
+    x += F3_DPP(0x142, 0xa);
+    x += F3_DPP(0x143, 0xc);
+#undef F3_DPP
+    return x;
 }
 
-// LG: log2 of the padded vertices per landmark (2 or 3).  NW: waves per workgroup.
-template <int CELL, int LG, int NW>
+// LDS of a workgroup besides the frames, in bytes: `rcap` survivors per wave (multiple of 8, <= 64), NW waves
+__host__ __device__ inline int f3_pool_bytes(int rcap, int vp, int nw)
+{
+    return nw * rcap * vp * 8    // sd2: squared distances, then logistic factors, of the survivors
+         + nw * 128 * 4          // ttab: landmark | ion << 24 per task (128 tasks per wave and batch)
+         + nw * rcap * 4         // sv_k: landmark | nv << 24 per survivor
+         + 64 * 16               // info: per ion of the window {offset vector, statics of its frame (xyz indices), frame}
+         + 64 * 4 * 6            // first / last survivor of an ion (two parities), entries written per ion, pending counts
+         + 16 * 8                // non-zero masks, one word per wave
+         + 64;                   // batch parameters
+}
+
+// LG: log2 of the padded vertices per landmark (2 or 3).  NW: waves per workgroup.  DYN: dynamic lattice mapping
+// (static ids go through the frame's lattice map; the static-lattice check was made by k_lattice_map).
+// h.contig: 2 = the workgroup's atoms are one run of doubles in memory (statics then mobiles, nothing else),
+// 1 = static_idx / mobile_idx are two consecutive ranges, 0 = arbitrary index lists.
+template <int CELL, int LG, int NW, int DYN>
 __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr full)
 {
     constexpr int VP = 1 << LG;
+    constexpr int NT = NW * 64;
+    constexpr int TPP = 64 >> LG;                               // tasks per pass of 64 lanes
+    constexpr int LCAP = 128 * NW;                              // landmark tasks per batch
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int S = h.S, M = h.M;
+    const int S = h.S, M = h.M, SM = S + M;
     const int fpb = h.fpb;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // layout: [per-wave buffers] [exp table] [statics] [mobiles] [frame flags]
-    const int wbytes = f3_wave_bytes(h.scap, VP);
-    char *wb = smem + wave * wbytes;
-    double *d2buf = (double *)wb;
-    double *tval = d2buf + h.scap;
-    double *fbuf = tval + F3_LCAP;
-    i32 *tk = (i32 *)(fbuf + 256);
-    i32 *pool_k = tk + F3_LCAP;
-    uint4 *info = (uint4 *)(pool_k + F3_POOL);
-    unsigned short *pool_a = (unsigned short *)(info + F3_IWMAX);
-    unsigned short *pool_t = pool_a + F3_POOL * VP;
-    unsigned char *smark = (unsigned char *)(pool_t + F3_POOL);
-    unsigned char *lmark = smark + h.scap;
-    double2 *etab = (double2 *)(smem + NW * wbytes);
-    double *sxyz = (double *)(etab + F3_EXPN);                  // [fpb][S][3] wrapped statics
-    double *mo = sxyz + 3 * fpb * S;                            // [fpb*M][3] wrapped ions, then centroid - ion
-    u64 *fmax = (u64 *)(mo + 3 * fpb * M);                      // [fpb]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rcap = h.rcap;
+    // layout: [pooled buffers] [exp table] [atoms: per frame statics then mobiles] [frame flags]
+    char *lp = smem;
+    double *sd2 = (double *)lp; lp += NW * rcap * VP * 8;
+    unsigned *ttab = (unsigned *)lp; lp += LCAP * 4;
+    unsigned *sv_k = (unsigned *)lp; lp += NW * rcap * 4;
+    uint4 *info = (uint4 *)lp; lp += 64 * 16;
+    unsigned *ifirst = (unsigned *)lp; lp += 64 * 4 * 2;        // [parity][ion]
+    unsigned *ilast = (unsigned *)lp; lp += 64 * 4 * 2;
+    unsigned *nzc = (unsigned *)lp; lp += 64 * 4;
+    unsigned *nzpend = (unsigned *)lp; lp += 64 * 4;
+    unsigned long long *nzmask = (unsigned long long *)lp; lp += 16 * 8;
+    int *bp = (int *)lp; lp += 64;
+    double2 *etab = (double2 *)lp; lp += F3_EXPN * 16;
+    double *xyz = (double *)lp;                                 // [fpb][S + M][3]; mobiles become centroid - ion
+    u64 *fmax = (u64 *)(xyz + 3 * fpb * SM);                    // [fpb]
     const Pbc &P = h.P;
     const i64 f0 = (i64)blockIdx.x * fpb;
     const int nf = (int)((h.F - f0) < fpb ? (h.F - f0) : fpb);
-    const int SM = S + M;
-    const bool dyn = h.dyn != 0;
     const u64 errw = (u64)(S + 1 + M);
 
     if (tid < fpb) fmax[tid] = 0ull;
     if (tid < F3_EXPN) etab[tid] = h.exptab[tid];
-    __syncthreads();
-    // ---- phase 1: stream the frames, wrap (Step 0), static-lattice check (helpers.pyx:57-80) ----
-    const double *fbase = h.frames + f0 * h.A * 3;
-    for (int t = tid; t < nf * SM; t += NW * 64) {
-        int fl = 0;
-        for (int q = 1; q < nf; q++) fl += t >= q * SM;
-        const int r = t - fl * SM;
-        const int atom = r < S ? h.static_idx[r] : h.mobile_idx[r - S];
-        const double *p = fbase + (unsigned)(fl * (int)h.A + atom) * 3u;
-        double x = p[0], y = p[1], z = p[2];
-        wrapc3<CELL>(P, x, y, z);
-        if (r < S) {
-            { double *d = sxyz + 3 * (fl * S + r); d[0] = x; d[1] = y; d[2] = z; }
-            if (!dyn) {
-                const double *rp = h.ref_static + 3 * r;
-                const double rx = rp[0], ry = rp[1], rz_ = rp[2];
-                // plain displacement: it bounds the periodic one, and while it is shorter than 0.45 cell heights
-                // the shifted atom is inside the cell, where the reference's wrap changes it by rounding only -
-                // no error, no beyond-delta flag (safe2 is below both bounds)
-                const double ex = x - rx, ey = y - ry, ez = z - rz_;
-                const double e2 = (ex * ex + ey * ey) + ez * ez;
-                if (!(e2 <= h.safe2)) {
-                    // PBCCalculator.distances(ref, atom) (util/PBCCalculator.pyx:64-103), squared; the sqrt is
-                    // taken only inside the rounding band around static_movement_threshold^2
-                    double qx = x + (P.cen[0] - rx), qy = y + (P.cen[1] - ry), qz = z + (P.cen[2] - rz_);
-                    wrapc3<CELL>(P, qx, qy, qz);
-                    const double dx = -qx + P.cen[0], dy = -qy + P.cen[1], dz = -qz + P.cen[2];
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (d2 > h.delta2) {
-                        atomicOr(&fmax[fl], 1ull);
-                        if (d2 > h.thr2_lo && (d2 > h.thr2_hi || sqrt(d2) > h.static_thr))
-                            atomicMin(h.err, (u64)(h.frame0 + f0 + fl) * errw + (u64)r);
-                    }
-                }
+    for (int q = tid; q < LCAP; q += NT) ttab[q] = 0u;         // stale entries must stay valid (landmark 0, ion 0)
+    if (tid < 64) info[tid] = make_uint4(0u, 0u, 0u, 0u);
+    // ---- phase 1a: copy this workgroup's atoms into LDS, eight independent loads per thread in flight ----
+    {
+        const double *fbase = h.frames + f0 * h.A * 3;
+        if (h.contig == 2) {
+            const int n = nf * SM * 3;
+            for (int e0 = tid; e0 < n; e0 += 8 * NT) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int e = e0 + u * NT; v[u] = e < n ? fbase[e] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int e = e0 + u * NT; if (e < n) xyz[e] = v[u]; }
             }
         } else {
-            double *d = mo + 3 * (fl * M + (r - S)); d[0] = x; d[1] = y; d[2] = z;
+            for (int fl = 0; fl < nf; fl++) {
+                const double *src = fbase + (i64)fl * h.A * 3;
+                double *dst = xyz + 3 * fl * SM;
+                const int n = 3 * SM;
+                for (int e0 = tid; e0 < n; e0 += 8 * NT) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int e = e0 + u * NT;
+                        v[u] = 0.0;
+                        if (e < n) {
+                            if (h.contig == 1) v[u] = src[e < 3 * S ? 3 * h.s0 + e : 3 * h.m0 + (e - 3 * S)];
+                            else { const int a = e / 3; v[u] = src[3 * (a < S ? h.static_idx[a] : h.mobile_idx[a - S]) + (e - 3 * a)]; }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int e = e0 + u * NT; if (e < n) dst[e] = v[u]; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 1b: wrap in place (Step 0), static-lattice check (helpers.pyx:57-80) ----
+    for (int a = tid; a < nf * SM; a += NT) {
+        int fl = 0;
+        for (int q = 1; q < nf; q++) fl += a >= q * SM;
+        const int r = a - fl * SM;
+        double *d = xyz + 3 * a;
+        double x = d[0], y = d[1], z = d[2];
+        wrapc3<CELL>(P, x, y, z);
+        d[0] = x; d[1] = y; d[2] = z;
+        if (!DYN && r < S) {
+            const double *rp = h.ref_static + 3 * r;
+            const double rx = rp[0], ry = rp[1], rz_ = rp[2];
+            // plain displacement: it bounds the periodic one, and while it is shorter than 0.45 cell heights
+            // the shifted atom is inside the cell, where the reference's wrap changes it by rounding only -
+            // no error, no beyond-delta flag (safe2 is below both bounds)
+            const double ex = x - rx, ey = y - ry, ez = z - rz_;
+            const double e2 = (ex * ex + ey * ey) + ez * ez;
+            if (!(e2 <= h.safe2)) {
+                // PBCCalculator.distances(ref, atom) (util/PBCCalculator.pyx:64-103), squared; the sqrt is
+                // taken only inside the rounding band around static_movement_threshold^2
+                double qx = x + (P.cen[0] - rx), qy = y + (P.cen[1] - ry), qz = z + (P.cen[2] - rz_);
+                wrapc3<CELL>(P, qx, qy, qz);
+                const double dx = -qx + P.cen[0], dy = -qy + P.cen[1], dz = -qz + P.cen[2];
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                if (d2 > h.delta2) {
+                    atomicOr(&fmax[fl], 1ull);
+                    if (d2 > h.thr2_lo && (d2 > h.thr2_hi || sqrt(d2) > h.static_thr))
+                        atomicMin(h.err, (u64)(h.frame0 + f0 + fl) * errw + (u64)r);
+                }
+            }
         }
     }
     __syncthreads();
     if (tid < nf) {
-        bool tight = dyn ? (h.frame_dmax[f0 + tid] * h.frame_dmax[f0 + tid] <= h.delta2) : (fmax[tid] == 0ull);
+        bool tight = DYN ? (h.frame_dmax[f0 + tid] * h.frame_dmax[f0 + tid] <= h.delta2) : (fmax[tid] == 0ull);
         if (h.force_loose) tight = false;
         fmax[tid] = tight ? 1ull : 0ull;
         if (!tight) atomicAdd(&h.scal[2], 1ull);
@@ -294,224 +338,238 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
 
     // phase-2 constants: scalar loads from the device copy of the arguments, issued after the barrier
     const Fill3Args __attribute__((address_space(4))) &g = *full;
+    const i32 *verts = g.verts;
     const double *hi2p = g.hi2p;
     const double2 *vr = g.vr;
-    const unsigned char *nvtab = g.nvtab;
-    const i32 *lattice_map = g.lattice_map;
-    const char *t_rec = (const char *)g.t_rec, *l_rec = (const char *)g.l_rec;
-    const i32 *t_roff = g.t_roff, *l_roff = g.l_roff;
     const double mid = g.midpoint, steep = g.steepness, rz = g.rz;
-    const i64 N = g.N;
-    const int W = g.W;
-    const bool store = g.row_val != nullptr;
-    const int scap = h.scap;
-    const int IW = h.iw;
+    const int myreg = wave * rcap;                              // my region of survivors
+    // per-lane constants of the (task, vertex) passes
+    const int hh = lane & (VP - 1), gl0 = lane & ~(VP - 1);     // my vertex, first lane of my task
+    const unsigned long long grpmask = (VP == 8 ? 0xffull : 0xfull) << gl0, below = (1ull << gl0) - 1ull;
+    const unsigned long long leadmask = VP == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
 
-    // ---- phase 2: every wave on its own; no workgroup barrier from here on ----
+    // ---- phase 2: windows of 64 ions; wave 0 owns the ions (one lane each) and cuts the window into batches of at
+    //      most LCAP landmark tasks; the tasks of a batch are spread over all waves ----
     const int nions = nf * M;
-    for (int ic0 = wave * IW; ic0 < nions; ic0 += NW * IW) {
-        const int nic = (nions - ic0) < IW ? (nions - ic0) : IW;
-        // 2a: lanes < nic own one ion: bin -> record, offset (helpers.pyx:100)
-        int fl = 0, j = 0, nL = 0, nS = 0;
-        unsigned rbyte = 0;                                   // byte offset of my record
-        const char *recbase = t_rec;
-        bool tight_ion = true;
-        if (lane < nic) {
-            const int ion = ic0 + lane;
-            for (int q = 1; q < nf; q++) fl += ion >= q * M;
-            j = ion - fl * M;
-            double *mp = mo + 3 * ion;
-            const double px = mp[0], py = mp[1], pz = mp[2];
-            tight_ion = fmax[fl] != 0ull;
-            i32 ro;
-            if (tight_ion) ro = t_roff[bin_of3<CELL>(P, px, py, pz, g.tG0, g.tG1, g.tG2)];
-            else { ro = l_roff[bin_of3<CELL>(P, px, py, pz, g.lG0, g.lG1, g.lG2)]; recbase = l_rec; }
-            rbyte = (unsigned)ro * 4u;
-            const unsigned hdr = *(const unsigned *)(recbase + rbyte);
-            nL = (int)(hdr & 0xffffu); nS = (int)(hdr >> 16);
-            mp[0] = P.cen[0] - px; mp[1] = P.cen[1] - py; mp[2] = P.cen[2] - pz;
+    for (int ib0 = 0; ib0 < nions; ib0 += 64) {
+        const int nib = (nions - ib0) < 64 ? (nions - ib0) : 64;
+        int fl = 0, j = 0, nL = 0, exL = 0, inL = 0;
+        const i32 *mylist = nullptr;
+        const unsigned char *mycrit = nullptr;
+        if (wave == 0) {
+            // owner lanes: bin -> candidate list, offset vector (helpers.pyx:100)
+            if (lane < nib) {
+                const int ion = ib0 + lane;
+                for (int q = 1; q < nf; q++) fl += ion >= q * M;
+                j = ion - fl * M;
+                double *mp = xyz + 3 * (fl * SM + S + j);
+                const double px = mp[0], py = mp[1], pz = mp[2];
+                if (fmax[fl] != 0ull) {
+                    const int b = bin_of3<CELL>(P, px, py, pz, g.tG0, g.tG1, g.tG2);
+                    const i32 lo = g.t_off[b];
+                    nL = g.t_off[b + 1] - lo; mylist = g.t_list + lo; mycrit = g.t_crit + lo;
+                } else {
+                    const int b = bin_of3<CELL>(P, px, py, pz, g.lG0, g.lG1, g.lG2);
+                    const i32 lo = g.l_off[b];
+                    nL = g.l_off[b + 1] - lo; mylist = g.l_list + lo; mycrit = g.l_crit + lo;
+                }
+                mp[0] = P.cen[0] - px; mp[1] = P.cen[1] - py; mp[2] = P.cen[2] - pz;
+                nzc[lane] = 0u; nzpend[lane] = 0xffffffffu;
+                // byte offsets into xyz[]: my offset vector, the statics of my frame; my frame
+                info[lane] = make_uint4(24u * (unsigned)(fl * SM + S + j), 24u * (unsigned)(fl * SM), (unsigned)fl, 0u);
+            }
+            inL = wave_add_scan(nL);
+            exL = inL - nL;
         }
-        // 2b: wave scan of (static tasks << 16 | landmark tasks)
-        int incl = (nS << 16) | nL;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
-        const int excl = incl - ((nS << 16) | nL);
-        const int exS = excl >> 16, exL = excl & 0xffff, inS = incl >> 16, inL = incl & 0xffff;
-        if (lane < nic) {
-            // every table address of a task is (per-ion constant) + stride * (task number in the chunk)
-            int w = 1 + nL + (nS + 1) / 2; w += w & 1;
-            uint4 v;
-            v.x = rbyte + 4u + 4u * (unsigned)nL - 2u * (unsigned)exS;           // union entries (u16)
-            v.y = rbyte + 4u - 4u * (unsigned)exL;                               // landmark ids (i32)
-            v.z = rbyte + 4u * (unsigned)w - (unsigned)VP * (unsigned)exL;       // slot bytes
-            v.w = (unsigned)exS | ((unsigned)fl << 16) | (tight_ion ? 0u : 0x80000000u);
-            info[lane] = v;
-        }
-        int nnz = 0;
-        const i64 row = (f0 + fl) * M + j;
         int ion_s = 0;
-        while (ion_s < nic) {
-            // 2c: batch [ion_s, ion_e) of whole ions within the static-task and landmark-task capacities
-            const int preS = __shfl(exS, ion_s), preL = __shfl(exL, ion_s);
-            const unsigned long long fit = __ballot(lane >= ion_s && lane < nic && inS - preS <= scap && inL - preL <= F3_LCAP);
-            if (!fit) { if (lane == 0) atomicAdd(&h.scal[3], 1ull); break; }   // cannot happen (capacities are checked on the host)
-            const int ion_e = ion_s + __popcll(fit);
-            const int nst = __shfl(inS, ion_e - 1) - preS, nlt = __shfl(inL, ion_e - 1) - preL;
-            const bool mine = lane >= ion_s && lane < ion_e;
-            // 2d: markers: the first task of every ion carries (ion + 1)
-            for (int q = lane * 4; q < nst; q += 256) *(unsigned *)(smark + q) = 0u;
-            for (int q = lane * 4; q < nlt; q += 256) *(unsigned *)(lmark + q) = 0u;
+        while (true) {
+            if (wave == 0) {
+                // batch [ion_s, ion_e): whole ions, at most LCAP landmark tasks
+                const int preL = __shfl(exL, ion_s);
+                const unsigned long long fit = __ballot(lane >= ion_s && lane < nib && inL - preL <= LCAP);
+                const int take = __popcll(fit);
+                const int ion_e = ion_s + take;
+                const int nlt = take > 0 ? __shfl(inL, ion_e - 1) - preL : 0;
+                if (lane >= ion_s && lane < ion_e) {
+                    ifirst[lane] = 0xffffffffu; ilast[lane] = 0u;
+                    for (int c = 0; c < nL; c++)       // landmark | critical vertex << 22 | ion << 26
+                        ttab[exL - preL + c] = (unsigned)mylist[c] | ((unsigned)mycrit[c] << 22) | ((unsigned)lane << 26);
+                }
+                if (lane == 0) { bp[0] = ion_e; bp[1] = nlt; bp[2] = 0; }
+            }
+            __syncthreads();                                                                   // B1
+            const int ion_e = __builtin_amdgcn_readfirstlane(bp[0]), nlt = __builtin_amdgcn_readfirstlane(bp[1]);
+            if (ion_e <= ion_s) { if (tid == 0) atomicAdd(&h.scal[3], 1ull); break; }          // cannot happen (host checks)
+            if (h.debug_stop == 9 && tid == 0) { atomicAdd(&h.scal[5], (u64)nlt); atomicAdd(&h.scal[7], 1ull); }
+            // a contiguous range of tasks per wave (so the survivors of wave w precede those of wave w + 1)
+            const int tpw = (nlt + NW - 1) / NW;
+            const int t_lo = wave * tpw < nlt ? wave * tpw : nlt, t_hi = (t_lo + tpw) < nlt ? (t_lo + tpw) : nlt;
+            // ---- D0: one lane per task tests the task's CRITICAL vertex (the one with the least room in this ion's
+            //      bin, candidates.hip); the tasks that pass are compacted in place ----
+            int t_end = t_lo;
+            for (int t0 = t_lo; t0 < t_hi; t0 += 64) {
+                const int t = t0 + lane;
+                const bool act = t < t_hi;
+                const unsigned tk = ttab[act ? t : t_lo];
+                const unsigned k = tk & 0x3fffffu, cv = (tk >> 22) & 7u;
+                const uint4 iv = info[tk >> 26];
+                i32 v = verts[k * VP + cv];
+                const double hk = hi2p[k * VP + cv];
+                v = v < 0 ? 0 : v;
+                if (DYN) v = g.lattice_map[(f0 + (i64)iv.z) * S + v];
+                const double *sp = (const double *)((const char *)xyz + (iv.y + 24u * (unsigned)v));
+                const double *op = (const double *)((const char *)xyz + iv.x);
+                double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];
+                wrapc3<CELL>(P, qx, qy, qz);
+                const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                const bool keep = act && !(d2 > hk);
+                const unsigned long long km = __ballot(keep);
+                if (keep) ttab[t_end + __popcll(km & ((1ull << lane) - 1ull))] = tk;
+                t_end += __popcll(km);
+            }
+            if (h.debug_stop == 9 && lane == 0) atomicAdd(&h.scal[4], (u64)(t_end - t_lo));
             __builtin_amdgcn_wave_barrier();
-            if (mine && nS > 0) smark[exS - preS] = (unsigned char)(lane + 1);
-            if (mine && nL > 0) lmark[exL - preL] = (unsigned char)(lane + 1);
-            __builtin_amdgcn_wave_barrier();
-            // 2e: one squared distance per (ion, union entry) (helpers.pyx:174-178 before the sqrt)
-            {
-                int carry = 0;
-                for (int t0 = 0; t0 < nst; t0 += 64) {
-                    const int t = t0 + lane;
-                    const bool act = t < nst;
-                    int m = act ? (int)smark[t] : 0;
-                    m = wave_max_scan(m);
-                    m = m > carry ? m : carry;
-                    carry = __builtin_amdgcn_readlane(m, 63);
-                    if (act) {
-                        const uint4 iv = info[m > 0 ? m - 1 : 0];
-                        const char *rb = (iv.w & 0x80000000u) ? l_rec : t_rec;
-                        i32 v = *(const unsigned short *)(rb + (iv.x + 2u * (unsigned)(t + preS)));
-                        const int tfl = (int)((iv.w >> 16) & 0x7fffu);
-                        if (dyn) v = lattice_map[(f0 + tfl) * S + v];
-                        const double *sp = sxyz + 3 * (tfl * S + v);
-                        const double *op = mo + 3 * (ic0 + m - 1);
+            const int pend = (t_end - t_lo + TPP - 1) / TPP;    // passes of TPP tasks over [t_lo, t_end)
+            int cursor = 0;
+            int par = 0;
+            while (true) {
+                // ---- D1: one squared distance per (task, vertex) lane (helpers.pyx:174-178 before the sqrt),
+                //      compared with (rz * vcd)^2; tasks with every vertex inside go to my region of survivors.
+                //      Two passes per iteration (loads and arithmetic of both first) while the region has room for
+                //      every task of both ----
+                int cnt = 0;
+                while (cursor < pend && cnt + TPP <= rcap) {
+                    const bool two = cursor + 1 < pend && cnt + 2 * TPP <= rcap;
+                    double d2[2];
+                    unsigned tk[2];
+                    unsigned long long bad[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        if (u == 1 && !two) { bad[1] = ~0ull; tk[1] = 0u; d2[1] = 0.0; break; }
+                        const int t = t_lo + TPP * (cursor + u) + (lane >> LG);
+                        tk[u] = ttab[t < LCAP ? t : 0];
+                        const unsigned k = tk[u] & 0x3fffffu;
+                        const uint4 iv = info[tk[u] >> 26];
+                        i32 v = verts[k * VP + hh];
+                        const double hk = hi2p[k * VP + hh];
+                        v = v < 0 ? 0 : v;
+                        if (DYN) v = g.lattice_map[(f0 + (i64)iv.z) * S + v];
+                        const double *sp = (const double *)((const char *)xyz + (iv.y + 24u * (unsigned)v));
+                        const double *op = (const double *)((const char *)xyz + iv.x);
                         double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];
                         wrapc3<CELL>(P, qx, qy, qz);
                         const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
-                        d2buf[t] = (dx * dx + dy * dy) + dz * dz;
+                        d2[u] = (dx * dx + dy * dy) + dz * dz;
+                        bad[u] = __ballot(!(t < t_end) || d2[u] > hk);
                     }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (h.debug_stop == 3) { ion_s = ion_e; nnz = 1; continue; }
-            // 2f: landmark tasks: gather the vertices' squared distances, screen against (rz * vcd)^2; survivors
-            // are pooled (landmark, task, table positions of the vertices) and evaluated 64 at a time
-            int npool = 0;
-            {
-                int carry = 0;
-                for (int t0 = 0; t0 < nlt; t0 += 64) {
-                    {
-                        const int t = t0 + lane;
-                        const bool act = t < nlt;
-                        int m = act ? (int)lmark[t] : 0;
-                        m = wave_max_scan(m);
-                        m = m > carry ? m : carry;
-                        carry = __builtin_amdgcn_readlane(m, 63);
-                        bool alive = false;
-                        int k = 0;
-                        unsigned short pos[VP];
-                        if (act) {
-                            const uint4 iv = info[m > 0 ? m - 1 : 0];
-                            const char *rb = (iv.w & 0x80000000u) ? l_rec : t_rec;
-                            k = *(const i32 *)(rb + (iv.y + 4u * (unsigned)(t + preL)));
-                            const unsigned char *sl = (const unsigned char *)(rb + (iv.z + (unsigned)VP * (unsigned)(t + preL)));
-                            unsigned s0 = *(const unsigned *)sl, s1 = 0;
-                            if (VP == 8) s1 = *(const unsigned *)(sl + 4);
-                            const int base = (int)(iv.w & 0xffffu) - preS;
-                            const double *hk = hi2p + (i64)k * VP;
-                            bool beyond = false;
 #pragma unroll
-                            for (int hh = 0; hh < VP; hh++) {
-                                const unsigned sb = ((hh < 4 ? s0 : s1) >> (8 * (hh & 3))) & 0xffu;
-                                pos[hh] = (unsigned short)(base + (int)sb);
-                                beyond |= d2buf[pos[hh]] > hk[hh];
-                            }
-                            alive = !beyond;
-                            tk[t] = k;
-                            if (!alive) tval[t] = 0.0;
-                        }
-                        const unsigned long long am = __ballot(alive);
-                        if (alive) {
-                            const int q = npool + __popcll(am & ((1ull << lane) - 1ull));
-                            pool_k[q] = k | ((int)nvtab[k] << 24);
-                            pool_t[q] = (unsigned short)t;
-#pragma unroll
-                            for (int hh = 0; hh < VP; hh++) pool_a[q * VP + hh] = pos[hh];
-                        }
-                        npool += __popcll(am);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    // evaluate when the pool could overflow with the next round, or at the end
-                    const bool last = t0 + 64 >= nlt;
-                    if (npool > 0 && (last || npool > F3_POOL - 64)) {
-                        if (h.debug_stop == 4) { for (int q = lane; q < npool; q += 64) tval[pool_t[q]] = 0.0; npool = 0; }
-                        for (int g0 = 0; g0 < npool; g0 += 64) {
-                            const int gs = (npool - g0) < 64 ? (npool - g0) : 64;
-                            double acc = 1.0;
-                            int mynv = 1;
-#pragma unroll
-                            for (int half = 0; half < VP / 4; half++) {
-                                // (survivor, vertex) items of this half: one logistic factor each (helpers.pyx:196-205)
-                                for (int i0 = 0; i0 < gs * 4; i0 += 64) {
-                                    const int i = i0 + lane;
-                                    if (i < gs * 4) {
-                                        const int q = g0 + (i >> 2), hh = (i & 3) + 4 * half;
-                                        const int kk = pool_k[q];
-                                        const int k = kk & 0xffffff, nv = (int)((unsigned)kk >> 24);
-                                        double f = 1.0;
-                                        if (hh < nv) {
-                                            const double2 c = vr[(i64)k * VP + hh];
-                                            f = vertex_factor(d2buf[pool_a[q * VP + hh]], c.x, c.y, rz, steep, mid, etab);
-                                        }
-                                        fbuf[i] = f;
-                                    }
-                                }
-                                __builtin_amdgcn_wave_barrier();
-                                // ci *= temp in vertex order (helpers.pyx:208), one lane per survivor
-                                if (lane < gs) {
-                                    const double2 *fp = (const double2 *)(fbuf + 4 * lane);
-                                    const double2 a = fp[0], b = fp[1];
-                                    if (half == 0) acc = a.x; else acc *= a.x;
-                                    acc *= a.y; acc *= b.x; acc *= b.y;
-                                }
-                                __builtin_amdgcn_wave_barrier();
-                            }
-                            if (lane < gs) {
-                                mynv = (int)((unsigned)pool_k[g0 + lane] >> 24);
-                                tval[pool_t[g0 + lane]] = acc != 0.0 ? root_chain(acc, mynv) : 0.0;   // helpers.pyx:212
+                    for (int u = 0; u < 2; u++) {
+                        if (u == 1 && !two) break;
+                        const bool aliveg = (bad[u] & grpmask) == 0ull;
+                        const unsigned long long leaders = __ballot(aliveg) & leadmask;
+                        if (aliveg) {
+                            const int q = myreg + cnt + __popcll(leaders & below);
+                            sd2[q * VP + hh] = d2[u];
+                            if (hh == 0) {
+                                const unsigned ion = tk[u] >> 26;
+                                sv_k[q] = tk[u];
+                                atomicMin(&ifirst[64 * par + ion], (unsigned)(64 * wave + q - myreg));
+                                atomicMax(&ilast[64 * par + ion], (unsigned)(64 * wave + q - myreg));
                             }
                         }
-                        npool = 0;
-                        __builtin_amdgcn_wave_barrier();
+                        cnt += __popcll(leaders);
+                    }
+                    cursor += two ? 2 : 1;
+                }
+                if (lane == 0 && cursor < pend) atomicOr(&bp[2], 1);
+                if (h.debug_stop == 9 && lane == 0) atomicAdd(&h.scal[6], (u64)cnt);
+                if (h.debug_stop == 4) cnt = 0;
+                __builtin_amdgcn_wave_barrier();
+                // ---- E: one logistic factor per (survivor, vertex) (helpers.pyx:196-205), in place; two items per
+                //      lane and iteration, loads first.  Padded vertices (1 / vcd stored as 0) give the factor 1 ----
+                const int items = cnt * VP;
+                for (int i0 = 0; i0 < items; i0 += 128) {
+                    double d2[2];
+                    double2 c[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int i = i0 + 64 * u + lane;
+                        const int ii = i < items ? i : 0;
+                        const unsigned kk = sv_k[myreg + (ii >> LG)];
+                        d2[u] = sd2[myreg * VP + ii];
+                        c[u] = vr[(i64)(kk & 0x3fffffu) * VP + (ii & (VP - 1))];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int i = i0 + 64 * u + lane;
+                        const double f = vertex_factor(d2[u], c[u].x, c[u].y, rz, steep, mid, etab);
+                        if (i < items) sd2[myreg * VP + i] = c[u].y != 0.0 ? f : 1.0;
                     }
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // 2g: my row, ascending landmark order
-            if (mine) {
-                const int at = exL - preL;
-                for (int c = 0; c < nL; c++) {
-                    const double val = tval[at + c];
-                    if (val != 0.0) {
-                        if (store) {
-                            if (nnz < W) { g.row_idx[(i64)nnz * N + row] = tk[at + c]; g.row_val[(i64)nnz * N + row] = val; }
-                            else atomicAdd(&h.scal[3], 1ull);
-                        }
-                        nnz++;
-                    }
+                __builtin_amdgcn_wave_barrier();
+                // ---- T1: ci *= temp in vertex order (helpers.pyx:208) and the n-th root (:212), one lane per survivor ----
+                double val = 0.0;
+                unsigned kk = 0;
+                const bool tact = lane < cnt;
+                if (tact) {
+                    kk = sv_k[myreg + lane];
+                    const int nv = (int)g.nvtab[kk & 0x3fffffu];
+                    const double2 *fp = (const double2 *)(sd2 + (myreg + lane) * VP);
+                    double2 a = fp[0], b = fp[1];
+                    double acc = a.x;
+                    acc *= a.y; acc *= b.x; acc *= b.y;
+                    if (VP == 8) { a = fp[2]; b = fp[3]; acc *= a.x; acc *= a.y; acc *= b.x; acc *= b.y; }
+                    if (acc != 0.0) val = root_chain(acc, nv);
                 }
+                const bool nz = tact && val != 0.0;
+                { const unsigned long long nzm = __ballot(nz); if (lane == 0) nzmask[wave] = nzm; }
+                if (tid < 64) {
+                    ifirst[64 * (par ^ 1) + tid] = 0xffffffffu; ilast[64 * (par ^ 1) + tid] = 0u;
+                    const unsigned pc = nzpend[tid];                    // counts published by the previous round
+                    if (pc != 0xffffffffu) { nzc[tid] = pc; nzpend[tid] = 0xffffffffu; }
+                }
+                __syncthreads();                                                               // B2
+                // ---- T2: the row entry of a component is the number of earlier non-zero components of its ion ----
+                const int more = __builtin_amdgcn_readfirstlane(bp[2]);
+                if (tact) {
+                    const unsigned ion = kk >> 26;
+                    const int me = 64 * wave + lane, first = (int)ifirst[64 * par + ion];
+                    int rank = 0;
+                    for (int wd = first >> 6; wd <= wave; wd++) {
+                        const int lo = first > 64 * wd ? first - 64 * wd : 0, hi = me - 64 * wd < 64 ? me - 64 * wd : 64;
+                        unsigned long long mk = nzmask[wd] >> lo;
+                        if (hi - lo < 64) mk &= (1ull << (hi - lo)) - 1ull;
+                        rank += __popcll(mk);
+                    }
+                    const int e = (int)nzc[ion] + rank;
+                    if (nz && g.row_val != nullptr) {
+                        const i64 row = f0 * M + ib0 + (i64)ion;                  // rows are frame-major
+                        if (e < g.W) { g.row_idx[(i64)e * g.N + row] = (i32)(kk & 0x3fffffu); g.row_val[(i64)e * g.N + row] = val; }
+                        else atomicAdd(&h.scal[3], 1ull);
+                    }
+                    // the ion's last survivor leaves the new count; it is folded into nzc[] behind the next barriers
+                    if (me == (int)ilast[64 * par + ion]) nzpend[ion] = (unsigned)(e + (nz ? 1 : 0));
+                }
+                __syncthreads();                                                               // B3: regions and masks free
+                if (!more) break;
+                if (tid == 0) bp[2] = 0;
+                par ^= 1;
+                __syncthreads();
             }
-            __builtin_amdgcn_wave_barrier();
             ion_s = ion_e;
+            if (ion_s >= nib) break;
         }
-        if (lane < nic) {
-            g.row_nnz[row] = nnz < W ? nnz : W;
+        if (wave == 0 && lane < nib) {
+            const unsigned pc = nzpend[lane];
+            const int nnz = h.debug_stop == 4 ? 1 : (int)(pc != 0xffffffffu ? pc : nzc[lane]);
+            const i64 row = (f0 + fl) * M + j;
+            g.row_nnz[row] = nnz < g.W ? nnz : g.W;
             if (nnz == 0) {                                               // helpers.pyx:116-120
                 if (g.check_zeros) atomicMin(h.err, (u64)(h.frame0 + f0 + fl) * errw + (u64)(S + 1 + j));
                 else atomicAdd(&h.scal[0], 1ull);
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -540,7 +598,7 @@ static int fill3_basis_tables(sit_ctx *c)
             const size_t e = (size_t)(k * c->Vp + hh);
             const bool valid = v[e] >= 0 && (i64)cnt == hh;    // vertices are a prefix (the reference breaks at -1)
             if (valid) cnt++; else hi2[e] = INFINITY;
-            vr[2 * e] = vcd[e]; vr[2 * e + 1] = 1.0 / vcd[e];
+            vr[2 * e] = vcd[e]; vr[2 * e + 1] = valid ? 1.0 / vcd[e] : 0.0;      // 0 marks a padded vertex
         }
         nv[(size_t)k] = (unsigned char)cnt;
     }
@@ -565,15 +623,13 @@ static int fill3_basis_tables(sit_ctx *c)
     return SIT_OK;
 }
 
-// Can this context's next fill run on the third-generation kernel?  (Vertices per landmark <= 8, records built for
-// both tables, every bin's union and candidate list within the wave capacities, row width as in fill2.)
+// Can this context's next fill run on the third-generation kernel?  (Landmarks of at most 8 vertices; the widest
+// candidate list must fit a batch.)
 bool fill3_eligible(sit_ctx *c)
 {
     if (c->fill_kernel != 3) return false;
     if (c->Vp != 4 && c->Vp != 8) return false;
-    if (c->D >= (1LL << 24) || c->S >= 65536 || c->M > 30000) return false;
-    if (!c->lrec_ok || c->W > F3_LCAP || c->lrec_maxS > 255) return false;
-    if (c->tight_delta >= 0 && (!c->trec_ok || c->W_tight > F3_LCAP)) return false;
+    if (c->D >= (1LL << 22) || c->M > 30000 || c->W > 255) return false;
     return true;
 }
 
@@ -586,9 +642,10 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
     const bool have_tight = c->tight_delta >= 0;
     Fill3Args a;
     memset(&a, 0, sizeof(a));
-    a.hi2p = c->d_hi2p; a.vr = (const double2 *)c->d_vr; a.nvtab = c->d_nv;
-    a.t_roff = have_tight ? c->d_troff : c->d_lroff; a.t_rec = have_tight ? c->d_trec : c->d_lrec;
-    a.l_roff = c->d_lroff; a.l_rec = c->d_lrec;
+    a.verts = c->d_verts; a.hi2p = c->d_hi2p; a.vr = (const double2 *)c->d_vr; a.nvtab = c->d_nv;
+    a.l_off = c->d_bin_off; a.l_list = c->d_bin_list; a.l_crit = c->d_bin_crit;
+    a.t_off = have_tight ? c->d_tbin_off : c->d_bin_off; a.t_list = have_tight ? c->d_tbin_list : c->d_bin_list;
+    a.t_crit = have_tight ? c->d_tbin_crit : c->d_bin_crit;
     a.lattice_map = p->dynamic_lattice_mapping ? c->d_lattice_map : nullptr;
     a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx; a.row_val = store ? c->d_row_val : nullptr;
     a.N = c->N; a.D = (int)c->D; a.W = (int)c->rows_W;
@@ -605,9 +662,11 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
     h.frame_dmax = p->dynamic_lattice_mapping ? c->d_frame_dmax : nullptr;
     h.exptab = (const double2 *)c->d_exptab;
     h.err = c->d_err; h.scal = c->d_scal; h.F = c->F; h.A = c->A; h.frame0 = c->frame0;
-    h.S = (int)S; h.M = (int)M; h.dyn = a.lattice_map != nullptr;
+    h.S = (int)S; h.M = (int)M;
+    const bool dynmap = a.lattice_map != nullptr;
     h.debug_stop = f3_env_int("SITATOR_DEBUG_STOP", 0);
     h.force_loose = have_tight ? 0 : 1;
+    h.s0 = (int)c->idx_s0; h.m0 = (int)c->idx_m0;
     h.delta2 = have_tight ? c->tight_delta * c->tight_delta : -1.0;
     h.thr2_lo = c->static_thr * c->static_thr * (1.0 - 1e-14);
     h.thr2_hi = c->static_thr * c->static_thr * (1.0 + 1e-14);
@@ -618,34 +677,36 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
         if (c->static_thr * (1.0 - 1e-9) < safe) safe = c->static_thr * (1.0 - 1e-9);
         h.safe2 = safe > 0 ? safe * safe * (1.0 - 1e-12) : -1.0;
     }
-    // launch shape: NW waves share the frames of a workgroup; every wave takes chunks of IW ions
-    const int maxS = std::max(c->lrec_maxS, have_tight ? c->trec_maxS : 0);
+    // launch shape: NW waves share the frames of a workgroup and work through its ions 64 at a time
     int nw = f3_env_int("SITATOR_FILL_WAVES", 0);
-    int iw = f3_env_int("SITATOR_FILL_IW", 0);
     int fpb = f3_env_int("SITATOR_FILL_FPB", 0);
-    int scap = f3_env_int("SITATOR_FILL_SCAP", 0);
+    int rcap = f3_env_int("SITATOR_FILL_RCAP", 0);
     const int vp = (int)c->Vp;
-    auto lds_bytes = [&](int nwv, int fpbv, int scapv) {
-        return (size_t)nwv * f3_wave_bytes(scapv, vp) + F3_EXPN * 16 + (size_t)fpbv * (size_t)(S + M) * 24 + (size_t)fpbv * 8 + 32;
+    const size_t frame_bytes = (size_t)(S + M) * 24;
+    auto lds_bytes = [&](int nwv, int fpbv, int rcapv) {
+        return (size_t)f3_pool_bytes(rcapv, vp, nwv) + F3_EXPN * 16 + (size_t)fpbv * frame_bytes + (size_t)fpbv * 8 + 32;
     };
-    if (nw != 4 && nw != 8) nw = (size_t)(S + M) * 24 > 40 * 1024 && M >= 6 * F3_IWMAX ? 8 : 4;
-    if (iw < 1 || iw > F3_IWMAX) iw = F3_IWMAX;
-    if (fpb < 1) {
-        i64 f = ((i64)nw * iw) / M; if (f < 1) f = 1; if (f > 32) f = 32;
-        fpb = (int)f;
-    }
+    if (fpb < 1) { i64 f = 64 / M; if (f < 1) f = 1; if (f > 32) f = 32; fpb = (int)f; }      // at least one window of 64 ions
     if (fpb > 32) fpb = 32;
-    if (scap < 64) {
-        // room for a whole chunk at the mean union size, at least the largest single union
-        scap = 384;
+    const bool rcap_auto = rcap < 8;
+    if (rcap_auto) rcap = 48;
+    rcap = (rcap + 7) / 8 * 8;
+    if (rcap > 64) rcap = 64;
+    if (nw != 4 && nw != 8 && nw != 16) {
+        // small frames: 4 waves and several workgroups per CU; a frame that leaves room for one workgroup only: 16
+        const size_t b4 = lds_bytes(4, fpb, rcap);
+        nw = b4 <= 53 * 1024 ? 4 : (b4 <= 72 * 1024 ? 8 : 16);
     }
-    scap = (scap + 63) / 64 * 64;
-    if (scap < (maxS + 63) / 64 * 64) scap = (maxS + 63) / 64 * 64;
-    while (fpb > 1 && lds_bytes(nw, fpb, scap) > 160 * 1024 - 512) fpb--;
-    const size_t lds = lds_bytes(nw, fpb, scap);
+    if (rcap_auto) {
+        // fewer survivor slots per wave when that admits one more workgroup per CU (a full region only costs a round)
+        auto wg_per_cu = [&](int r) { const size_t b = lds_bytes(nw, fpb, r); size_t k = (160 * 1024) / b; return k > 8 ? (size_t)8 : k; };
+        for (int r : {40, 32}) if (wg_per_cu(r) > wg_per_cu(rcap)) rcap = r;
+    }
+    while (fpb > 1 && lds_bytes(nw, fpb, rcap) > 160 * 1024 - 512) fpb--;
+    const size_t lds = lds_bytes(nw, fpb, rcap);
     SIT_REQUIRE(c, lds <= 160 * 1024 - 256, "sit_fill: one frame's atoms do not fit in LDS");
-    h.fpb = fpb; h.iw = iw; h.scap = scap;
-    c->last_fpb = fpb; c->last_kernel = 3; c->last_iw = iw; c->last_nw = nw;
+    h.fpb = fpb; h.rcap = rcap;
+    c->last_fpb = fpb; c->last_kernel = 3; c->last_iw = rcap; c->last_nw = nw;
     const unsigned grid = (unsigned)((c->F + fpb - 1) / fpb);
     if (!c->d_fill_args) {
         if ((rc = dev_alloc(c, &c->d_fill_args, (i64)std::max(sizeof(Fill3Args), (size_t)1024)))) return rc;
@@ -657,18 +718,25 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
     }
     const Fill3ArgsPtr full = (Fill3ArgsPtr)c->d_fill_args;
     const bool diag = c->cell_diagonal;
-#define F3_LAUNCH(CELL, LGV, NWV)                                                                                              \
+    int contig = c->idx_contig ? 1 : 0;
+    if (contig && c->idx_s0 == 0 && c->idx_m0 == S && c->A == S + M) contig = 2;
+    { const int forced = f3_env_int("SITATOR_FILL_CONTIG", -1); if (forced >= 0 && forced < contig) contig = forced; }
+    h.contig = contig;
+#define F3_LAUNCH(CELL, LGV, NWV, DY)                                                                                          \
     do {                                                                                                                   \
-        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill3<CELL, LGV, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        k_fill3<CELL, LGV, NWV><<<dim3(grid), dim3(NWV * 64), lds, c->stream>>>(h, full);                                  \
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill3<CELL, LGV, NWV, DY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        k_fill3<CELL, LGV, NWV, DY><<<dim3(grid), dim3(NWV * 64), lds, c->stream>>>(h, full);                              \
     } while (0)
-    if (diag) {
-        if (vp == 8) { if (nw == 8) F3_LAUNCH(1, 3, 8); else F3_LAUNCH(1, 3, 4); }
-        else { if (nw == 8) F3_LAUNCH(1, 2, 8); else F3_LAUNCH(1, 2, 4); }
-    } else {
-        if (vp == 8) { if (nw == 8) F3_LAUNCH(0, 3, 8); else F3_LAUNCH(0, 3, 4); }
-        else { if (nw == 8) F3_LAUNCH(0, 2, 8); else F3_LAUNCH(0, 2, 4); }
-    }
+#define F3_PICK2(CELL, LGV, NWV)                                                                                               \
+    do { if (dynmap) F3_LAUNCH(CELL, LGV, NWV, 1); else F3_LAUNCH(CELL, LGV, NWV, 0); } while (0)
+#define F3_PICK(CELL, LGV)                                                                                                     \
+    do {                                                                                                                   \
+        if (nw == 16) F3_PICK2(CELL, LGV, 16); else if (nw == 8) F3_PICK2(CELL, LGV, 8); else F3_PICK2(CELL, LGV, 4);      \
+    } while (0)
+    if (diag) { if (vp == 8) F3_PICK(1, 3); else F3_PICK(1, 2); }
+    else { if (vp == 8) F3_PICK(0, 3); else F3_PICK(0, 2); }
+#undef F3_PICK
+#undef F3_PICK2
 #undef F3_LAUNCH
     HIP_TRY(c, hipGetLastError());
     return SIT_OK;

@@ -47,6 +47,7 @@ struct sit_ctx {
     int G[3] = {1, 1, 1};
     i32 *d_bin_off = nullptr;         // [nbins+1]
     i32 *d_bin_list = nullptr;
+    unsigned char *d_bin_crit = nullptr, *d_tbin_crit = nullptr;   // critical vertex of every list entry (candidates.hip)
     i64 W = 0;                        // row width = longest candidate list (loose table)
     double mean_candidates = 0;
     // tight table: built for the static displacement actually present (fill2.hip)
@@ -62,18 +63,16 @@ struct sit_ctx {
     i64 fallback_frames = 0;
     int last_fpb = 0;
     double *d_frame_dmax = nullptr;   // [F] per-frame displacement maximum (dynamic mapping)
-    // third-generation fill (fill3.hip): per-bin records (candidates.hip), inf-padded bounds, {vcd, 1/vcd} pairs
+    // third-generation fill (fill3.hip): inf-padded bounds, {vcd, 1/vcd} pairs, vertex counts, exp table
     double *d_hi2p = nullptr;         // [D,Vp] as d_hi2 but +inf on padded vertices
     double *d_vr = nullptr;           // [D,Vp,2] {vcd, correctly rounded 1/vcd}
     unsigned char *d_nv = nullptr;    // [D] vertices per landmark
     double *d_exptab = nullptr;       // [128,2] {hi, lo} of 2^(j/128)
-    i32 *d_lroff = nullptr, *d_lrec = nullptr;   // records of the loose table
-    i32 *d_troff = nullptr, *d_trec = nullptr;   // records of the tight table
-    i64 lrec_words = 0, trec_words = 0;
-    int lrec_maxS = 0, trec_maxS = 0;
-    bool lrec_ok = false, trec_ok = false;
+    bool idx_contig = false;          // static_idx / mobile_idx are consecutive atom ranges
+    i64 idx_s0 = 0, idx_m0 = 0;
     double hmin = 0;                  // smallest perpendicular height of the cell
     int last_kernel = 0, last_iw = 0, last_nw = 0;
+    double census[4] = {0, 0, 0, 0};  // SITATOR_DEBUG_STOP=9: static tasks, landmark tasks, survivors, wave batches
 
     // trajectory (sit_set_frames)
     i64 F = 0, A = 0, M = 0, frame0 = 0;
@@ -255,11 +254,9 @@ int fitfast_to_dense(sit_ctx *c, std::vector<double> &cen, std::vector<i64> &cnt
 int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val, const i64 *weights, i64 stride,
                    int width, i64 nrows, double threshold, i64 *consumed);
 // pruning table for static displacements up to `displacement`, built and kept on the device (candidates.hip)
-int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32 **d_off, i32 **d_list, int G_out[3],
-                         i64 *W, double *mean);
+int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32 **d_off, i32 **d_list,
+                         unsigned char **d_crit, int G_out[3], i64 *W, double *mean);
 int fill2_sample_dmax(sit_ctx *c, std::vector<double> &out);
 int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, double threshold);
-int sit_build_records(sit_ctx *c, const i32 *d_off, const i32 *d_list, i64 nb, i32 **d_roff, i32 **d_rec, i64 *words,
-                      int *maxS, bool *ok);
 bool fill3_eligible(sit_ctx *c);
 int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store);

@@ -69,22 +69,24 @@ def test_third_generation_rows_match_oracle(oracle, cfg, M, F, dyn):
     np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
 
 
-@pytest.mark.parametrize("iw,fpb,scap", [("16", "1", "320"), ("32", "2", "640"), ("7", "3", "64"), ("32", "4", "128")])
-def test_third_generation_launch_shapes_agree(iw, fpb, scap):
-    """Ions per wave chunk, frames per workgroup and the static-task capacity only change how the work is cut into
-    wave batches: rows are identical bit for bit."""
+@pytest.mark.parametrize("waves,fpb,rcap,contig", [("4", "1", "48", "2"), ("8", "2", "8", "1"), ("16", "3", "64", "0"),
+                                                   ("4", "4", "16", "2")])
+def test_third_generation_launch_shapes_agree(waves, fpb, rcap, contig):
+    """Waves and frames per workgroup, the survivor slots per wave (a full region forces extra rounds) and the way the
+    frames are copied into LDS only change how the work is cut up: rows are identical bit for bit."""
     from sitator_amd import synth
     host = synth.config_host("C2")
     ctx, *_ = _setup(host, 64, 90, seed=23, kernel="3")
     assert ctx.fill()[0] == 0
     base = ctx.rows_dense()
-    os.environ["SITATOR_FILL_IW"], os.environ["SITATOR_FILL_FPB"], os.environ["SITATOR_FILL_SCAP"] = iw, fpb, scap
+    env = {"SITATOR_FILL_WAVES": waves, "SITATOR_FILL_FPB": fpb, "SITATOR_FILL_RCAP": rcap, "SITATOR_FILL_CONTIG": contig}
+    os.environ.update(env)
     try:
         assert ctx.fill()[0] == 0
-        assert ctx.info()["ions_per_wave"] == int(iw)
+        assert ctx.info()["waves_per_workgroup"] == int(waves)
         got = ctx.rows_dense()
     finally:
-        for k in ("SITATOR_FILL_IW", "SITATOR_FILL_FPB", "SITATOR_FILL_SCAP"):
+        for k in env:
             os.environ.pop(k, None)
     assert np.array_equal(base, got)
 
