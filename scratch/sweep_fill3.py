@@ -39,7 +39,7 @@ a = ctx2.rows_dense(0, min(ctx2.N, 64 * 200)); b = ctx3.rows_dense(0, min(ctx3.N
 print("pattern equal", bool(np.array_equal(a != 0, b != 0)), "max rel diff", float(np.max(np.abs(a - b) / np.maximum(np.abs(a), 1e-300))), flush=True)
 t = run(ctx3, reps=1, SITATOR_DEBUG_STOP=9)
 cs = t[2]["census"]; ni = F * M
-print("  census: landmark tasks/ion %.2f survivors/ion %.2f ions/batch %.2f" % (cs[1] / ni, cs[2] / ni, ni / max(cs[3], 1)), flush=True)
+print("  census: landmark tasks/ion %.2f past the critical vertex %.2f survivors/ion %.2f ions/batch %.2f" % (cs[1] / ni, cs[0] / ni, cs[2] / ni, ni / max(cs[3], 1)), flush=True)
 for stop in (1, 4):
     t = run(ctx3, SITATOR_DEBUG_STOP=stop)
     print("  gen3 debug_stop=%d: %.4f ms" % (stop, t[0]), flush=True)

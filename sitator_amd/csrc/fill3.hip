@@ -433,6 +433,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
             const int pend = (t_end - t_lo + TPP - 1) / TPP;    // passes of TPP tasks over [t_lo, t_end)
             int cursor = 0;
             int par = 0;
+            bool hadmore = false;
+            int rounds = 0;
             while (true) {
                 // ---- D1: one squared distance per (task, vertex) lane (helpers.pyx:174-178 before the sqrt),
                 //      compared with (rz * vcd)^2; tasks with every vertex inside go to my region of survivors.
@@ -553,9 +555,32 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 }
                 __syncthreads();                                                               // B3: regions and masks free
                 if (!more) break;
+                if (++rounds > LCAP) { if (tid == 0) atomicAdd(&h.scal[3], 1ull); break; }    // cannot happen: a round takes at least one pass
+                hadmore = true;
                 if (tid == 0) bp[2] = 0;
                 par ^= 1;
                 __syncthreads();
+            }
+            // A wave whose region filled up continued in a later round, possibly after the next wave had written
+            // later components of the same ion: the entries of this batch's rows are then complete but not in
+            // ascending landmark order.  Rows are short; their owners sort them.
+            if (hadmore && wave == 0 && lane >= ion_s && lane < ion_e && g.row_val != nullptr) {
+                const unsigned pc = nzpend[lane];
+                int n = (int)(pc != 0xffffffffu ? pc : nzc[lane]);
+                n = n < g.W ? n : g.W;
+                const i64 row = f0 * M + ib0 + lane;
+                for (int i = 1; i < n; i++) {
+                    const i32 ki = g.row_idx[(i64)i * g.N + row];
+                    const double vi = g.row_val[(i64)i * g.N + row];
+                    int q = i - 1;
+                    while (q >= 0 && g.row_idx[(i64)q * g.N + row] > ki) {
+                        g.row_idx[(i64)(q + 1) * g.N + row] = g.row_idx[(i64)q * g.N + row];
+                        g.row_val[(i64)(q + 1) * g.N + row] = g.row_val[(i64)q * g.N + row];
+                        q--;
+                    }
+                    g.row_idx[(i64)(q + 1) * g.N + row] = ki;
+                    g.row_val[(i64)(q + 1) * g.N + row] = vi;
+                }
             }
             ion_s = ion_e;
             if (ion_s >= nib) break;
@@ -692,6 +717,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
     if (rcap_auto) rcap = 48;
     rcap = (rcap + 7) / 8 * 8;
     if (rcap > 64) rcap = 64;
+    if (rcap < 64 / vp) rcap = 64 / vp;                        // a pass of 64 / vp tasks must fit an empty region
     if (nw != 4 && nw != 8 && nw != 16) {
         // small frames: 4 waves and several workgroups per CU; a frame that leaves room for one workgroup only: 16
         const size_t b4 = lds_bytes(4, fpb, rcap);

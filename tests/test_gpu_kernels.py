@@ -69,6 +69,33 @@ def test_third_generation_rows_match_oracle(oracle, cfg, M, F, dyn):
     np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("cfg,M,F,rcap", [("C1b", 5, 300, "8"), ("C1b", 4, 200, "0"), ("C5", 160, 20, "16"), ("C2", 64, 50, "8")])
+def test_third_generation_sparse_rows_are_ascending(oracle, cfg, M, F, rcap):
+    """The fit and predict kernels merge sparse rows by ascending landmark id.  With few survivor slots per wave a
+    batch needs several rounds and the waves finish in different rounds: entries must still come out ascending,
+    each exactly once, with the oracle's values."""
+    from sitator_amd import synth
+    host = synth.config_host(cfg)
+    ctx, frames, sm, mm, ref = _setup(host, M, F, seed=41, kernel="3")
+    if rcap != "0":
+        os.environ["SITATOR_FILL_RCAP"] = rcap
+    try:
+        assert ctx.fill(check_for_zeros=False)[0] == 0
+    finally:
+        os.environ.pop("SITATOR_FILL_RCAP", None)
+    nnz, idx, val = ctx.rows_sparse()
+    W = idx.shape[0]
+    for e in range(1, W):
+        m = nnz > e
+        assert np.all(idx[e][m] > idx[e - 1][m]), "row entries out of order at slot %d" % e
+    verts, vcd = oracle.site_vertex_distances(host.cell, host.centers, host.vertices, ref[sm])
+    exp, _ = oracle.fill(host.cell, oracle.wrap_points(host.cell, frames), np.where(sm)[0], np.where(mm)[0],
+                         ref[sm], verts, vcd, check_for_zeros=False)
+    assert np.array_equal(nnz, (exp != 0).sum(axis=1))
+    got = ctx.rows_dense()
+    np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
+
+
 @pytest.mark.parametrize("waves,fpb,rcap,contig", [("4", "1", "48", "2"), ("8", "2", "8", "1"), ("16", "3", "64", "0"),
                                                    ("4", "4", "16", "2")])
 def test_third_generation_launch_shapes_agree(waves, fpb, rcap, contig):
