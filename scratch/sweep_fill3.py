@@ -43,13 +43,13 @@ print("  census: landmark tasks/ion %.2f past the critical vertex %.2f survivors
 for stop in (1, 4):
     t = run(ctx3, SITATOR_DEBUG_STOP=stop)
     print("  gen3 debug_stop=%d: %.4f ms" % (stop, t[0]), flush=True)
-shapes = [(4, 1, 48), (4, 1, 40), (4, 1, 32), (4, 1, 64), (8, 1, 24), (8, 2, 48), (4, 2, 64), (16, 4, 48)]
+shapes = [(4, 1, 48, 16), (4, 1, 40, 16), (4, 1, 32, 16), (4, 2, 48, 32), (4, 2, 64, 32), (8, 2, 40, 16), (8, 1, 24, 8), (4, 1, 40, 32), (8, 1, 40, 16)]
 if len(sys.argv) > 3:
     shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[3:]]
-for nw, fpb, rcap in shapes:
-    env = dict(SITATOR_FILL_WAVES=nw, SITATOR_FILL_FPB=fpb, SITATOR_FILL_RCAP=rcap)
+for nw, fpb, rcap, iw in shapes:
+    env = dict(SITATOR_FILL_WAVES=nw, SITATOR_FILL_FPB=fpb, SITATOR_FILL_RCAP=rcap, SITATOR_FILL_IW=iw)
     try:
         t = run(ctx3, **env)
-        print("  nw %2d fpb %d rcap %2d: min %.4f med %.4f ms" % (nw, fpb, rcap, t[0], t[1]), flush=True)
+        print("  nw %2d fpb %d rcap %2d iw %2d: min %.4f med %.4f ms (nw used %d)" % (nw, fpb, rcap, iw, t[0], t[1], t[2]["waves_per_workgroup"]), flush=True)
     except AssertionError as e:
-        print("  nw %d fpb %d rcap %d: failed %s" % (nw, fpb, rcap, e), flush=True)
+        print("  nw %d fpb %d rcap %d iw %d: failed %s" % (nw, fpb, rcap, iw, e), flush=True)

@@ -4,14 +4,16 @@
 // contraction of the reference's expressions); what changes is where the instructions and the waiting go.  The second
 // generation was VALU-issue-bound at ~100 wave-instructions per ion, less than half of them arithmetic of the
 // reference, and every wave kept private task lists:
-//   * a workgroup (one frame of a 64-ion system) works through its ions 64 at a time, every stage spread over all
-//     its waves: ONE wave owns the ions (a lane each: bin, candidate list, offset vector) and writes a flat task
-//     table; all waves then take (landmark task, vertex) LANES - eight lanes per task, one squared distance each,
-//     compared against (rz * vcd)^2 - so a pass has no per-lane loops and no divergence;
-//   * the tasks whose eight lanes all pass are compacted with two ballots into a wave-private region of survivors
+//   * a workgroup parks one frame (of a 64-ion system) in LDS; each wave then owns a window of its ions (a lane each:
+//     bin, candidate list, offset vector) and writes a flat table of (ion, landmark) tasks.  A first pass tests
+//     every task's CRITICAL vertex with one lane (the vertex with the least room in the ion's bin, from the table
+//     builder) and compacts the table in place; the remaining tasks take (task, vertex) LANES - eight lanes per
+//     task, one squared distance each, compared against (rz * vcd)^2 - so a pass has no per-lane loops;
+//   * the tasks whose eight lanes all pass are compacted with two ballots into the wave's region of survivors
 //     (their squared distances, 64 bytes each); the logistic factors are then evaluated one lane per (survivor,
 //     vertex) IN PLACE, multiplied in vertex order by one lane per survivor, and that lane writes the row entry
-//     directly (its position in the row is a population count over the non-zero masks of the workgroup);
+//     directly (its position in the row is a population count over the wave's non-zero mask);
+//   * nothing in this is shared between waves but the read-only frame: no workgroup barrier after phase 1;
 //   * sqrt, the two divisions and exp went through the general-purpose library sequences (range scaling, special
 //     cases, a degree-11 polynomial).  The operands here have known ranges, so: sqrt = the library's own
 //     Newton sequence without the range scaling (bit-identical for normal operands), dist/vcd = multiplication
@@ -21,7 +23,7 @@
 //     than the device library's exp);
 //   * the frames are copied into LDS as straight runs of doubles (eight loads per thread in flight) and wrapped in
 //     place; the static-lattice check first tries the plain displacement, which bounds the periodic one.
-// LDS per workgroup is ~35 KB at 64 ions and 512 statics (16 waves per CU) and a batch costs two workgroup barriers.
+// LDS per workgroup is ~32 KB at 64 ions and 512 statics (five workgroups = 20 waves per CU).
 // Kept from fill2: tight/loose pruning tables, error keys, slot-major sparse rows, exactness rules.
 #include <cmath>
 #include <cstdlib>
@@ -58,7 +60,7 @@ struct Fill3Head {
     const double2 *exptab;
     u64 *err, *scal;
     i64 F, A, frame0;
-    int S, M, fpb, contig, debug_stop, rcap, force_loose, s0, m0;
+    int S, M, fpb, contig, debug_stop, rcap, iw, force_loose, s0, m0;
     double delta2, thr2_lo, thr2_hi, static_thr, safe2;
 };
 typedef const Fill3Args __attribute__((address_space(4))) *Fill3ArgsPtr;
@@ -207,16 +209,16 @@ __device__ __forceinline__ int wave_add_scan(int x)
     return x;
 }
 
-// LDS of a workgroup besides the frames, in bytes: `rcap` survivors per wave (multiple of 8, <= 64), NW waves
-__host__ __device__ inline int f3_pool_bytes(int rcap, int vp, int nw)
+#define F3_TCAP 128        // (ion, landmark) tasks of a wave batch
+
+// LDS of a wave, in bytes: `rcap` survivor slots (multiple of 8, <= 64), windows of `iw` ions (multiple of 4, <= 64)
+__host__ __device__ inline int f3_wave_bytes(int rcap, int vp, int iw)
 {
-    return nw * rcap * vp * 8    // sd2: squared distances, then logistic factors, of the survivors
-         + nw * 128 * 4          // ttab: landmark | ion << 24 per task (128 tasks per wave and batch)
-         + nw * rcap * 4         // sv_k: landmark | nv << 24 per survivor
-         + 64 * 16               // info: per ion of the window {offset vector, statics of its frame (xyz indices), frame}
-         + 64 * 4 * 6            // first / last survivor of an ion (two parities), entries written per ion, pending counts
-         + 16 * 8                // non-zero masks, one word per wave
-         + 64;                   // batch parameters
+    return rcap * vp * 8         // sd2: squared distances, then logistic factors, of the survivors
+         + F3_TCAP * 4           // ttab: landmark | critical vertex << 22 | ion << 26 per task
+         + rcap * 4              // sv_k: the task of every survivor
+         + iw * 16               // info: per ion of the window {offset vector, statics of its frame (byte offsets), frame}
+         + iw * 4;               // entries written per ion
 }
 
 // LG: log2 of the padded vertices per landmark (2 or 3).  NW: waves per workgroup.  DYN: dynamic lattice mapping
@@ -229,26 +231,21 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     constexpr int VP = 1 << LG;
     constexpr int NT = NW * 64;
     constexpr int TPP = 64 >> LG;                               // tasks per pass of 64 lanes
-    constexpr int LCAP = 128 * NW;                              // landmark tasks per batch
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = h.S, M = h.M, SM = S + M;
     const int fpb = h.fpb;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rcap = h.rcap;
-    // layout: [pooled buffers] [exp table] [atoms: per frame statics then mobiles] [frame flags]
-    char *lp = smem;
-    double *sd2 = (double *)lp; lp += NW * rcap * VP * 8;
-    unsigned *ttab = (unsigned *)lp; lp += LCAP * 4;
-    unsigned *sv_k = (unsigned *)lp; lp += NW * rcap * 4;
-    uint4 *info = (uint4 *)lp; lp += 64 * 16;
-    unsigned *ifirst = (unsigned *)lp; lp += 64 * 4 * 2;        // [parity][ion]
-    unsigned *ilast = (unsigned *)lp; lp += 64 * 4 * 2;
-    unsigned *nzc = (unsigned *)lp; lp += 64 * 4;
-    unsigned *nzpend = (unsigned *)lp; lp += 64 * 4;
-    unsigned long long *nzmask = (unsigned long long *)lp; lp += 16 * 8;
-    int *bp = (int *)lp; lp += 64;
-    double2 *etab = (double2 *)lp; lp += F3_EXPN * 16;
-    double *xyz = (double *)lp;                                 // [fpb][S + M][3]; mobiles become centroid - ion
+    // layout: [per-wave buffers] [exp table] [atoms: per frame statics then mobiles] [frame flags]
+    const int IW = h.iw;
+    char *lp = smem + wave * f3_wave_bytes(rcap, VP, IW);
+    double *sd2 = (double *)lp; lp += rcap * VP * 8;
+    unsigned *ttab = (unsigned *)lp; lp += F3_TCAP * 4;
+    unsigned *sv_k = (unsigned *)lp; lp += rcap * 4;
+    uint4 *info = (uint4 *)lp; lp += IW * 16;
+    unsigned *nzc = (unsigned *)lp;
+    double2 *etab = (double2 *)(smem + NW * f3_wave_bytes(rcap, VP, IW));
+    double *xyz = (double *)(etab + F3_EXPN);                   // [fpb][S + M][3]; mobiles become centroid - ion
     u64 *fmax = (u64 *)(xyz + 3 * fpb * SM);                    // [fpb]
     const Pbc &P = h.P;
     const i64 f0 = (i64)blockIdx.x * fpb;
@@ -257,8 +254,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
 
     if (tid < fpb) fmax[tid] = 0ull;
     if (tid < F3_EXPN) etab[tid] = h.exptab[tid];
-    for (int q = tid; q < LCAP; q += NT) ttab[q] = 0u;         // stale entries must stay valid (landmark 0, ion 0)
-    if (tid < 64) info[tid] = make_uint4(0u, 0u, 0u, 0u);
+    for (int q = lane; q < F3_TCAP; q += 64) ttab[q] = 0u;     // stale entries must stay valid (landmark 0, ion 0)
+    if (lane < IW) info[lane] = make_uint4(0u, 0u, 0u, 0u);
     // ---- phase 1a: copy this workgroup's atoms into LDS, eight independent loads per thread in flight ----
     {
         const double *fbase = h.frames + f0 * h.A * 3;
@@ -342,75 +339,68 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     const double *hi2p = g.hi2p;
     const double2 *vr = g.vr;
     const double mid = g.midpoint, steep = g.steepness, rz = g.rz;
-    const int myreg = wave * rcap;                              // my region of survivors
     // per-lane constants of the (task, vertex) passes
     const int hh = lane & (VP - 1), gl0 = lane & ~(VP - 1);     // my vertex, first lane of my task
     const unsigned long long grpmask = (VP == 8 ? 0xffull : 0xfull) << gl0, below = (1ull << gl0) - 1ull;
     const unsigned long long leadmask = VP == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
 
-    // ---- phase 2: windows of 64 ions; wave 0 owns the ions (one lane each) and cuts the window into batches of at
-    //      most LCAP landmark tasks; the tasks of a batch are spread over all waves ----
+    // ---- phase 2: every wave on its own (windows of IW ions, a lane each); no workgroup barrier from here on ----
     const int nions = nf * M;
-    for (int ib0 = 0; ib0 < nions; ib0 += 64) {
-        const int nib = (nions - ib0) < 64 ? (nions - ib0) : 64;
-        int fl = 0, j = 0, nL = 0, exL = 0, inL = 0;
+    for (int ib0 = wave * IW; ib0 < nions; ib0 += NW * IW) {
+        const int nib = (nions - ib0) < IW ? (nions - ib0) : IW;
+        // owner lanes: bin -> candidate list, offset vector (helpers.pyx:100)
+        int fl = 0, j = 0, nL = 0;
         const i32 *mylist = nullptr;
         const unsigned char *mycrit = nullptr;
-        if (wave == 0) {
-            // owner lanes: bin -> candidate list, offset vector (helpers.pyx:100)
-            if (lane < nib) {
-                const int ion = ib0 + lane;
-                for (int q = 1; q < nf; q++) fl += ion >= q * M;
-                j = ion - fl * M;
-                double *mp = xyz + 3 * (fl * SM + S + j);
-                const double px = mp[0], py = mp[1], pz = mp[2];
-                if (fmax[fl] != 0ull) {
-                    const int b = bin_of3<CELL>(P, px, py, pz, g.tG0, g.tG1, g.tG2);
-                    const i32 lo = g.t_off[b];
-                    nL = g.t_off[b + 1] - lo; mylist = g.t_list + lo; mycrit = g.t_crit + lo;
-                } else {
-                    const int b = bin_of3<CELL>(P, px, py, pz, g.lG0, g.lG1, g.lG2);
-                    const i32 lo = g.l_off[b];
-                    nL = g.l_off[b + 1] - lo; mylist = g.l_list + lo; mycrit = g.l_crit + lo;
-                }
-                mp[0] = P.cen[0] - px; mp[1] = P.cen[1] - py; mp[2] = P.cen[2] - pz;
-                nzc[lane] = 0u; nzpend[lane] = 0xffffffffu;
-                // byte offsets into xyz[]: my offset vector, the statics of my frame; my frame
-                info[lane] = make_uint4(24u * (unsigned)(fl * SM + S + j), 24u * (unsigned)(fl * SM), (unsigned)fl, 0u);
+        if (lane < nib) {
+            const int ion = ib0 + lane;
+            for (int q = 1; q < nf; q++) fl += ion >= q * M;
+            j = ion - fl * M;
+            double *mp = xyz + 3 * (fl * SM + S + j);
+            const double px = mp[0], py = mp[1], pz = mp[2];
+            if (fmax[fl] != 0ull) {
+                const int b = bin_of3<CELL>(P, px, py, pz, g.tG0, g.tG1, g.tG2);
+                const i32 lo = g.t_off[b];
+                nL = g.t_off[b + 1] - lo; mylist = g.t_list + lo; mycrit = g.t_crit + lo;
+            } else {
+                const int b = bin_of3<CELL>(P, px, py, pz, g.lG0, g.lG1, g.lG2);
+                const i32 lo = g.l_off[b];
+                nL = g.l_off[b + 1] - lo; mylist = g.l_list + lo; mycrit = g.l_crit + lo;
             }
-            inL = wave_add_scan(nL);
-            exL = inL - nL;
+            mp[0] = P.cen[0] - px; mp[1] = P.cen[1] - py; mp[2] = P.cen[2] - pz;
+            nzc[lane] = 0u;
+            // byte offsets into xyz[]: my offset vector, the statics of my frame; my frame
+            info[lane] = make_uint4(24u * (unsigned)(fl * SM + S + j), 24u * (unsigned)(fl * SM), (unsigned)fl, 0u);
         }
+        const int inL = wave_add_scan(nL), exL = inL - nL;
         int ion_s = 0;
-        while (true) {
-            if (wave == 0) {
-                // batch [ion_s, ion_e): whole ions, at most LCAP landmark tasks
-                const int preL = __shfl(exL, ion_s);
-                const unsigned long long fit = __ballot(lane >= ion_s && lane < nib && inL - preL <= LCAP);
-                const int take = __popcll(fit);
-                const int ion_e = ion_s + take;
-                const int nlt = take > 0 ? __shfl(inL, ion_e - 1) - preL : 0;
-                if (lane >= ion_s && lane < ion_e) {
-                    ifirst[lane] = 0xffffffffu; ilast[lane] = 0u;
-                    for (int c = 0; c < nL; c++)       // landmark | critical vertex << 22 | ion << 26
-                        ttab[exL - preL + c] = (unsigned)mylist[c] | ((unsigned)mycrit[c] << 22) | ((unsigned)lane << 26);
+        while (ion_s < nib) {
+            // batch [ion_s, ion_e): whole ions, at most F3_TCAP tasks
+            const int preL = __shfl(exL, ion_s);
+            const unsigned long long fit = __ballot(lane >= ion_s && lane < nib && inL - preL <= F3_TCAP);
+            if (!fit) { if (lane == 0) atomicAdd(&h.scal[3], 1ull); break; }       // cannot happen (host checks)
+            const int ion_e = ion_s + __popcll(fit);
+            const int nlt = __shfl(inL, ion_e - 1) - preL;
+            if (lane >= ion_s && lane < ion_e) {
+                // task = landmark | critical vertex << 22 | ion << 26; four list entries in flight per lane
+                for (int c0 = 0; c0 < nL; c0 += 4) {
+                    unsigned e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) e[u] = c0 + u < nL ? ((unsigned)mylist[c0 + u] | ((unsigned)mycrit[c0 + u] << 22)) : 0u;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (c0 + u < nL) ttab[exL - preL + c0 + u] = e[u] | ((unsigned)lane << 26);
                 }
-                if (lane == 0) { bp[0] = ion_e; bp[1] = nlt; bp[2] = 0; }
             }
-            __syncthreads();                                                                   // B1
-            const int ion_e = __builtin_amdgcn_readfirstlane(bp[0]), nlt = __builtin_amdgcn_readfirstlane(bp[1]);
-            if (ion_e <= ion_s) { if (tid == 0) atomicAdd(&h.scal[3], 1ull); break; }          // cannot happen (host checks)
-            if (h.debug_stop == 9 && tid == 0) { atomicAdd(&h.scal[5], (u64)nlt); atomicAdd(&h.scal[7], 1ull); }
-            // a contiguous range of tasks per wave (so the survivors of wave w precede those of wave w + 1)
-            const int tpw = (nlt + NW - 1) / NW;
-            const int t_lo = wave * tpw < nlt ? wave * tpw : nlt, t_hi = (t_lo + tpw) < nlt ? (t_lo + tpw) : nlt;
+            if (h.debug_stop == 9 && lane == 0) { atomicAdd(&h.scal[5], (u64)nlt); atomicAdd(&h.scal[7], 1ull); }
+            __builtin_amdgcn_wave_barrier();
             // ---- D0: one lane per task tests the task's CRITICAL vertex (the one with the least room in this ion's
             //      bin, candidates.hip); the tasks that pass are compacted in place ----
-            int t_end = t_lo;
-            for (int t0 = t_lo; t0 < t_hi; t0 += 64) {
+            int t_end = 0;
+            for (int t0 = 0; t0 < nlt; t0 += 64) {
                 const int t = t0 + lane;
-                const bool act = t < t_hi;
-                const unsigned tk = ttab[act ? t : t_lo];
+                const bool act = t < nlt;
+                const unsigned tk = ttab[act ? t : 0];
                 const unsigned k = tk & 0x3fffffu, cv = (tk >> 22) & 7u;
                 const uint4 iv = info[tk >> 26];
                 i32 v = verts[k * VP + cv];
@@ -425,19 +415,16 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 const double d2 = (dx * dx + dy * dy) + dz * dz;
                 const bool keep = act && !(d2 > hk);
                 const unsigned long long km = __ballot(keep);
-                if (keep) ttab[t_end + __popcll(km & ((1ull << lane) - 1ull))] = tk;
+                if (keep) ttab[t_end + __popcll(km & ltmask)] = tk;
                 t_end += __popcll(km);
             }
-            if (h.debug_stop == 9 && lane == 0) atomicAdd(&h.scal[4], (u64)(t_end - t_lo));
+            if (h.debug_stop == 9 && lane == 0) atomicAdd(&h.scal[4], (u64)t_end);
             __builtin_amdgcn_wave_barrier();
-            const int pend = (t_end - t_lo + TPP - 1) / TPP;    // passes of TPP tasks over [t_lo, t_end)
+            const int pend = (t_end + TPP - 1) / TPP;           // passes of TPP tasks over [0, t_end)
             int cursor = 0;
-            int par = 0;
-            bool hadmore = false;
-            int rounds = 0;
             while (true) {
                 // ---- D1: one squared distance per (task, vertex) lane (helpers.pyx:174-178 before the sqrt),
-                //      compared with (rz * vcd)^2; tasks with every vertex inside go to my region of survivors.
+                //      compared with (rz * vcd)^2; tasks with every vertex inside go to the region of survivors.
                 //      Two passes per iteration (loads and arithmetic of both first) while the region has room for
                 //      every task of both ----
                 int cnt = 0;
@@ -449,8 +436,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         if (u == 1 && !two) { bad[1] = ~0ull; tk[1] = 0u; d2[1] = 0.0; break; }
-                        const int t = t_lo + TPP * (cursor + u) + (lane >> LG);
-                        tk[u] = ttab[t < LCAP ? t : 0];
+                        const int t = TPP * (cursor + u) + (lane >> LG);
+                        tk[u] = ttab[t < F3_TCAP ? t : 0];
                         const unsigned k = tk[u] & 0x3fffffu;
                         const uint4 iv = info[tk[u] >> 26];
                         i32 v = verts[k * VP + hh];
@@ -471,20 +458,14 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                         const bool aliveg = (bad[u] & grpmask) == 0ull;
                         const unsigned long long leaders = __ballot(aliveg) & leadmask;
                         if (aliveg) {
-                            const int q = myreg + cnt + __popcll(leaders & below);
+                            const int q = cnt + __popcll(leaders & below);
                             sd2[q * VP + hh] = d2[u];
-                            if (hh == 0) {
-                                const unsigned ion = tk[u] >> 26;
-                                sv_k[q] = tk[u];
-                                atomicMin(&ifirst[64 * par + ion], (unsigned)(64 * wave + q - myreg));
-                                atomicMax(&ilast[64 * par + ion], (unsigned)(64 * wave + q - myreg));
-                            }
+                            if (hh == 0) sv_k[q] = tk[u];
                         }
                         cnt += __popcll(leaders);
                     }
                     cursor += two ? 2 : 1;
                 }
-                if (lane == 0 && cursor < pend) atomicOr(&bp[2], 1);
                 if (h.debug_stop == 9 && lane == 0) atomicAdd(&h.scal[6], (u64)cnt);
                 if (h.debug_stop == 4) cnt = 0;
                 __builtin_amdgcn_wave_barrier();
@@ -498,26 +479,28 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                     for (int u = 0; u < 2; u++) {
                         const int i = i0 + 64 * u + lane;
                         const int ii = i < items ? i : 0;
-                        const unsigned kk = sv_k[myreg + (ii >> LG)];
-                        d2[u] = sd2[myreg * VP + ii];
+                        const unsigned kk = sv_k[ii >> LG];
+                        d2[u] = sd2[ii];
                         c[u] = vr[(i64)(kk & 0x3fffffu) * VP + (ii & (VP - 1))];
                     }
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const int i = i0 + 64 * u + lane;
                         const double f = vertex_factor(d2[u], c[u].x, c[u].y, rz, steep, mid, etab);
-                        if (i < items) sd2[myreg * VP + i] = c[u].y != 0.0 ? f : 1.0;
+                        if (i < items) sd2[i] = c[u].y != 0.0 ? f : 1.0;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                // ---- T1: ci *= temp in vertex order (helpers.pyx:208) and the n-th root (:212), one lane per survivor ----
+                // ---- T: ci *= temp in vertex order (helpers.pyx:208) and the n-th root (:212), one lane per
+                //      survivor; the row entry of a component is the number of earlier non-zero components of its
+                //      ion (the survivors are in task order: ion-major, ascending landmark) ----
                 double val = 0.0;
                 unsigned kk = 0;
                 const bool tact = lane < cnt;
                 if (tact) {
-                    kk = sv_k[myreg + lane];
+                    kk = sv_k[lane];
                     const int nv = (int)g.nvtab[kk & 0x3fffffu];
-                    const double2 *fp = (const double2 *)(sd2 + (myreg + lane) * VP);
+                    const double2 *fp = (const double2 *)(sd2 + lane * VP);
                     double2 a = fp[0], b = fp[1];
                     double acc = a.x;
                     acc *= a.y; acc *= b.x; acc *= b.y;
@@ -525,69 +508,29 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                     if (acc != 0.0) val = root_chain(acc, nv);
                 }
                 const bool nz = tact && val != 0.0;
-                { const unsigned long long nzm = __ballot(nz); if (lane == 0) nzmask[wave] = nzm; }
-                if (tid < 64) {
-                    ifirst[64 * (par ^ 1) + tid] = 0xffffffffu; ilast[64 * (par ^ 1) + tid] = 0u;
-                    const unsigned pc = nzpend[tid];                    // counts published by the previous round
-                    if (pc != 0xffffffffu) { nzc[tid] = pc; nzpend[tid] = 0xffffffffu; }
-                }
-                __syncthreads();                                                               // B2
-                // ---- T2: the row entry of a component is the number of earlier non-zero components of its ion ----
-                const int more = __builtin_amdgcn_readfirstlane(bp[2]);
+                const int ion = tact ? (int)(kk >> 26) : -1;
+                const int prev = __builtin_amdgcn_update_dpp(-1, ion, 0x138, 0xf, 0xf, false);      // wave_shr:1
+                const int next = __builtin_amdgcn_update_dpp(-1, ion, 0x130, 0xf, 0xf, false);      // wave_shl:1
+                const unsigned long long starts = __ballot(tact && prev != ion), nzm = __ballot(nz);
                 if (tact) {
-                    const unsigned ion = kk >> 26;
-                    const int me = 64 * wave + lane, first = (int)ifirst[64 * par + ion];
-                    int rank = 0;
-                    for (int wd = first >> 6; wd <= wave; wd++) {
-                        const int lo = first > 64 * wd ? first - 64 * wd : 0, hi = me - 64 * wd < 64 ? me - 64 * wd : 64;
-                        unsigned long long mk = nzmask[wd] >> lo;
-                        if (hi - lo < 64) mk &= (1ull << (hi - lo)) - 1ull;
-                        rank += __popcll(mk);
-                    }
-                    const int e = (int)nzc[ion] + rank;
+                    const int start = 63 - __clzll(starts & (ltmask | (1ull << lane)));               // my ion's first survivor
+                    const int e = (int)nzc[ion] + __popcll(nzm & ltmask & ~((1ull << start) - 1ull));
                     if (nz && g.row_val != nullptr) {
                         const i64 row = f0 * M + ib0 + (i64)ion;                  // rows are frame-major
                         if (e < g.W) { g.row_idx[(i64)e * g.N + row] = (i32)(kk & 0x3fffffu); g.row_val[(i64)e * g.N + row] = val; }
                         else atomicAdd(&h.scal[3], 1ull);
                     }
-                    // the ion's last survivor leaves the new count; it is folded into nzc[] behind the next barriers
-                    if (me == (int)ilast[64 * par + ion]) nzpend[ion] = (unsigned)(e + (nz ? 1 : 0));
+                    __builtin_amdgcn_wave_barrier();
+                    if (next != ion) nzc[ion] = (unsigned)(e + (nz ? 1 : 0));     // the ion's last survivor of this round
                 }
-                __syncthreads();                                                               // B3: regions and masks free
-                if (!more) break;
-                if (++rounds > LCAP) { if (tid == 0) atomicAdd(&h.scal[3], 1ull); break; }    // cannot happen: a round takes at least one pass
-                hadmore = true;
-                if (tid == 0) bp[2] = 0;
-                par ^= 1;
-                __syncthreads();
-            }
-            // A wave whose region filled up continued in a later round, possibly after the next wave had written
-            // later components of the same ion: the entries of this batch's rows are then complete but not in
-            // ascending landmark order.  Rows are short; their owners sort them.
-            if (hadmore && wave == 0 && lane >= ion_s && lane < ion_e && g.row_val != nullptr) {
-                const unsigned pc = nzpend[lane];
-                int n = (int)(pc != 0xffffffffu ? pc : nzc[lane]);
-                n = n < g.W ? n : g.W;
-                const i64 row = f0 * M + ib0 + lane;
-                for (int i = 1; i < n; i++) {
-                    const i32 ki = g.row_idx[(i64)i * g.N + row];
-                    const double vi = g.row_val[(i64)i * g.N + row];
-                    int q = i - 1;
-                    while (q >= 0 && g.row_idx[(i64)q * g.N + row] > ki) {
-                        g.row_idx[(i64)(q + 1) * g.N + row] = g.row_idx[(i64)q * g.N + row];
-                        g.row_val[(i64)(q + 1) * g.N + row] = g.row_val[(i64)q * g.N + row];
-                        q--;
-                    }
-                    g.row_idx[(i64)(q + 1) * g.N + row] = ki;
-                    g.row_val[(i64)(q + 1) * g.N + row] = vi;
-                }
+                __builtin_amdgcn_wave_barrier();
+                if (cursor >= pend) break;
             }
             ion_s = ion_e;
-            if (ion_s >= nib) break;
         }
-        if (wave == 0 && lane < nib) {
-            const unsigned pc = nzpend[lane];
-            const int nnz = h.debug_stop == 4 ? 1 : (int)(pc != 0xffffffffu ? pc : nzc[lane]);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nib) {
+            const int nnz = h.debug_stop == 4 ? 1 : (int)nzc[lane];
             const i64 row = (f0 + fl) * M + j;
             g.row_nnz[row] = nnz < g.W ? nnz : g.W;
             if (nnz == 0) {                                               // helpers.pyx:116-120
@@ -595,6 +538,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 else atomicAdd(&h.scal[0], 1ull);
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -702,22 +646,29 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
         if (c->static_thr * (1.0 - 1e-9) < safe) safe = c->static_thr * (1.0 - 1e-9);
         h.safe2 = safe > 0 ? safe * safe * (1.0 - 1e-12) : -1.0;
     }
-    // launch shape: NW waves share the frames of a workgroup and work through its ions 64 at a time
+    // launch shape: NW waves share the frames of a workgroup; every wave takes windows of IW of its ions
     int nw = f3_env_int("SITATOR_FILL_WAVES", 0);
     int fpb = f3_env_int("SITATOR_FILL_FPB", 0);
     int rcap = f3_env_int("SITATOR_FILL_RCAP", 0);
     const int vp = (int)c->Vp;
     const size_t frame_bytes = (size_t)(S + M) * 24;
-    auto lds_bytes = [&](int nwv, int fpbv, int rcapv) {
-        return (size_t)f3_pool_bytes(rcapv, vp, nwv) + F3_EXPN * 16 + (size_t)fpbv * frame_bytes + (size_t)fpbv * 8 + 32;
-    };
-    if (fpb < 1) { i64 f = 64 / M; if (f < 1) f = 1; if (f > 32) f = 32; fpb = (int)f; }      // at least one window of 64 ions
+    int iw = f3_env_int("SITATOR_FILL_IW", 0);
+    if (fpb < 1) { i64 f = 64 / M; if (f < 1) f = 1; if (f > 32) f = 32; fpb = (int)f; }      // about 64 ions per workgroup
     if (fpb > 32) fpb = 32;
     const bool rcap_auto = rcap < 8;
     if (rcap_auto) rcap = 48;
     rcap = (rcap + 7) / 8 * 8;
     if (rcap > 64) rcap = 64;
     if (rcap < 64 / vp) rcap = 64 / vp;                        // a pass of 64 / vp tasks must fit an empty region
+    auto iw_for = [&](int nwv, int fpbv) {
+        // ions per wave window: the workgroup's ions dealt evenly, at least 16 (the owner lanes of a window work alone)
+        if (iw >= 1 && iw <= 64) return (iw + 3) / 4 * 4;
+        const i64 per = ((i64)fpbv * M + nwv - 1) / nwv;
+        return (int)(per < 16 ? 16 : (per > 64 ? 64 : (per + 3) / 4 * 4));
+    };
+    auto lds_bytes = [&](int nwv, int fpbv, int rcapv) {
+        return (size_t)nwv * f3_wave_bytes(rcapv, vp, iw_for(nwv, fpbv)) + F3_EXPN * 16 + (size_t)fpbv * frame_bytes + (size_t)fpbv * 8 + 32;
+    };
     if (nw != 4 && nw != 8 && nw != 16) {
         // small frames: 4 waves and several workgroups per CU; a frame that leaves room for one workgroup only: 16
         const size_t b4 = lds_bytes(4, fpb, rcap);
@@ -725,13 +676,15 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
     }
     if (rcap_auto) {
         // fewer survivor slots per wave when that admits one more workgroup per CU (a full region only costs a round)
-        auto wg_per_cu = [&](int r) { const size_t b = lds_bytes(nw, fpb, r); size_t k = (160 * 1024) / b; return k > 8 ? (size_t)8 : k; };
+        // (workgroups are admitted with some slack: 5 x 31.5 KB did not run five per CU, 5 x 29.5 KB did)
+        auto wg_per_cu = [&](int r) { const size_t b = (lds_bytes(nw, fpb, r) + 1535) / 1024 * 1024; size_t k = (160 * 1024) / b; return k > 8 ? (size_t)8 : k; };
         for (int r : {40, 32}) if (wg_per_cu(r) > wg_per_cu(rcap)) rcap = r;
     }
     while (fpb > 1 && lds_bytes(nw, fpb, rcap) > 160 * 1024 - 512) fpb--;
     const size_t lds = lds_bytes(nw, fpb, rcap);
     SIT_REQUIRE(c, lds <= 160 * 1024 - 256, "sit_fill: one frame's atoms do not fit in LDS");
-    h.fpb = fpb; h.rcap = rcap;
+    iw = iw_for(nw, fpb);
+    h.fpb = fpb; h.rcap = rcap; h.iw = iw;
     c->last_fpb = fpb; c->last_kernel = 3; c->last_iw = rcap; c->last_nw = nw;
     const unsigned grid = (unsigned)((c->F + fpb - 1) / fpb);
     if (!c->d_fill_args) {
