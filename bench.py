@@ -12,17 +12,26 @@ confidence per (frame, ion).  Frames are resident in HBM before the timed region
 centres come from the product's own end-to-end `run()` on the same trajectory (outside the timed
 region; its wall time is reported as `end_to_end_run`).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_fill_rows) with the
-algorithmic bytes of SURVEY.md section 8(d): B = 24*A/M + 16 bytes per landmark vector.
-`cpu_baseline` = the oracle's C port of the same pass, single thread, on a bounded cut.
+N > 1: one process per GPU.  Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks come from
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; a bare `python bench.py --gpus N` starts the N ranks itself (fresh child
+processes, before anything touches a GPU).  The ranks talk through the library's own RCCL entry points
+(`sit_comm_*`, sitator_amd/sharding.py `RcclComm`) - the end-to-end run exercises every exchange step of the path
+(first-offender keys, counts, the ordered fit relay, site-centre anchors and sums, occupancy); the timed pass has no
+collective in it (frames shard embarrassingly) and is bracketed by an RCCL barrier on both sides.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the fill kernel that ran: k_fill3 unless the
+tables force an older generation) with the algorithmic bytes of SURVEY.md section 8(d): B = 24*A/M + 16 bytes per
+landmark vector; `roofline.frac_step` is the same for the whole step (fill + assignment).
+`cpu_baseline` = the oracle's C port of the same pass on a bounded cut, one thread (the reference's execution model)
+and all host cores.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -37,41 +46,76 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=100000, help="frames per GPU")
     ap.add_argument("--config", default="C2")
-    ap.add_argument("--cpu-frames", type=int, default=2000, help="frames of the CPU-baseline cut (0 = skip)")
-    ap.add_argument("--compare-v1", action="store_true",
-                    help="also time the first-generation kernels (fill + predict), interleaved in this process")
+    ap.add_argument("--cpu-frames", type=int, default=1000, help="frames per core of the CPU-baseline cut (0 = skip)")
+    ap.add_argument("--compare-v2", action="store_true",
+                    help="also time the second-generation fill kernel, interleaved in this process")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has
+    not touched a GPU and never will), pass rank 0's JSON line through."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout
+    rc = 0
+    try:
+        for line in out0:
+            sys.stdout.write(line.decode())
+            sys.stdout.flush()
+        for p in procs:
+            rc = max(rc, p.wait())
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    backend = os.environ.get("SITATOR_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path on a 1-GPU box
+    backend = os.environ.get("SITATOR_BENCH_BACKEND", "rccl")     # "gloo": rehearsal of the N>1 path on a 1-GPU box
+    import numpy as np
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth, _lib, sharding
+
+    comm = None
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        ndev = torch.cuda.device_count()
-        if backend == "nccl":
+        if backend == "rccl":
+            ndev = _lib.device_count()
+            if os.environ.get("SITATOR_BENCH_SHARE_GPU") == "1":      # rehearsal: several ranks on one GPU
+                local = local % max(ndev, 1)
             if local >= ndev:
                 raise RuntimeError("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local, ndev))
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            comm = sharding.RcclComm.from_env(device=local)
+            print("[rank %d/%d] RCCL communicator up on GPU %d" % (rank, world, local), file=sys.stderr, flush=True)
         else:
-            local = local % max(ndev, 1)
-            torch.cuda.set_device(local)
+            import torch.distributed as dist
+            local = local % max(_lib.device_count(), 1)
             dist.init_process_group(backend)
-    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth, _lib
+            comm = sharding.TorchComm(device="cpu")
 
     host = synth.config_host(args.config)
     M = synth.CONFIG_MOBILE[args.config]
     S, D = len(host.static_pos), len(host.centers)
     A = S + M
     F = args.frames
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     gen = synth.TrajectoryGenerator(host, M, seed=synth.CONFIG_SEED[args.config] + 1000 * rank,
-                                    threads=max(1, min(16, (os.cpu_count() or 8) // max(1, min(world, 8)))))
+                                    threads=max(1, min(16, ncpu // max(1, min(world, 8)))))
     ref = gen.reference_positions()
     t0 = time.time()
     frames = gen.generate(F)
@@ -80,17 +124,19 @@ def main():
     sn.centers = host.centers
     sn.vertices = host.vertices
 
-    # --- end-to-end: the product's own LandmarkAnalysis.run() on this rank's whole trajectory (upload,
-    #     tables, fill, exact fit_centers, two predict passes, site centres, occupancy check).  It is
-    #     reported beside the headline and supplies the fitted site centres for the timed pass. ---
+    # --- end-to-end: the product's own LandmarkAnalysis.run() on the whole (N*F-frame) trajectory, this rank's
+    #     shard resident on its GPU (upload, tables, fill, exact fit_centers, two predict passes, site centres,
+    #     occupancy check; with N > 1 every exchange step of the path runs on RCCL).  It is reported beside the
+    #     headline and supplies the fitted site centres for the timed pass. ---
     t0 = time.time()
-    la = LandmarkAnalysis(verbose=False, device=local)
+    la = LandmarkAnalysis(verbose=False, device=local, comm=comm)
     st_full = la.run(sn, frames)
     t_e2e = time.time() - t0
-    e2e = {"frames": F, "seconds": round(t_e2e, 4), "lvec_per_s": round(F * M / t_e2e, 1),
+    e2e = {"frames": F * world, "seconds": round(t_e2e, 4), "lvec_per_s": round(world * F * M / t_e2e, 1),
            "wall_s": {k: round(v, 4) for k, v in la.wall_timings.items()},
            "sites": int(st_full.site_network.n_sites), "unassigned_frac": float(st_full.percent_unassigned),
-           "fit": {k: v for k, v in la._ctx.info().items() if k.startswith("fit_")}}
+           "fit": {k: v for k, v in la._ctx.info().items() if k.startswith("fit_")},
+           "exchange": "none (single process)" if comm is None else ("rccl" if backend == "rccl" else backend)}
     e2e_labels = st_full.traj.reshape(-1)
 
     # --- resident context for the timed pass ---
@@ -105,7 +151,7 @@ def main():
     ctx.set_basis(ref_static, verts, vcd, 1.5, 30, 1.0)
     ctx.set_frames(frames, np.where(gen.static_mask)[0], np.where(gen.mobile_mask)[0], frame0=rank * F)
     h2d_ms = ctx.timers()["h2d"]
-    # centres fitted on the cut: representative vectors of the sites found
+    # centres of the sites found by the run above
     fit_ctx_centers = np.asarray(la.cluster_centers_)
     with np.errstate(divide="ignore", invalid="ignore"):
         normed = fit_ctx_centers / np.linalg.norm(fit_ctx_centers, axis=1)[:, None]
@@ -118,10 +164,8 @@ def main():
 
     def sync_all():
         ctx.synchronize()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+        if comm is not None:
+            comm.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -135,32 +179,33 @@ def main():
         pred_ms.append(tm["predict"])
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    if comm is not None:
+        if hasattr(comm, "allreduce_max"):
+            elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
+        else:
+            elapsed = float(np.max(comm.allgather(np.array([elapsed]))))
+    info = ctx.info()
 
     ab = None
-    if args.compare_v1:
-        os.environ["SITATOR_FILL_KERNEL"] = "1"
+    if args.compare_v2:
+        os.environ["SITATOR_FILL_KERNEL"] = "2"
         ctx1 = _lib.HipContext(host.cell, device=local)
         ctx1.set_basis(ref_static, verts, vcd, 1.5, 30, 1.0)
         os.environ.pop("SITATOR_FILL_KERNEL")
         ctx1.set_frames(frames, np.where(gen.static_mask)[0], np.where(gen.mobile_mask)[0], frame0=rank * F)
         ctx1.set_centers(normed, True)
-        t_v1, t_v2 = [], []
+        t_v2, t_v3 = [], []
         for _ in range(max(3, args.steps)):
             ctx1.fill(False, False, True, assign=True, predict_threshold=0.8)
-            tm = ctx1.timers()
-            t_v1.append(tm["fill"] + tm["predict"])
+            t_v2.append(ctx1.timers()["fill"])
             step()
-            t_v2.append(ctx.timers()["fill"] + ctx.timers()["predict"])
+            t_v3.append(ctx.timers()["fill"])
         l1, c1, n1 = ctx1.assignments()
         l2, c2, n2 = ctx.assignments()
-        ab = {"v1_fill_plus_predict_ms": {"median": float(np.median(t_v1)), "min": float(np.min(t_v1))},
-              "v2_fill_plus_predict_ms": {"median": float(np.median(t_v2)), "min": float(np.min(t_v2))},
-              "labels_identical": bool(np.array_equal(l1, l2)), "confs_identical": bool(np.array_equal(c1, c2))}
+        ab = {"gen2_fill_ms": {"median": float(np.median(t_v2)), "min": float(np.min(t_v2))},
+              "gen3_fill_ms": {"median": float(np.median(t_v3)), "min": float(np.min(t_v3))},
+              "labels_identical": bool(np.array_equal(l1, l2)),
+              "max_rel_conf_diff": float(np.max(np.abs(c1 - c2) / np.maximum(np.abs(c1), 1e-300)))}
         ctx1.close()
 
     labels, confs, counts = ctx.assignments()
@@ -173,14 +218,9 @@ def main():
         value = n_lvec / elapsed
         bytes_per_lvec = 24.0 * A / M + 16.0
         fill_avg_ms = float(np.mean(fill_ms))
+        step_ms = fill_avg_ms + float(np.mean(pred_ms))
         achieved = (F * M * bytes_per_lvec) / (fill_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("k_fill2_bytes_per_launch")
-            except Exception:
-                traffic = None
+        kernel = "k_fill%d" % info["fill_kernel"] if info["fill_kernel"] > 1 else "k_fill_rows"
         out = {
             "metric": "landmark-vectors/sec (frames x mobile atoms), fill + site assignment",
             "value": value, "unit": "lvec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -191,9 +231,10 @@ def main():
                        "frames_per_gpu": F, "n_mobile": M, "n_static": S, "landmark_dim": D,
                        "parallelism": "frame-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_fill2", "kernel_ms": fill_avg_ms,
-                         "algorithmic_bytes_per_lvec": bytes_per_lvec},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel),
+                         "kernel": kernel, "kernel_ms": fill_avg_ms,
+                         "algorithmic_bytes_per_lvec": bytes_per_lvec,
+                         "frac_step": (F * M * bytes_per_lvec) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "stages_ms": {"fill": fill_avg_ms, "predict": float(np.mean(pred_ms)), "h2d_frames": h2d_ms,
                           "generate_s": round(t_gen, 2)},
             "end_to_end_run": e2e,
@@ -202,29 +243,76 @@ def main():
         if ab is not None:
             out["ab_kernels"] = ab
         if args.cpu_frames > 0 and world == 1:          # a reported baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(host, gen, frames[:min(F, args.cpu_frames)], ref, fit_ctx_centers, M)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            out["cpu_baseline"] = cpu_baseline(host, gen, frames, ref, fit_ctx_centers, M, args.cpu_frames, ncpu)
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.barrier()
+        if hasattr(comm, "close"):
+            comm.close()
 
 
-def cpu_baseline(host, gen, frames, ref, centers, M):
-    """The oracle's C port of the same pass (wrap, static check, dense landmark vectors, predict),
-    one thread, on a leading cut of the same trajectory."""
+def lib_sha():
+    p = os.path.join(ROOT, "sitator_amd", "lib", "libsitator_hip.so")
+    h = hashlib.sha256()
+    with open(p, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of the fill kernel from the PMC passes kept under profiles/ (FETCH_SIZE x 2 + WRITE_SIZE,
+    MI355X_MICROARCH.md) - only if they were taken with THIS build of the library, else null."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(tpath))
+        if rec.get("lib_sha16") == lib_sha() and rec.get("kernel") == kernel:
+            return rec.get("bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(host, gen, frames, ref, centers, M, frames_per_core, ncpu):
+    """The oracle's C port of the same pass (wrap, static check, dense landmark vectors, predict) on leading cuts of
+    the same trajectory: one thread (how the reference runs), and one cut per host core in parallel (ctypes releases
+    the GIL; the reference itself has no threading)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as orc
     orc.lib()
-    t0 = time.perf_counter()
-    wrapped = orc.wrap_points(host.cell, frames)
     ref_static = ref[gen.static_mask]
     verts, vcd = orc.site_vertex_distances(host.cell, host.centers, host.vertices, ref_static)
-    lv, _ = orc.fill(host.cell, wrapped, np.where(gen.static_mask)[0], np.where(gen.mobile_mask)[0],
-                     ref_static, verts, vcd)
-    orc.predict(lv, centers, 0.8, True)
-    dt = time.perf_counter() - t0
-    return {"value": len(frames) * M / dt, "unit": "lvec/s", "cores": 1, "kind": "port",
-            "sample": "leading %d frames of the same workload (%d landmark vectors), %.1f s"
-                      % (len(frames), len(frames) * M, dt)}
+    sidx, midx = np.where(gen.static_mask)[0], np.where(gen.mobile_mask)[0]
+
+    def one(cut):
+        wrapped = orc.wrap_points(host.cell, cut)
+        lv, _ = orc.fill(host.cell, wrapped, sidx, midx, ref_static, verts, vcd)
+        orc.predict(lv, centers, 0.8, True)
+        return len(cut)
+
+    n1 = min(len(frames), frames_per_core)
+    t0 = time.perf_counter()
+    one(frames[:n1])
+    dt1 = time.perf_counter() - t0
+    cuts = [frames[i * n1:(i + 1) * n1] for i in range(ncpu) if (i + 1) * n1 <= len(frames)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=len(cuts)) as ex:
+        nall = sum(ex.map(one, cuts))
+    dta = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": n1 * M / dt1, "unit": "lvec/s", "cores": 1, "kind": "port",
+            "sample": "leading %d frames of the same workload (%d landmark vectors), %.1f s" % (n1, n1 * M, dt1),
+            "all_cores": {"value": nall * M / dta, "cores": len(cuts),
+                          "sample": "%d cuts of %d frames in parallel threads, %.1f s" % (len(cuts), n1, dta)},
+            "cpu_model": model, "host_cores": ncpu}
 
 
 if __name__ == "__main__":

@@ -228,6 +228,23 @@ int sit_running_mode(sit_ctx *ctx, int64_t wleft, int64_t wright, int64_t thresh
 int sit_recenter(sit_ctx *ctx, double *arr, int64_t F, int64_t A, const double *masses,
                  const double *factors, const double *add3);
 
+/* ---- frame sharding across GPUs ------------------------------------ */
+
+/* The reference has no communication layer (it is single-process); these are the exchange steps a frame-sharded
+ * run() adds between one process per GPU: RCCL collectives over xGMI on the context's device and stream.  Buffers
+ * are HOST buffers (the payloads are small per-rank statistics: first-offender keys, counts, the D x D Gram matrix
+ * of landmark/cluster/mcl.py:55, the site-centre sums of util/PBCCalculator.pyx:127-134); staging is internal.
+ * librccl.so is loaded on the first call.                                                               */
+int sit_comm_unique_id(uint8_t *id128);                 /* ncclGetUniqueId: rank 0 makes it, every rank gets it */
+int sit_comm_create(sit_ctx *ctx, const uint8_t *id128, int rank, int world);
+int sit_comm_destroy(sit_ctx *ctx);
+/* In place on buf[count]; dtype 0 = float64, 1 = int64, 2 = uint64; op 0 = sum, 1 = min, 2 = max.       */
+int sit_comm_allreduce(sit_ctx *ctx, void *buf, int64_t count, int dtype, int op);
+/* recv[world * nbytes] = every rank's send[nbytes] in rank order.                                        */
+int sit_comm_allgather(sit_ctx *ctx, const void *send, void *recv, int64_t nbytes);
+int sit_comm_broadcast(sit_ctx *ctx, void *buf, int64_t nbytes, int root);
+int sit_comm_barrier(sit_ctx *ctx);
+
 /* ---- measurement --------------------------------------------------------------------- */
 
 /* Device time (ms, HIP events on the library's stream) of the last call of each stage:

@@ -75,6 +75,13 @@ SIGNATURES = {
     "sit_assign_last_known": (C.c_int, [_vp, i64, _ip, _ip, _ip, _i32p, _ip, _ip, _ip]),
     "sit_running_mode": (C.c_int, [_vp, i64, i64, i64, C.c_int, _ip]),
     "sit_recenter": (C.c_int, [_vp, _dp, i64, i64, _dp, _dp, _dp]),
+    "sit_comm_unique_id": (C.c_int, [_u8p]),
+    "sit_comm_create": (C.c_int, [_vp, _u8p, C.c_int, C.c_int]),
+    "sit_comm_destroy": (C.c_int, [_vp]),
+    "sit_comm_allreduce": (C.c_int, [_vp, C.c_void_p, i64, C.c_int, C.c_int]),
+    "sit_comm_allgather": (C.c_int, [_vp, C.c_void_p, C.c_void_p, i64]),
+    "sit_comm_broadcast": (C.c_int, [_vp, C.c_void_p, i64, C.c_int]),
+    "sit_comm_barrier": (C.c_int, [_vp]),
     "sit_timers": (C.c_int, [_vp, _dp, C.c_int]),
     "sit_info": (C.c_int, [_vp, _dp, C.c_int]),
     "sit_synchronize": (C.c_int, [_vp]),
@@ -98,6 +105,14 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def comm_unique_id():
+    """ncclGetUniqueId: 128 bytes that rank 0 makes and every rank of the job receives."""
+    uid = np.zeros(128, dtype=np.uint8)
+    if load().sit_comm_unique_id(uid.ctypes.data_as(_u8p)) != 0:
+        raise RuntimeError("sit_comm_unique_id failed (librccl.so not loadable?)")
+    return uid.tobytes()
 
 
 def device_count():
@@ -434,6 +449,38 @@ class HipContext(object):
         a3 = None if add3 is None else _f64(add3)
         self._check(self.lib.sit_recenter(self._h, _d(arr), arr.shape[0], arr.shape[1], _d(masses), _d(factors),
                                           None if a3 is None else _d(a3)))
+
+    # ---- RCCL exchange of the frame-sharded path (csrc/comm.hip) ----
+    def comm_create(self, unique_id, rank, world):
+        uid = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        assert uid.size == 128
+        self._check(self.lib.sit_comm_create(self._h, uid.ctypes.data_as(_u8p), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self.lib.sit_comm_destroy(self._h)
+
+    def comm_allreduce(self, arr, op="sum"):
+        """In place on a contiguous float64 / int64 / uint64 array."""
+        code = {np.dtype(np.float64): 0, np.dtype(np.int64): 1, np.dtype(np.uint64): 2}[arr.dtype]
+        assert arr.flags.c_contiguous
+        self._check(self.lib.sit_comm_allreduce(self._h, arr.ctypes.data_as(C.c_void_p), arr.size, code,
+                                                {"sum": 0, "min": 1, "max": 2}[op]))
+        return arr
+
+    def comm_allgather(self, send, world):
+        send = np.ascontiguousarray(send)
+        recv = np.empty((world,) + send.shape, dtype=send.dtype)
+        self._check(self.lib.sit_comm_allgather(self._h, send.ctypes.data_as(C.c_void_p), recv.ctypes.data_as(C.c_void_p),
+                                                send.nbytes))
+        return recv
+
+    def comm_broadcast(self, arr, root):
+        assert arr.flags.c_contiguous
+        self._check(self.lib.sit_comm_broadcast(self._h, arr.ctypes.data_as(C.c_void_p), arr.nbytes, int(root)))
+        return arr
+
+    def comm_barrier(self):
+        self._check(self.lib.sit_comm_barrier(self._h))
 
     def timers(self):
         t = np.zeros(8)

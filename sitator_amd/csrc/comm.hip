@@ -1,0 +1,170 @@
+// The exchange steps of the frame-sharded path on RCCL: one communicator per context
+// (= per GPU = per process), collectives on the context's stream, device staging in the context's scratch.
+// The payloads are small statistics (first-offender keys, counts, site-centre sums, the D x D Gram matrix); the
+// data path itself has no collective.  librccl.so is loaded on first use, so a single-GPU process never needs it.
+#include <dlfcn.h>
+#include <cstring>
+
+#include <rccl/rccl.h>
+
+#include "sit_internal.h"
+
+namespace {
+
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+RcclApi *rccl()
+{
+    static RcclApi api;
+    if (api.lib || !api.err.empty()) return &api;
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) break;
+    }
+    if (!api.lib) { api.err = std::string("cannot load librccl.so: ") + dlerror(); return &api; }
+#define SIT_SYM(field, sym)                                                                  \
+    do {                                                                                     \
+        *(void **)(&api.field) = dlsym(api.lib, sym);                                        \
+        if (!api.field) { api.err = std::string("librccl.so lacks ") + sym; return &api; }   \
+    } while (0)
+    SIT_SYM(GetUniqueId, "ncclGetUniqueId");
+    SIT_SYM(CommInitRank, "ncclCommInitRank");
+    SIT_SYM(CommDestroy, "ncclCommDestroy");
+    SIT_SYM(AllReduce, "ncclAllReduce");
+    SIT_SYM(AllGather, "ncclAllGather");
+    SIT_SYM(Broadcast, "ncclBroadcast");
+    SIT_SYM(GetErrorString, "ncclGetErrorString");
+#undef SIT_SYM
+    return &api;
+}
+
+#define RCCL_TRY(ctx, api, expr)                                                            \
+    do {                                                                                    \
+        ncclResult_t r__ = (expr);                                                          \
+        if (r__ != ncclSuccess) {                                                           \
+            (ctx)->msg = std::string(#expr) + ": " + (api)->GetErrorString(r__);            \
+            return SIT_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+int need_comm(sit_ctx *c, RcclApi **api)
+{
+    *api = rccl();
+    if (!(*api)->err.empty()) { c->msg = (*api)->err; return SIT_ERR_HIP; }
+    SIT_REQUIRE(c, c->comm != nullptr, "sit_comm_*: no communicator (call sit_comm_create first)");
+    return SIT_OK;
+}
+
+}  // namespace
+
+extern "C" int sit_comm_unique_id(uint8_t *id128)
+{
+    if (!id128) return SIT_ERR_INVALID;
+    RcclApi *api = rccl();
+    if (!api->err.empty()) return SIT_ERR_HIP;
+    ncclUniqueId id;
+    if (api->GetUniqueId(&id) != ncclSuccess) return SIT_ERR_HIP;
+    memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return SIT_OK;
+}
+
+extern "C" int sit_comm_create(sit_ctx *c, const uint8_t *id128, int rank, int world)
+{
+    if (!c || !id128) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, world >= 1 && rank >= 0 && rank < world, "sit_comm_create: bad rank / world size");
+    RcclApi *api = rccl();
+    if (!api->err.empty()) { c->msg = api->err; return SIT_ERR_HIP; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->comm) { (void)api->CommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(c, api, api->CommInitRank(&comm, world, id, rank));
+    c->comm = comm; c->comm_rank = rank; c->comm_size = world;
+    return SIT_OK;
+}
+
+extern "C" int sit_comm_destroy(sit_ctx *c)
+{
+    if (!c) return SIT_ERR_INVALID;
+    if (!c->comm) return SIT_OK;
+    RcclApi *api = rccl();
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (api->CommDestroy) (void)api->CommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr; c->comm_size = 1; c->comm_rank = 0;
+    return SIT_OK;
+}
+
+// dtype: 0 = float64, 1 = int64, 2 = uint64; op: 0 = sum, 1 = min, 2 = max.  In place on a host buffer.
+extern "C" int sit_comm_allreduce(sit_ctx *c, void *buf, int64_t count, int dtype, int op)
+{
+    if (!c || (!buf && count > 0)) return SIT_ERR_INVALID;
+    RcclApi *api;
+    int rc = need_comm(c, &api);
+    if (rc) return rc;
+    SIT_REQUIRE(c, dtype >= 0 && dtype <= 2 && op >= 0 && op <= 2 && count >= 0, "sit_comm_allreduce: bad dtype / op");
+    if (count == 0) return SIT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = ensure_scratch(c, count * 8))) return rc;
+    const ncclDataType_t dt = dtype == 0 ? ncclFloat64 : (dtype == 1 ? ncclInt64 : ncclUint64);
+    const ncclRedOp_t ro = op == 0 ? ncclSum : (op == 1 ? ncclMin : ncclMax);
+    HIP_TRY(c, hipMemcpyAsync(c->d_scratch, buf, (size_t)count * 8, hipMemcpyHostToDevice, c->stream));
+    RCCL_TRY(c, api, api->AllReduce(c->d_scratch, c->d_scratch, (size_t)count, dt, ro, (ncclComm_t)c->comm, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(buf, c->d_scratch, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+// recv[world * nbytes] = every rank's send[nbytes], in rank order
+extern "C" int sit_comm_allgather(sit_ctx *c, const void *send, void *recv, int64_t nbytes)
+{
+    if (!c || ((!send || !recv) && nbytes > 0)) return SIT_ERR_INVALID;
+    RcclApi *api;
+    int rc = need_comm(c, &api);
+    if (rc) return rc;
+    if (nbytes <= 0) return SIT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 total = nbytes * (c->comm_size + 1);
+    if ((rc = ensure_scratch(c, total))) return rc;
+    char *d_send = (char *)c->d_scratch, *d_recv = d_send + nbytes;
+    HIP_TRY(c, hipMemcpyAsync(d_send, send, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    RCCL_TRY(c, api, api->AllGather(d_send, d_recv, (size_t)nbytes, ncclUint8, (ncclComm_t)c->comm, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(recv, d_recv, (size_t)(nbytes * c->comm_size), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+extern "C" int sit_comm_broadcast(sit_ctx *c, void *buf, int64_t nbytes, int root)
+{
+    if (!c || (!buf && nbytes > 0)) return SIT_ERR_INVALID;
+    RcclApi *api;
+    int rc = need_comm(c, &api);
+    if (rc) return rc;
+    SIT_REQUIRE(c, root >= 0 && root < c->comm_size, "sit_comm_broadcast: bad root");
+    if (nbytes <= 0) return SIT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if ((rc = ensure_scratch(c, nbytes))) return rc;
+    if (c->comm_rank == root) HIP_TRY(c, hipMemcpyAsync(c->d_scratch, buf, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    RCCL_TRY(c, api, api->Broadcast(c->d_scratch, c->d_scratch, (size_t)nbytes, ncclUint8, root, (ncclComm_t)c->comm, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(buf, c->d_scratch, (size_t)nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+// every rank's stream work up to here is done, on every rank
+extern "C" int sit_comm_barrier(sit_ctx *c)
+{
+    int64_t one = 1;
+    return sit_comm_allreduce(c, &one, 1, 1, 0);
+}

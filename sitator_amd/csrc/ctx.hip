@@ -39,6 +39,7 @@ extern "C" int sit_create(const double *cell, const double *cell_inv, int device
 extern "C" void sit_destroy(sit_ctx *c)
 {
     if (!c) return;
+    (void)sit_comm_destroy(c);
     (void)hipSetDevice(c->device);
     void *ptrs[] = {c->d_ref_static, c->d_verts, c->d_vcd, c->d_hi2, c->d_bin_off, c->d_bin_list,
                     c->frames_owned ? c->d_frames : nullptr, c->d_static_idx, c->d_mobile_idx,

@@ -114,6 +114,10 @@ struct sit_ctx {
     bool fit_use_fast = true;         // SITATOR_FIT=serial disables it
     i64 ff_batches = 0, ff_serial_rows = 0, ff_rewalks = 0;
 
+    // RCCL communicator of the frame-sharded path (comm.hip); opaque here
+    void *comm = nullptr;
+    int comm_rank = 0, comm_size = 1;
+
     // scalars on device
     u64 *d_err = nullptr;             // packed first-offender key (atomicMin)
     u64 *d_scal = nullptr;            // [16] general purpose counters

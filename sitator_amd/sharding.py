@@ -3,10 +3,17 @@ order.  The data path has no collective; only small per-r
 are exchanged (first-offender keys, cluster counts, the D x D Gram matrix, site-centre sums), and
 the ordered ``fit_centers`` state is chained from rank to rank.
 
-``Comm`` is the tiny interface the host code needs; ``TorchComm`` implements it on
-``torch.distributed`` (backend ``nccl`` is RCCL over xGMI on ROCm, ``gloo`` for CPU tests).
-Torch is plumbing here: the product library itself (libsitator_hip.so) does not link it.
+``Comm`` is the tiny interface the host code needs.  ``RcclComm`` implements it on the library's own
+RCCL entry points (``sit_comm_*``, csrc/comm.hip: one communicator per context = per GPU, collectives over
+xGMI on the context's stream); the only thing exchanged outside RCCL is the 128-byte ncclUniqueId, over a
+TCP socket on the node (``MASTER_ADDR`` / ``MASTER_PORT`` + 1...).  ``TorchComm`` (``gloo``) is the CPU test
+double of the same interface: it runs here without a GPU (tests/test_sharded_gloo.py).
 """
+import os
+import socket
+import struct
+import time
+
 import numpy as np
 
 
@@ -26,6 +33,130 @@ class Comm(object):
 
     def barrier(self):
         pass
+
+
+_MAGIC = b"SITATOR-RCCL-ID1"
+
+
+def _serve_unique_id(uid, world, addr, port0, timeout):
+    """Rank 0: hand the id to the world - 1 other ranks.  Binds the first free port of port0 .. port0 + 15."""
+    srv = None
+    for port in range(port0, port0 + 16):
+        try:
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            s.bind((addr, port))
+            s.listen(world)
+            srv = s
+            break
+        except OSError:
+            s.close()
+    if srv is None:
+        raise RuntimeError("no free port in %d..%d for the RCCL id exchange" % (port0, port0 + 15))
+    srv.settimeout(timeout)
+    served = 0
+    try:
+        while served < world - 1:
+            conn, _ = srv.accept()
+            with conn:
+                conn.settimeout(10.0)
+                try:
+                    hello = conn.recv(len(_MAGIC) + 4)
+                except OSError:
+                    continue
+                if hello[:len(_MAGIC)] != _MAGIC:
+                    continue
+                conn.sendall(_MAGIC + uid)
+                served += 1
+    finally:
+        srv.close()
+
+
+def _fetch_unique_id(rank, addr, port0, timeout):
+    """Ranks > 0: ask rank 0 (which may not be listening yet, and on any of 16 ports) for the id."""
+    t_end = time.time() + timeout
+    while time.time() < t_end:
+        for port in range(port0, port0 + 16):
+            try:
+                with socket.create_connection((addr, port), timeout=2.0) as s:
+                    s.sendall(_MAGIC + struct.pack("<i", rank))
+                    buf = b""
+                    while len(buf) < len(_MAGIC) + 128:
+                        chunk = s.recv(len(_MAGIC) + 128 - len(buf))
+                        if not chunk:
+                            break
+                        buf += chunk
+                    if buf[:len(_MAGIC)] == _MAGIC and len(buf) == len(_MAGIC) + 128:
+                        return buf[len(_MAGIC):]
+            except OSError:
+                pass
+        time.sleep(0.05)
+    raise RuntimeError("rank %d: no RCCL unique id from rank 0 at %s:%d..%d within %.0f s" % (rank, addr, port0, port0 + 15, timeout))
+
+
+class RcclComm(Comm):
+    """RCCL over xGMI through the C-ABI of libsitator_hip.so; one instance per process / GPU / context."""
+
+    def __init__(self, device, rank, size, unique_id):
+        from . import _lib
+        # the communicator lives in a small context of its own (device, stream, staging buffer)
+        self.ctx = _lib.HipContext(np.eye(3), device=int(device))
+        self.rank = int(rank)
+        self.size = int(size)
+        self.ctx.comm_create(unique_id, self.rank, self.size)
+
+    @classmethod
+    def from_env(cls, device=None, timeout=300.0):
+        """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torchrun (or bench.py's own launcher) sets
+        them; ``device`` defaults to LOCAL_RANK."""
+        from . import _lib
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        rank = int(os.environ.get("RANK", "0"))
+        size = int(os.environ.get("WORLD_SIZE", "1"))
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port0 = int(os.environ.get("SITATOR_COMM_PORT", str(int(os.environ.get("MASTER_PORT", "29500")) + 1)))
+        if rank == 0:
+            uid = _lib.comm_unique_id()
+            if size > 1:
+                _serve_unique_id(uid, size, addr, port0, timeout)
+        else:
+            uid = _fetch_unique_id(rank, addr, port0, timeout)
+        return cls(device, rank, size, uid)
+
+    def allreduce_sum(self, arr):
+        arr = np.asarray(arr)
+        if arr.dtype not in (np.dtype(np.float64), np.dtype(np.int64), np.dtype(np.uint64)):
+            raise TypeError("allreduce_sum: float64 / int64 / uint64 only, got %s" % arr.dtype)
+        return self.ctx.comm_allreduce(np.ascontiguousarray(arr).copy(), "sum").reshape(arr.shape)
+
+    def allreduce_max(self, arr):
+        arr = np.asarray(arr)
+        return self.ctx.comm_allreduce(np.ascontiguousarray(arr).copy(), "max").reshape(arr.shape)
+
+    def allgather(self, arr):
+        return self.ctx.comm_allgather(np.asarray(arr), self.size)
+
+    def bcast(self, arr, root=0):
+        arr = np.asarray(arr)
+        # shapes may differ per rank (fit state): the shape goes first
+        hdr = np.zeros(6, dtype=np.int64)
+        if self.rank == root:
+            hdr[0] = arr.ndim
+            hdr[1:1 + arr.ndim] = arr.shape
+        self.ctx.comm_broadcast(hdr, root)
+        shape = tuple(int(x) for x in hdr[1:1 + int(hdr[0])])
+        out = np.ascontiguousarray(arr).copy() if self.rank == root else np.zeros(shape, dtype=arr.dtype)
+        if out.size:
+            self.ctx.comm_broadcast(out, root)
+        return out.reshape(shape)
+
+    def barrier(self):
+        self.ctx.comm_barrier()
+
+    def close(self):
+        self.ctx.comm_destroy()
+        self.ctx.close()
 
 
 class TorchComm(Comm):
