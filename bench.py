@@ -295,7 +295,8 @@ def cpu_baseline(host, gen, frames, ref, centers, M, frames_per_core, ncpu):
     t0 = time.perf_counter()
     one(frames[:n1])
     dt1 = time.perf_counter() - t0
-    cuts = [frames[i * n1:(i + 1) * n1] for i in range(ncpu) if (i + 1) * n1 <= len(frames)]
+    nthr = min(ncpu, 16)                      # the CPU share of a one-GPU box
+    cuts = [frames[i * n1:(i + 1) * n1] for i in range(nthr) if (i + 1) * n1 <= len(frames)]
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=len(cuts)) as ex:
         nall = sum(ex.map(one, cuts))
