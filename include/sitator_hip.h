@@ -157,6 +157,10 @@ int sit_get_assignments(sit_ctx *ctx, int64_t *labels, double *confs, int64_t *c
 
 /* G = X^T X (un-normalised, :55), seen[d] = count_nonzero(X[:, d]) (:54).                */
 int sit_gram(sit_ctx *ctx, double *G, int64_t *seen);
+/* The same sums as exact integers: entry q = (int128)(hi[q] << 64 | lo[q]) * 2^-80.  They are accumulated with
+ * integer atomics (order-independent, so bit-reproducible) and can be added up across ranks exactly; sit_gram
+ * rounds them to double.                                                                  */
+int sit_gram_limbs(sit_ctx *ctx, uint64_t *hi, uint64_t *lo, int64_t *seen);
 /* argmax_n |X[n] . c| with first-max tie-break (:80-83): index, the dot, and |X[n]|.     */
 int sit_best_match(sit_ctx *ctx, const double *c, int64_t *row, double *dot, double *norm);
 /* The same for G centres with DISJOINT supports in one pass over the rows (the mcl plugin's landmark groups
@@ -166,6 +170,8 @@ int sit_best_match_groups(sit_ctx *ctx, const int32_t *group_of_dim, const doubl
                           int64_t *rows, double *dots, double *norms);
 /* sums[k] = sum_n w_n X[n], wsum[k] = sum_n w_n, w_n = (label==k) * (conf or 1) (:117-122) */
 int sit_weighted_row_sums(sit_ctx *ctx, int weighted, int64_t K, double *sums, double *wsum);
+/* As sit_gram_limbs: [K*D + K] exact entries, the sums then the weights.                  */
+int sit_weighted_row_sums_limbs(sit_ctx *ctx, int weighted, int64_t K, uint64_t *hi, uint64_t *lo);
 
 /* ---- site centres (landmark/LandmarkAnalysis.py:276-287 + PBCCalculator.average) ------ */
 

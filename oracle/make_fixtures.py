@@ -93,8 +93,15 @@ def step1_reference(ref, inputs):
     return verts, vcd
 
 
-def save_case(name, inputs, runs):
-    """runs: list of (tag, kwargs, outputs)."""
+def frames_digest(frames):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(frames).tobytes()).hexdigest()
+
+
+def save_case(name, inputs, runs, lvec_head_frames=None):
+    """runs: list of (tag, kwargs, outputs).  Long cases do not store their frames: they store the recipe
+    (``synth.make_trajectory`` arguments) and a digest, and the tests regenerate and verify them; their landmark
+    vectors are kept for the leading ``lvec_head_frames`` frames only."""
     blob = {
         "cell": np.asarray(inputs["cell"], dtype=np.float64),
         "ref_positions": inputs["ref_positions"],
@@ -103,13 +110,21 @@ def save_case(name, inputs, runs):
         "centers": np.asarray(inputs["centers"]),
         "verts_np": inputs["verts_np"],
         "site_vert_dists": inputs["site_vert_dists"],
-        "frames": inputs["frames"],
         "wrapped_head": inputs["wrapped_head"],
         "tags": np.array([t for t, _, _ in runs]),
     }
+    if "recipe" in inputs:
+        blob["frames_recipe"] = np.array(json.dumps(inputs["recipe"]))
+        blob["frames_sha256"] = np.array(frames_digest(inputs["frames"]))
+        blob["frames_head"] = inputs["frames"][:2]
+    else:
+        blob["frames"] = inputs["frames"]
+    n_mobile = int(np.sum(inputs["mobile_mask"]))
     for tag, kwargs, out in runs:
         blob[tag + "/kwargs"] = np.array(json.dumps(kwargs))
         for k, v in out.items():
+            if k == "lvecs" and lvec_head_frames is not None:
+                v = np.asarray(v)[:lvec_head_frames * n_mobile]
             blob[tag + "/" + k] = np.asarray(v)
     path = os.path.join(GOLDEN, name + ".npz")
     np.savez_compressed(path, **blob)
@@ -122,6 +137,13 @@ def make_inputs(ref, host, M, F, seed, **gen_kw):
     inputs = dict(cell=host.cell, ref_positions=refpos, static_mask=sm, mobile_mask=mm,
                   centers=host.centers, vertices=host.vertices, frames=frames)
     finish_inputs(ref, inputs)
+    return inputs
+
+
+def make_long_inputs(ref, config, M, F, seed, **gen_kw):
+    """Inputs that the tests regenerate from the recipe instead of loading."""
+    inputs = make_inputs(ref, synth.config_host(config), M, F, seed, **gen_kw)
+    inputs["recipe"] = dict(config=config, n_mobile=M, n_frames=F, seed=seed, kw=gen_kw)
     return inputs
 
 
@@ -225,6 +247,37 @@ def pipeline_cases(ref):
     fr[:, midx[3]] = fr[:, midx[1]] + 0.05 * rng.standard_normal((80, 3))
     finish_inputs(ref, inp)
     go("err_insufficient_sites", inp, [("default", {})])   # reference: NameError (LandmarkAnalysis.py:13,267)
+
+
+def long_cases(ref, only=None):
+    """Cuts of the BASELINE configurations long enough to hold hops, transition samples (unassigned), clusters
+    founded late in the stream and jumps: C2 (400 frames, both plugins), C5 (300 frames: Markov clustering + jump
+    detection on the ragged FCC host), C3 / C4 (200 frames, dotprod)."""
+    import time
+    both = [("dotprod", {"clustering_algorithm": "dotprod"}), ("mcl", {"clustering_algorithm": "mcl"})]
+    plan = [
+        ("c2_long_ortho", ("C2", 64, 400, 2002), dict(p_hop=1.0 / 60), both, 40),
+        # C5 with the mcl plugin's defaults puts two ions on one site (MultipleOccupancyError: a golden too);
+        # max_mobile_per_site=2 lets the full pipeline (Markov clustering + jump detection) through
+        ("c5_long_fcc_ragged", ("C5", 160, 300, 2005), dict(p_hop=1.0 / 60), both + [
+            ("mcl_max2", {"clustering_algorithm": "mcl", "max_mobile_per_site": 2})], 30),
+        ("c3_long", ("C3", 448, 200, 2003), dict(p_hop=1.0 / 60), both[:1], 6),
+        ("c4_long", ("C4", 256, 200, 2004), dict(p_hop=1.0 / 60), both[:1], 6),
+    ]
+    for name, (cfg, M, F, seed), kw, variants, head in plan:
+        if only and name not in only:
+            continue
+        t0 = time.time()
+        inputs = make_long_inputs(ref, cfg, M, F, seed, **kw)
+        runs = []
+        for tag, kwargs in variants:
+            out = run_reference(ref, inputs, kwargs)
+            if "labels" in out:
+                print("   %s/%s: sites %d unassigned %.2f %% jumps %d (%.0f s)" % (
+                    name, tag, len(out["site_centers"]), 100.0 * np.mean(out["labels"] < 0), len(out["jumps"]),
+                    time.time() - t0), flush=True)
+            runs.append((tag, kwargs, out))
+        save_case(name, inputs, runs, lvec_head_frames=head)
 
 
 def pbc_cases(ref):
@@ -456,9 +509,13 @@ def main():
     if "--merge-only" in sys.argv:
         merge_cases(ref)
         return 0
+    if "--long-only" in sys.argv:
+        long_cases(ref, only=[a for a in sys.argv[1:] if not a.startswith("--")] or None)
+        return 0
     pbc_cases(ref)
     dotprod_cases(ref)
     pipeline_cases(ref)
+    long_cases(ref)
     next_tier_cases(ref)
     merge_cases(ref)
     return 0

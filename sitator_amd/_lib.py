@@ -62,6 +62,8 @@ SIGNATURES = {
     "sit_predict": (C.c_int, [_vp, C.c_double, _ip, _dp, _ip]),
     "sit_get_assignments": (C.c_int, [_vp, _ip, _dp, _ip]),
     "sit_gram": (C.c_int, [_vp, _dp, _ip]),
+    "sit_gram_limbs": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _ip]),
+    "sit_weighted_row_sums_limbs": (C.c_int, [_vp, C.c_int, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "sit_best_match": (C.c_int, [_vp, _dp, _ip, _dp, _dp]),
     "sit_best_match_groups": (C.c_int, [_vp, C.POINTER(C.c_int32), _dp, i64, _ip, _dp, _dp]),
     "sit_weighted_row_sums": (C.c_int, [_vp, C.c_int, i64, _dp, _dp]),
@@ -332,6 +334,24 @@ class HipContext(object):
         seen = np.empty(self.D, dtype=np.int64)
         self._check(self.lib.sit_gram(self._h, _d(G), _i(seen)))
         return G, seen
+
+    def gram_limbs(self):
+        """The Gram matrix as exact integers (hi, lo) in units of 2^-80 (see ``exact_sum_across``), and ``seen``."""
+        hi = np.empty((self.D, self.D), dtype=np.uint64)
+        lo = np.empty((self.D, self.D), dtype=np.uint64)
+        seen = np.empty(self.D, dtype=np.int64)
+        u64p = C.POINTER(C.c_uint64)
+        self._check(self.lib.sit_gram_limbs(self._h, hi.ctypes.data_as(u64p), lo.ctypes.data_as(u64p), _i(seen)))
+        return hi, lo, seen
+
+    def weighted_row_sums_limbs(self, K, weighted=True):
+        n = K * self.D + K
+        hi = np.empty(n, dtype=np.uint64)
+        lo = np.empty(n, dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        self._check(self.lib.sit_weighted_row_sums_limbs(self._h, int(weighted), int(K), hi.ctypes.data_as(u64p),
+                                                         lo.ctypes.data_as(u64p)))
+        return hi, lo
 
     def best_match(self, c):
         c = _f64(c)

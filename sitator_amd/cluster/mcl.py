@@ -66,10 +66,17 @@ def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, ver
     comm = X.comm
     n_lmk = X.shape[1]
 
-    gram, seen_ntimes = X.ctx.gram()                                   # :54-55
     n_rows = X.shape[0]
+    if comm.size > 1 and hasattr(X.ctx, "gram_limbs"):
+        # exact integer accumulators add up across ranks without rounding: same bits for any number of GPUs
+        from ..sharding import exact_sum_across
+        hi, lo, seen_ntimes = X.ctx.gram_limbs()                       # :54-55
+        gram = exact_sum_across(comm, hi, lo)
+    else:
+        gram, seen_ntimes = X.ctx.gram()                               # :54-55
+        if comm.size > 1:
+            gram = comm.allreduce_sum(gram)
     if comm.size > 1:
-        gram = comm.allreduce_sum(gram)
         seen_ntimes = comm.allreduce_sum(seen_ntimes)
         n_rows = int(comm.allreduce_sum(np.array([n_rows], dtype=np.int64))[0])
     cov = gram / n_rows
@@ -116,10 +123,17 @@ def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, ver
 
     # representative landmark vector of each site: confidence-weighted mean of its rows (:114-122)
     weighted = params.get("weighted_representative_landmarks", True)
-    sums, wsum = X.ctx.weighted_row_sums(len(groups), weighted=weighted)
-    if comm.size > 1:
-        sums = comm.allreduce_sum(sums)
-        wsum = comm.allreduce_sum(wsum)
+    if comm.size > 1 and hasattr(X.ctx, "weighted_row_sums_limbs"):
+        from ..sharding import exact_sum_across
+        K = len(groups)
+        hi, lo = X.ctx.weighted_row_sums_limbs(K, weighted=weighted)
+        tot = exact_sum_across(comm, hi, lo)
+        sums, wsum = tot[:K * n_lmk].reshape(K, n_lmk), tot[K * n_lmk:]
+    else:
+        sums, wsum = X.ctx.weighted_row_sums(len(groups), weighted=weighted)
+        if comm.size > 1:
+            sums = comm.allreduce_sum(sums)
+            wsum = comm.allreduce_sum(wsum)
     reps = sums / wsum[:, np.newaxis]
 
     return {

@@ -581,7 +581,8 @@ extern "C" int sit_fit_push_dense_rows(sit_ctx *c, const double *rows, const i64
 
 // ---- mcl plugin reductions (landmark/cluster/mcl.py:53-59, :80-83, :114-122) ----------------
 
-__global__ void k_gram(const i32 *nnz, const i32 *idx, const double *val, i64 N, i64 D, double *G, u64 *seen)
+// G = X^T X accumulated exactly (exact_add, sit_internal.h): the same bits every run
+__global__ void k_gram(const i32 *nnz, const i32 *idx, const double *val, i64 N, i64 D, u64 *Ghi, u64 *Glo, u64 *seen)
 {
     const i64 row = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= N) return;
@@ -590,32 +591,55 @@ __global__ void k_gram(const i32 *nnz, const i32 *idx, const double *val, i64 N,
         const i32 d1 = idx[(i64)e1 * N + row];
         const double v1 = val[(i64)e1 * N + row];
         atomicAdd(&seen[d1], 1ull);
-        for (int e2 = 0; e2 < n; e2++)
-            unsafeAtomicAdd(&G[(i64)d1 * D + idx[(i64)e2 * N + row]], v1 * val[(i64)e2 * N + row]);
+        for (int e2 = 0; e2 < n; e2++) {
+            const i64 q = (i64)d1 * D + idx[(i64)e2 * N + row];
+            exact_add(&Ghi[q], &Glo[q], v1 * val[(i64)e2 * N + row]);
+        }
     }
+}
+
+__global__ void k_limbs_to_double(const u64 *hi, const u64 *lo, i64 n, double *out)
+{
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) out[q] = exact_value(hi[q], lo[q]);
+}
+
+// limbs: hi[D*D], lo[D*D] (may be null: then G[D*D] doubles are produced instead)
+static int gram_impl(sit_ctx *c, double *G, u64 *hi, u64 *lo, i64 *seen)
+{
+    SIT_REQUIRE(c, c->rows_valid, "sit_gram: no landmark rows on the device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 D = c->D, DD = D * D;
+    int rc = ensure_scratch(c, DD * 24 + D * 8);
+    if (rc) return rc;
+    u64 *dhi = (u64 *)c->d_scratch, *dlo = dhi + DD, *ds = dlo + DD;
+    double *dG = (double *)(ds + D);
+    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(DD * 16 + D * 8), c->stream));
+    StageTimer t(c, T_GRAM);
+    if (c->N > 0) {
+        k_gram<<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dhi, dlo, ds);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (G) k_limbs_to_double<<<dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, c->stream>>>(dhi, dlo, DD, dG);
+    t.stop();
+    if (G) HIP_TRY(c, hipMemcpyAsync(G, dG, (size_t)DD * 8, hipMemcpyDeviceToHost, c->stream));
+    if (hi) HIP_TRY(c, hipMemcpyAsync(hi, dhi, (size_t)DD * 8, hipMemcpyDeviceToHost, c->stream));
+    if (lo) HIP_TRY(c, hipMemcpyAsync(lo, dlo, (size_t)DD * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(seen, ds, (size_t)D * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
 }
 
 extern "C" int sit_gram(sit_ctx *c, double *G, i64 *seen)
 {
     if (!c || !G || !seen) return SIT_ERR_INVALID;
-    SIT_REQUIRE(c, c->rows_valid, "sit_gram: no landmark rows on the device");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const i64 D = c->D;
-    int rc = ensure_scratch(c, D * D * 8 + D * 8);
-    if (rc) return rc;
-    double *dG = (double *)c->d_scratch;
-    u64 *ds = (u64 *)(dG + D * D);
-    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(D * D * 8 + D * 8), c->stream));
-    StageTimer t(c, T_GRAM);
-    if (c->N > 0) {
-        k_gram<<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dG, ds);
-        HIP_TRY(c, hipGetLastError());
-    }
-    t.stop();
-    HIP_TRY(c, hipMemcpyAsync(G, dG, (size_t)(D * D) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(seen, ds, (size_t)D * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return SIT_OK;
+    return gram_impl(c, G, nullptr, nullptr, seen);
+}
+
+extern "C" int sit_gram_limbs(sit_ctx *c, uint64_t *hi, uint64_t *lo, i64 *seen)
+{
+    if (!c || !hi || !lo || !seen) return SIT_ERR_INVALID;
+    return gram_impl(c, nullptr, (u64 *)hi, (u64 *)lo, seen);
 }
 
 // per block: argmax over its rows of |X[n] . cvec| with numpy's rules
@@ -787,39 +811,61 @@ extern "C" int sit_best_match_groups(sit_ctx *c, const int32_t *group_of_dim, co
     return SIT_OK;
 }
 
+// sums[k] += w X[n], wsum[k] += w, accumulated exactly ([K*D + K] limb pairs: the sums, then the weights)
 __global__ void k_weighted_row_sums(const i32 *nnz, const i32 *idx, const double *val, const i64 *labels,
-                                    const double *confs, i64 N, i64 D, i64 K, int weighted, double *sums, double *wsum)
+                                    const double *confs, i64 N, i64 D, i64 K, int weighted, u64 *hi, u64 *lo)
 {
     const i64 row = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= N) return;
     const i64 l = labels[row];
     if (l < 0 || l >= K) return;
     const double w = weighted ? confs[row] : 1.0;
-    unsafeAtomicAdd(&wsum[l], w);
+    exact_add(&hi[K * D + l], &lo[K * D + l], w);
     const int n = nnz[row];
-    for (int e = 0; e < n; e++)
-        unsafeAtomicAdd(&sums[l * D + idx[(i64)e * N + row]], w * val[(i64)e * N + row]);
+    for (int e = 0; e < n; e++) {
+        const i64 q = l * D + idx[(i64)e * N + row];
+        exact_add(&hi[q], &lo[q], w * val[(i64)e * N + row]);
+    }
+}
+
+// out: [K*D + K] doubles (sums then weights), or the raw limbs
+static int weighted_row_sums_impl(sit_ctx *c, int weighted, i64 K, double *sums, double *wsum, u64 *hi, u64 *lo)
+{
+    SIT_REQUIRE(c, c->rows_valid && c->assign_valid && K > 0, "sit_weighted_row_sums: rows and assignments needed");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 D = c->D, n = K * D + K;
+    int rc = ensure_scratch(c, n * 24);
+    if (rc) return rc;
+    u64 *dhi = (u64 *)c->d_scratch, *dlo = dhi + n;
+    double *dout = (double *)(dlo + n);
+    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(n * 16), c->stream));
+    if (c->N > 0) {
+        k_weighted_row_sums<<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(
+            c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs, c->N, D, K, weighted, dhi, dlo);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (sums) {
+        k_limbs_to_double<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(dhi, dlo, n, dout);
+        HIP_TRY(c, hipMemcpyAsync(sums, dout, (size_t)(K * D) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(wsum, dout + K * D, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(hi, dhi, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(lo, dlo, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
 }
 
 extern "C" int sit_weighted_row_sums(sit_ctx *c, int weighted, i64 K, double *sums, double *wsum)
 {
     if (!c || !sums || !wsum) return SIT_ERR_INVALID;
-    SIT_REQUIRE(c, c->rows_valid && c->assign_valid && K > 0, "sit_weighted_row_sums: rows and assignments needed");
-    HIP_TRY(c, hipSetDevice(c->device));
-    const i64 D = c->D;
-    int rc = ensure_scratch(c, (K * D + K) * 8);
-    if (rc) return rc;
-    double *ds = (double *)c->d_scratch, *dw = ds + K * D;
-    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)((K * D + K) * 8), c->stream));
-    if (c->N > 0) {
-        k_weighted_row_sums<<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(
-            c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs, c->N, D, K, weighted, ds, dw);
-        HIP_TRY(c, hipGetLastError());
-    }
-    HIP_TRY(c, hipMemcpyAsync(sums, ds, (size_t)(K * D) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(wsum, dw, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return SIT_OK;
+    return weighted_row_sums_impl(c, weighted, K, sums, wsum, nullptr, nullptr);
+}
+
+extern "C" int sit_weighted_row_sums_limbs(sit_ctx *c, int weighted, i64 K, uint64_t *hi, uint64_t *lo)
+{
+    if (!c || !hi || !lo) return SIT_ERR_INVALID;
+    return weighted_row_sums_impl(c, weighted, K, nullptr, nullptr, (u64 *)hi, (u64 *)lo);
 }
 
 // ---- caller-provided dense rows (stand-alone DotProdClassifier) ---------------------------------

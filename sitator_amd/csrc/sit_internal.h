@@ -247,6 +247,41 @@ __device__ __forceinline__ Best best_of(double v, i64 i)
 }
 
 
+// ---- exact, order-independent accumulation of doubles ------------------------------------------------------
+// A sum of doubles taken with floating-point atomics depends on the order the hardware happens to serve them.
+// Here a value is converted to 128-bit two's-complement fixed point (units of 2^-80; exact for |v| >= 2^-27,
+// truncated below 2^-80) and added to the pair (hi, lo) with integer atomics: the low word's add returns the old
+// value, so exactly the adder that wraps it carries one into the high word.  Integer addition commutes: the
+// result does not depend on scheduling, on the number of workgroups, or (added up across ranks) on the number of
+// GPUs.  Range |sum| < 2^47.
+__device__ __forceinline__ void exact_add(u64 *hi, u64 *lo, double v)
+{
+    if (v == 0.0 || !(v == v)) return;
+    int e;
+    const double m = frexp(fabs(v), &e);                  // |v| = m 2^e, m in [0.5, 1)
+    const u64 mant = (u64)ldexp(m, 53);                   // 53-bit integer
+    const int sh = e + 27;                                // |v| 2^80 = mant 2^sh
+    u64 xlo = 0, xhi = 0;
+    if (sh >= 64) xhi = sh < 128 ? mant << (sh - 64) : 0;
+    else if (sh > 0) { xlo = mant << sh; xhi = mant >> (64 - sh); }
+    else if (sh == 0) xlo = mant;
+    else if (sh > -64) xlo = mant >> (-sh);
+    if (v < 0.0) {                                        // two's complement of (xhi, xlo)
+        xhi = ~xhi + (xlo == 0 ? 1ull : 0ull);
+        xlo = ~xlo + 1ull;
+    }
+    u64 carry = 0;
+    if (xlo) { const u64 old = atomicAdd(lo, xlo); carry = (old + xlo) < old ? 1ull : 0ull; }
+    if (xhi + carry) atomicAdd(hi, xhi + carry);
+}
+
+// (hi, lo) of exact_add as a double: two roundings (the low word's conversion and the final sum), both deterministic
+__host__ __device__ inline double exact_value(u64 hi, u64 lo)
+{
+    const double h = ldexp((double)(long long)hi, -16);   // signed high word
+    return h + ldexp((double)lo, -80);
+}
+
 // host-side pieces implemented in other translation units
 int sit_predict_internal(sit_ctx *c, double threshold);
 int sit_label_counts(sit_ctx *c);

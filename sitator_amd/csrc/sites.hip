@@ -30,6 +30,45 @@ __global__ void k_site_first(const i64 *labels, const double *confs, i64 N, i64 
     if ((u64)__double_as_longlong(w) == wmax_bits[l]) atomicMin(&first_row[l], (u64)(row + row_offset));
 }
 
+// The same two passes with a per-workgroup table in LDS (sites <= 8192): a workgroup reduces its rows there (LDS
+// atomics, low contention: the ions of a frame sit on different sites) and merges with one global atomic per
+// touched site.  6.4e6 global atomics on 480 addresses became ~2e5.
+#define SITE_ROWS_PER_WG 16384
+__global__ __launch_bounds__(256) void k_site_wmax_lds(const i64 *labels, const double *confs, i64 N, i64 K, int weighted, u64 *wmax_bits)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64 *tab = (u64 *)smem;
+    for (i64 q = threadIdx.x; q < K; q += 256) tab[q] = 0ull;
+    __syncthreads();
+    const i64 r0 = (i64)blockIdx.x * SITE_ROWS_PER_WG, r1 = r0 + SITE_ROWS_PER_WG < N ? r0 + SITE_ROWS_PER_WG : N;
+    for (i64 row = r0 + threadIdx.x; row < r1; row += 256) {
+        const i64 l = labels[row];
+        if (l < 0 || l >= K) continue;
+        const double w = weighted ? confs[row] : 1.0;
+        atomicMax(&tab[l], (u64)__double_as_longlong(w) + 1ull);           // + 1: a touched site is never 0
+    }
+    __syncthreads();
+    for (i64 q = threadIdx.x; q < K; q += 256) if (tab[q]) atomicMax(&wmax_bits[q], tab[q] - 1ull);
+}
+
+__global__ __launch_bounds__(256) void k_site_first_lds(const i64 *labels, const double *confs, i64 N, i64 K, int weighted,
+                                                        const u64 *wmax_bits, u64 *first_row, i64 row_offset)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64 *tab = (u64 *)smem;
+    for (i64 q = threadIdx.x; q < K; q += 256) tab[q] = SIT_NO_ERROR_KEY;
+    __syncthreads();
+    const i64 r0 = (i64)blockIdx.x * SITE_ROWS_PER_WG, r1 = r0 + SITE_ROWS_PER_WG < N ? r0 + SITE_ROWS_PER_WG : N;
+    for (i64 row = r0 + threadIdx.x; row < r1; row += 256) {
+        const i64 l = labels[row];
+        if (l < 0 || l >= K) continue;
+        const double w = weighted ? confs[row] : 1.0;
+        if ((u64)__double_as_longlong(w) == wmax_bits[l]) atomicMin(&tab[l], (u64)(row + row_offset));
+    }
+    __syncthreads();
+    for (i64 q = threadIdx.x; q < K; q += 256) if (tab[q] != SIT_NO_ERROR_KEY) atomicMin(&first_row[q], tab[q]);
+}
+
 // wrapped (Step 0) position of the mobile ion of a row
 __device__ __forceinline__ void ion_position(const Pbc &P, const double *frames, const i32 *mobile_idx,
                                              i64 A, i64 M, i64 row, double &x, double &y, double &z)
@@ -55,10 +94,11 @@ __global__ void k_site_anchor_pts(Pbc P, const double *frames, const i32 *mobile
 }
 
 // Pass 2: per site (sum w, sum w*q) with q = wrap(p + (centroid - anchor)) (:127-134), in a FIXED summation
-// order (run-to-run reproducible, no floating-point atomics): a workgroup owns a contiguous row range; rows are
-// staged 256 at a time in LDS and thread t then adds, in row order, the staged rows of the sites it owns
-// (site % 256 == t) into its LDS accumulators; the per-workgroup partials are summed in workgroup order by
-// k_site_sums_final.
+// order (run-to-run reproducible, no floating-point atomics): a workgroup owns a contiguous row range and keeps its
+// partial sums in LDS; rows are taken 256 at a time (one per thread) and added in ROW ORDER: in every round each
+// pending thread bids for its site with its thread number (LDS atomicMin), the lowest bidder of a site adds its row
+// and withdraws.  The rounds of a chunk are the largest number of its rows on one site (the ions of a frame sit on
+// different sites: a handful).  The per-workgroup partials are summed in workgroup order by k_site_sums_final.
 __global__ __launch_bounds__(256) void k_site_sums(Pbc P, const double *frames, const i32 *mobile_idx, i64 A,
                                                    i64 M, const i64 *labels, const double *confs, i64 N, i64 K,
                                                    int weighted, const double *anchors, double *partials,
@@ -66,14 +106,14 @@ __global__ __launch_bounds__(256) void k_site_sums(Pbc P, const double *frames, 
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *part = (double *)smem;                 // [K,4]
-    double *stage = part + 4 * K;                  // [256,4]
-    int *slab = (int *)(stage + 4 * 256);          // [256]
+    unsigned *bid = (unsigned *)(part + 4 * K);    // [K]
     const int t = threadIdx.x;
     for (i64 q = t; q < K * 4; q += 256) part[q] = 0.0;
+    for (i64 q = t; q < K; q += 256) bid[q] = 0xffffffffu;
+    __syncthreads();
     const i64 r0 = (i64)blockIdx.x * rows_per_block;
     const i64 r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
     for (i64 base = r0; base < r1; base += 256) {
-        __syncthreads();
         const i64 row = base + t;
         int l = -1;
         double w = 0.0, x = 0.0, y = 0.0, z = 0.0;
@@ -87,14 +127,14 @@ __global__ __launch_bounds__(256) void k_site_sums(Pbc P, const double *frames, 
                 wrap3(P, x, y, z);
             }
         }
-        slab[t] = l;
-        stage[4 * t] = w; stage[4 * t + 1] = w * x; stage[4 * t + 2] = w * y; stage[4 * t + 3] = w * z;
-        __syncthreads();
-        for (int i = 0; i < 256; i++) {
-            const int li = slab[i];
-            if (li >= 0 && (li & 255) == t) {
-                part[4 * li] += stage[4 * i]; part[4 * li + 1] += stage[4 * i + 1];
-                part[4 * li + 2] += stage[4 * i + 2]; part[4 * li + 3] += stage[4 * i + 3];
+        bool pending = l >= 0;
+        while (__syncthreads_or(pending ? 1 : 0)) {
+            if (pending) atomicMin(&bid[l], (unsigned)t);
+            __syncthreads();
+            if (pending && bid[l] == (unsigned)t) {
+                part[4 * l] += w; part[4 * l + 1] += w * x; part[4 * l + 2] += w * y; part[4 * l + 3] += w * z;
+                bid[l] = 0xffffffffu;
+                pending = false;
             }
         }
     }
@@ -125,7 +165,12 @@ extern "C" int sit_site_anchors(sit_ctx *c, int weighted, i64 K, double *wmax, i
     HIP_TRY(c, hipMemsetAsync(dw, 0, (size_t)K * 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(df, 0xFF, (size_t)K * 8, c->stream));
     StageTimer t(c, T_CENTERS);
-    if (c->N > 0) {
+    if (c->N > 0 && K <= 8192) {
+        const unsigned grid = (unsigned)((c->N + SITE_ROWS_PER_WG - 1) / SITE_ROWS_PER_WG);
+        const size_t lds = (size_t)K * 8;
+        k_site_wmax_lds<<<dim3(grid), dim3(256), lds, c->stream>>>(c->d_labels, c->d_confs, c->N, K, weighted, dw);
+        k_site_first_lds<<<dim3(grid), dim3(256), lds, c->stream>>>(c->d_labels, c->d_confs, c->N, K, weighted, dw, df, row_offset);
+    } else if (c->N > 0) {
         const unsigned grid = (unsigned)((c->N + 255) / 256);
         k_site_wmax<<<dim3(grid), dim3(256), 0, c->stream>>>(c->d_labels, c->d_confs, c->N, K, weighted, dw);
         k_site_first<<<dim3(grid), dim3(256), 0, c->stream>>>(c->d_labels, c->d_confs, c->N, K, weighted, dw, df, row_offset);
@@ -147,7 +192,7 @@ extern "C" int sit_site_sums(sit_ctx *c, int weighted, i64 K, const double *anch
 {
     if (!c || !anchor_pts || !sums) return SIT_ERR_INVALID;
     SIT_REQUIRE(c, c->assign_valid && c->d_frames && K > 0, "sit_site_sums: assignments and frames needed");
-    SIT_REQUIRE(c, K * 32 + 256 * 36 <= 150 * 1024, "sit_site_sums: too many sites for the LDS-private partial sums");
+    SIT_REQUIRE(c, K * 36 <= 150 * 1024, "sit_site_sums: too many sites for the LDS-private partial sums");
     HIP_TRY(c, hipSetDevice(c->device));
     // at most 1024 workgroups, each a contiguous row range (a multiple of 256 rows)
     i64 rpb = (c->N + 1023) / 1024;
@@ -161,7 +206,7 @@ extern "C" int sit_site_sums(sit_ctx *c, int weighted, i64 K, const double *anch
     HIP_TRY(c, hipMemsetAsync(ds, 0, (size_t)K * 32, c->stream));
     StageTimer t(c, T_CENTERS);
     if (c->N > 0) {
-        const size_t lds = (size_t)K * 32 + 256 * 36;
+        const size_t lds = (size_t)K * 36;
         HIP_TRY(c, hipFuncSetAttribute((const void *)k_site_sums, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_site_sums<<<dim3((unsigned)nblocks), dim3(256), lds, c->stream>>>(
             c->pbc, c->d_frames, c->d_mobile_idx, c->A, c->M, c->d_labels, c->d_confs, c->N, K, weighted, da, dp, rpb);

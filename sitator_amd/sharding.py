@@ -212,6 +212,26 @@ class TorchComm(Comm):
         self._dist.barrier()
 
 
+def exact_sum_across(comm, hi, lo):
+    """Sum over the ranks of exact accumulators (``sit_gram_limbs`` / ``sit_weighted_row_sums_limbs``: two's-complement
+    128-bit integers hi * 2^64 + lo in units of 2^-80), rounded to float64 the way the library rounds a single rank's
+    (csrc/sit_internal.h ``exact_value``).  Integer addition commutes, so the result has the same bits for any number
+    of ranks; the low word travels as two 32-bit halves so that its sum cannot wrap."""
+    hi = np.ascontiguousarray(hi, dtype=np.uint64)
+    lo = np.ascontiguousarray(lo, dtype=np.uint64)
+    if comm is not None and comm.size > 1:
+        m32 = np.uint64(0xffffffff)
+        s_hi = comm.allreduce_sum(hi)                              # wraps like two's complement: intended
+        s_l0 = comm.allreduce_sum(lo & m32)
+        s_l1 = comm.allreduce_sum(lo >> np.uint64(32))
+        # lo' = (s_l0 + (s_l1 << 32)) mod 2^64, carries into hi
+        mid = s_l1 + (s_l0 >> np.uint64(32))
+        lo = (s_l0 & m32) | ((mid & m32) << np.uint64(32))
+        with np.errstate(over="ignore"):
+            hi = s_hi + (mid >> np.uint64(32))
+    return np.ldexp(hi.view(np.int64).astype(np.float64), -16) + np.ldexp(lo.astype(np.float64), -80)
+
+
 def shard_frames(n_frames, rank, size):
     """Contiguous block [lo, hi) of frames owned by ``rank`` (rank order = frame order)."""
     per = (n_frames + size - 1) // size

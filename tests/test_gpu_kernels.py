@@ -426,3 +426,50 @@ def test_big_frames_pick_eight_waves_and_match_oracle(oracle):
     got = ctx.rows_dense()
     assert np.array_equal(got != 0, exp != 0)
     np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
+
+
+def test_mcl_reductions_are_exact_and_reproducible(oracle):
+    """The Gram matrix and the weighted row sums of the mcl plugin are accumulated as exact integers: two runs give the
+    same bits, the limbs add up across frame shards to the bits of the whole, and the values agree with numpy."""
+    from sitator_amd import synth, sharding
+    host = synth.config_host("C1b")
+    ctx, frames, sm, mm, ref = _setup(host, 4, 900, seed=52)
+    assert ctx.fill()[0] == 0
+    G1, seen1 = ctx.gram()
+    G2, seen2 = ctx.gram()
+    assert np.array_equal(G1, G2) and np.array_equal(seen1, seen2)
+    X = ctx.rows_dense()
+    np.testing.assert_allclose(G1, X.T @ X, rtol=1e-13, atol=1e-300)
+    assert np.array_equal(seen1, np.count_nonzero(X, axis=0))
+    hi, lo, _ = ctx.gram_limbs()
+    assert np.array_equal(sharding.exact_sum_across(None, hi, lo), G1)
+    # two shards: limbs of the parts add up to the bits of the whole (the carry of the low words included)
+    parts = []
+    for lo_f, hi_f in ((0, 400), (400, 900)):
+        c2, *_ = _setup(host, 4, 900, seed=52)
+        c2.set_frames(frames[lo_f:hi_f], np.where(sm)[0], np.where(mm)[0])
+        assert c2.fill()[0] == 0
+        parts.append(c2.gram_limbs())
+
+    # emulate the all-reduce of exact_sum_across on the two parts
+    m32 = np.uint64(0xffffffff)
+    with np.errstate(over="ignore"):
+        s_hi = parts[0][0] + parts[1][0]
+    s_l0 = (parts[0][1] & m32) + (parts[1][1] & m32)
+    s_l1 = (parts[0][1] >> np.uint64(32)) + (parts[1][1] >> np.uint64(32))
+    mid = s_l1 + (s_l0 >> np.uint64(32))
+    lo2 = (s_l0 & m32) | ((mid & m32) << np.uint64(32))
+    with np.errstate(over="ignore"):
+        hi2 = s_hi + (mid >> np.uint64(32))
+    assert np.array_equal(hi2, hi) and np.array_equal(lo2, lo)
+    # weighted row sums
+    cen = oracle.fit_centers(X, 0.45)
+    ctx.set_centers(cen / np.linalg.norm(cen, axis=1)[:, None], True)
+    lab, conf, cnt = ctx.predict(0.8)
+    s1, w1 = ctx.weighted_row_sums(len(cen))
+    s2, w2 = ctx.weighted_row_sums(len(cen))
+    assert np.array_equal(s1, s2) and np.array_equal(w1, w2)
+    for k in range(len(cen)):
+        m = lab == k
+        np.testing.assert_allclose(w1[k], conf[m].sum(), rtol=1e-13)
+        np.testing.assert_allclose(s1[k], (conf[m][:, None] * X[m]).sum(axis=0), rtol=1e-12, atol=1e-300)

@@ -127,6 +127,40 @@ def test_operator_against_reference_golden(name, tag):
         la.run(make_sn(c), c.frames)          # one-shot, as the reference
 
 
+@pytest.mark.parametrize("name,tag", G.long_runs())
+def test_long_cut_against_reference_golden(name, tag):
+    """Cuts of C2 / C3 / C4 / C5 run through the TRUE reference (oracle/make_fixtures.py long_cases): hundreds of frames
+    with hops, so the stream holds transition samples that stay unassigned, clusters founded late, and jumps.  C5 runs
+    the Markov-clustering plugin and the jump detection on the ragged FCC host (BASELINE configs[4])."""
+    from sitator_amd import LandmarkAnalysis, errors
+    c = case(name)
+    exp = c.out(tag)
+    la = LandmarkAnalysis(verbose=False, **c.kwargs(tag))
+    if "error_type" in exp:                                # C5 / mcl defaults: two ions end up on one merged site
+        assert str(exp["error_type"]) == "MultipleOccupancyError"
+        with pytest.raises(errors.MultipleOccupancyError) as ei:
+            la.run(make_sn(c), c.frames)
+        assert ei.value.frame == int(exp["error_frame"]) and ei.value.site == int(exp["error_site"])
+        assert list(ei.value.mobile_particles) == list(exp["error_mobile_particles"])
+        return
+    assert np.mean(exp["labels"] < 0) > 0 and len(exp["jumps"]) >= 1, "the fixture must bite"
+    st = la.run(make_sn(c), c.frames)
+    assert np.array_equal(st.traj, exp["labels"]), "site indices must be bit-identical"
+    assert np.array_equal(np.bincount(st.traj[st.traj >= 0], minlength=st.site_network.n_sites), exp["counts"])
+    m = exp["labels"] >= 0
+    np.testing.assert_allclose(st.confidences[m], exp["confs"][m], rtol=RTOL)
+    np.testing.assert_allclose(st.site_network.centers, exp["site_centers"], rtol=RTOL, atol=1e-8)
+    assert la.n_all_zero_lvecs == int(exp["n_all_zero_lvecs"])
+    assert la.n_multiple_assignments == int(exp["n_multiple_assignments"])
+    assert la.avg_mobile_per_site == pytest.approx(float(exp["avg_mobile_per_site"]), rel=1e-12)
+    assert list(st.jumps()) == [tuple(r) for r in exp["jumps"]]
+    assert list(st.jumps(unknown_as_jump=True)) == [tuple(r) for r in exp["jumps_unknown"]]
+    if "site_vertices" in exp:
+        assert [sorted(v) for v in st.site_network.vertices] == G.vertices_of(exp["site_vertices"])
+    head = exp["lvecs"]                                   # the leading frames' landmark vectors
+    assert_lvecs(la._ctx.rows_dense(0, len(head)), head)
+
+
 def test_step1_and_wrap_against_reference():
     from sitator_amd import PBCCalculator
     for name in ("c1_hex_scgrid", "c1b_tri_bcctet", "c5_cut_fcc_ragged"):

@@ -110,6 +110,35 @@ def test_pipeline(oracle, name, tag):
         assert o["site_vertices"] == G.vertices_of(exp["site_vertices"])
 
 
+@pytest.mark.parametrize("name,tag", G.long_runs(G.LONG_CASES_CPU))
+def test_long_cuts(oracle, name, tag):
+    """The oracle on the long C2 / C5 cuts of the true reference (hops, unassigned samples, late clusters, jumps;
+    C5 with the Markov-clustering plugin): landmark vectors of the stored head bit-identical, labels identical."""
+    c = case(name)
+    exp = c.out(tag)
+    if "error_type" in exp:
+        with pytest.raises(oracle.OracleError) as ei:
+            run_oracle(oracle, c, tag)
+        assert ei.value.kind == str(exp["error_type"])
+        assert ei.value.frame == int(exp["error_frame"]) and ei.value.site == int(exp["error_site"])
+        assert list(ei.value.mobile) == list(exp["error_mobile_particles"])
+        return
+    o = run_oracle(oracle, c, tag)
+    head = exp["lvecs"]
+    assert np.array_equal(o["lvecs"][:len(head)], head), "landmark vectors must be bit-identical"
+    assert o["n_all_zero_lvecs"] == int(exp["n_all_zero_lvecs"])
+    assert np.array_equal(o["labels"], exp["labels"])
+    assert np.array_equal(o["counts"], exp["counts"])
+    m = exp["labels"] >= 0
+    np.testing.assert_allclose(o["confs"][m], exp["confs"][m], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(o["site_centers"], exp["site_centers"], rtol=1e-12, atol=1e-12)
+    assert o["n_multiple_assignments"] == int(exp["n_multiple_assignments"])
+    assert oracle.jumps(o["labels"]) == [tuple(r) for r in exp["jumps"]]
+    assert oracle.jumps(o["labels"], unknown_as_jump=True) == [tuple(r) for r in exp["jumps_unknown"]]
+    if "site_vertices" in exp:
+        assert o["site_vertices"] == G.vertices_of(exp["site_vertices"])
+
+
 @pytest.mark.parametrize("n,seed", [(700, 0), (1500, 1)])
 def test_sparse_markov_clustering_equals_dense(oracle, n, seed):
     """The product's scipy.sparse iteration (graphs of >= 600 landmarks) gives the groups of the dense iteration
