@@ -28,7 +28,7 @@ RcclApi *rccl()
     static RcclApi api;
     if (api.lib || !api.err.empty()) return &api;
     for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);    // LOCAL: a process may also hold another copy (torch ships one)
         if (api.lib) break;
     }
     if (!api.lib) { api.err = std::string("cannot load librccl.so: ") + dlerror(); return &api; }

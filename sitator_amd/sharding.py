@@ -221,9 +221,10 @@ def exact_sum_across(comm, hi, lo):
     lo = np.ascontiguousarray(lo, dtype=np.uint64)
     if comm is not None and comm.size > 1:
         m32 = np.uint64(0xffffffff)
-        s_hi = comm.allreduce_sum(hi)                              # wraps like two's complement: intended
-        s_l0 = comm.allreduce_sum(lo & m32)
-        s_l1 = comm.allreduce_sum(lo >> np.uint64(32))
+        # int64 on the wire (every Comm sums it; the high word wraps like two's complement, which is intended)
+        s_hi = comm.allreduce_sum(hi.view(np.int64)).view(np.uint64)
+        s_l0 = comm.allreduce_sum((lo & m32).view(np.int64)).view(np.uint64)
+        s_l1 = comm.allreduce_sum((lo >> np.uint64(32)).view(np.int64)).view(np.uint64)
         # lo' = (s_l0 + (s_l1 << 32)) mod 2^64, carries into hi
         mid = s_l1 + (s_l0 >> np.uint64(32))
         lo = (s_l0 & m32) | ((mid & m32) << np.uint64(32))
