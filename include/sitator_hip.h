@@ -150,6 +150,9 @@ int sit_set_centers(sit_ctx *ctx, const double *centers, int64_t K, int normed);
 /* predict (:129-197) over the stored rows.  labels / confs may be NULL (kept on device);
  * counts[K] = np.bincount(labels[labels >= 0]) (:92).                                     */
 int sit_predict(sit_ctx *ctx, double threshold, int64_t *labels, double *confs, int64_t *counts);
+/* Number of all-zero rows and the first of them (-1: none).  They get label -1; predict warns, or raises with
+ * ignore_zeros=False (:168-172, :192).                                                     */
+int sit_count_zero_rows(sit_ctx *ctx, int64_t *n_zero, int64_t *first_row);
 /* Labels / confidences of the last predict or fused assign, from the device.              */
 int sit_get_assignments(sit_ctx *ctx, int64_t *labels, double *confs, int64_t *counts);
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "sit_set_centers": (C.c_int, [_vp, _dp, i64, C.c_int]),
     "sit_predict": (C.c_int, [_vp, C.c_double, _ip, _dp, _ip]),
     "sit_get_assignments": (C.c_int, [_vp, _ip, _dp, _ip]),
+    "sit_count_zero_rows": (C.c_int, [_vp, _ip, _ip]),
     "sit_gram": (C.c_int, [_vp, _dp, _ip]),
     "sit_gram_limbs": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), _ip]),
     "sit_weighted_row_sums_limbs": (C.c_int, [_vp, C.c_int, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -327,6 +328,12 @@ class HipContext(object):
         counts = np.zeros(self.K, dtype=np.int64)
         self._check(self.lib.sit_get_assignments(self._h, _i(labels), _d(confs), _i(counts)))
         return labels, confs, counts
+
+    def count_zero_rows(self):
+        """(number of all-zero rows, index of the first one or -1)."""
+        n, first = i64(0), i64(0)
+        self._check(self.lib.sit_count_zero_rows(self._h, C.byref(n), C.byref(first)))
+        return n.value, first.value
 
     # -- mcl support
     def gram(self):

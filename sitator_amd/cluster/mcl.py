@@ -31,6 +31,21 @@ def cov2corr(A):
     return ((A.T / d).T) / d
 
 
+def _global_best_match_single(X, center):
+    """max_n |X[n] . c| and the norm of the first row reaching it, over all ranks (:80-87), for one centre."""
+    row, dot, nrm = X.ctx.best_match(center)
+    if X.comm.size > 1:
+        allv = X.comm.allgather(np.array([dot, nrm]))
+        best = 0
+        for r in range(1, X.comm.size):
+            if np.isnan(allv[best, 0]):
+                break
+            if np.isnan(allv[r, 0]) or allv[r, 0] > allv[best, 0]:
+                best = r
+        dot, nrm = allv[best, 0], allv[best, 1]
+    return dot, nrm
+
+
 def _global_best_matches(X, group_of_dim, cvec, n_groups):
     """Per landmark group: max_n |X[n] . c_g| and the norm of the first row reaching it, over all ranks (:80-87).
     The groups partition the landmarks, so one pass over the rows serves every centre."""
@@ -98,12 +113,26 @@ def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, ver
             centers[i, group] = 1.0
         else:
             centers[i, group] = _top_eigenvector(cov[group][:, group]).T   # :78
+    # Markov clustering normally partitions the landmarks, and then one pass over the rows finds the best-matching
+    # row of EVERY group; a landmark attracted to two attractors appears in two groups (util/mcl.py:54-60 allows
+    # it): those few groups are matched one by one, as the reference does (:80-83)
     group_of_dim = np.full(n_lmk, -1, dtype=np.int32)
     cvec = np.zeros(n_lmk)
+    shared = np.zeros(len(groups), dtype=bool)
     for i, group in enumerate(groups):
+        taken = group_of_dim[group] >= 0
+        if np.any(taken):
+            shared[i] = True
+            shared[np.unique(group_of_dim[np.asarray(group)[taken]])] = True
         group_of_dim[group] = i
-        cvec[group] = centers[i, group]
+    for i, group in enumerate(groups):
+        if shared[i]:
+            group_of_dim[np.asarray(group)[group_of_dim[group] == i]] = -1
+        else:
+            cvec[group] = centers[i, group]
     best_dots, best_norms = _global_best_matches(X, group_of_dim, cvec, len(groups)) if len(groups) else ([], [])
+    for i in np.nonzero(shared)[0]:
+        best_dots[i], best_norms[i] = _global_best_match_single(X, centers[i])
     for i in range(len(groups)):
         best_dot, best_norm = best_dots[i], best_norms[i]
         with np.errstate(divide="ignore", invalid="ignore"):

@@ -274,6 +274,40 @@ extern "C" int sit_get_assignments(sit_ctx *c, i64 *labels, double *confs, i64 *
     return SIT_OK;
 }
 
+// rows without a non-zero component (util/DotProdClassifier.pyx:168-172 counts them to warn or raise)
+__global__ __launch_bounds__(256) void k_count_zero_rows(const i32 *nnz, i64 N, u64 *out)
+{
+    u64 n = 0, first = SIT_NO_ERROR_KEY;
+    for (i64 r = (i64)blockIdx.x * 256 + threadIdx.x; r < N; r += (i64)gridDim.x * 256)
+        if (nnz[r] == 0) { n++; first = (u64)r < first ? (u64)r : first; }
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_down(n, off);
+        const u64 o = __shfl_down(first, off);
+        first = o < first ? o : first;
+    }
+    if ((threadIdx.x & 63) == 0 && n) { atomicAdd(&out[0], n); atomicMin(&out[1], first); }
+}
+
+extern "C" int sit_count_zero_rows(sit_ctx *c, i64 *n_zero, i64 *first_row)
+{
+    if (!c || !n_zero || !first_row) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->rows_valid, "sit_count_zero_rows: no landmark rows on the device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_scal + 1, 0xFF, sizeof(u64), c->stream));
+    if (c->N > 0) {
+        const i64 blocks = (c->N + 255) / 256;
+        k_count_zero_rows<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, c->stream>>>(c->d_row_nnz, c->N, c->d_scal);
+        HIP_TRY(c, hipGetLastError());
+    }
+    u64 *hb = (u64 *)c->h_pinned;
+    HIP_TRY(c, hipMemcpyAsync(hb, c->d_scal, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_zero = (i64)hb[0];
+    *first_row = hb[0] ? (i64)hb[1] : -1;
+    return SIT_OK;
+}
+
 extern "C" int sit_predict(sit_ctx *c, double threshold, i64 *labels, double *confs, i64 *counts)
 {
     if (!c) return SIT_ERR_INVALID;

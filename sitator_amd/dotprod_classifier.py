@@ -126,11 +126,18 @@ class DotProdClassifier(object):
             raise TypeError("X has wrong dimension %s; should be (%i)" % (X.shape, self._featuredim))
         if threshold is None:
             threshold = self._threshold
-        labels, confs, _, zeros = self._predict_device(X, threshold, predict_normed)
+        zeros, first = X.ctx.count_zero_rows()                             # :168-172
+        if X.comm.size > 1:
+            nrows = X.comm.allgather(np.array([X.shape[0], zeros, first], dtype=np.int64))
+            zeros = int(nrows[:, 1].sum())
+            offs = np.concatenate([[0], np.cumsum(nrows[:, 0])[:-1]])
+            firsts = [int(offs[r] + nrows[r, 2]) for r in range(X.comm.size) if nrows[r, 2] >= 0]
+            first = min(firsts) if firsts else -1
+        if zeros > 0 and not ignore_zeros:
+            raise ValueError("Data %i is all zeros!" % first)
+        labels, confs, _, _ = self._predict_device(X, threshold, predict_normed)
         if zeros > 0:
-            if not ignore_zeros:
-                raise ValueError("Data contains %i all-zero rows!" % zeros)
-            logger.warning("Encountered %i zero vectors during prediction" % zeros)
+            logger.warning("Encountered %i zero vectors during prediction" % zeros)                  # :192
         return (labels, confs) if return_confidences else labels
 
     def _predict_device(self, X, threshold, predict_normed, fetch=True):

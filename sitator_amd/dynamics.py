@@ -10,6 +10,8 @@ import logging
 
 import numpy as np
 
+from . import errors
+
 from .markov import markov_clustering
 from .merging import MergeSites
 from .pbc import PBCCalculator
@@ -34,6 +36,9 @@ class JumpAnalysis(object):
         logger.info("Running JumpAnalysis...")
         sn = st.site_network
         n_sites = sn.n_sites
+        if st._traj.size and int(st._traj.max()) >= n_sites:
+            # the reference's fancy indexing raises here (JumpAnalysis.py:75-88); the kernels index K x K tables
+            raise IndexError("index %i is out of bounds for axis 0 with size %i" % (int(st._traj.max()), n_sites))
         ctx = st._device()
         comm = st._comm
         n_frames = st.n_frames
@@ -108,14 +113,20 @@ class SmoothSiteTrajectory(object):
             seen = np.zeros(sn.n_sites, dtype=bool)
             seen[np.unique(out[out >= 0])] = True
             if not np.all(seen):
+                n_new = int(np.sum(seen))
+                if n_new < sn.n_mobile:                      # dynamics/RemoveUnoccupiedSites.py:42-47
+                    raise errors.InsufficientSitesError(verb="Removing unoccupied sites", n_sites=n_new,
+                                                        n_mobile=sn.n_mobile)
                 trans = np.full(sn.n_sites + 1, -1, dtype=np.int64)
-                trans[:-1][seen] = np.arange(int(np.sum(seen)))
+                trans[:-1][seen] = np.arange(n_new)
                 new._traj = trans[out]
-                verts = sn.vertices
+                verts, types = sn.vertices, sn.site_types
                 newsn = sn.copy()
-                newsn.centers = np.asarray(sn.centers)[seen]
+                newsn.centers = np.asarray(sn.centers)[seen]     # (the setter drops vertices and types)
                 if verts is not None:
                     newsn.vertices = [v for v, keep in zip(verts, seen) if keep]
+                if types is not None:
+                    newsn.site_types = np.asarray(types)[seen]   # old_sn[seen_mask] keeps them (:62)
                 new._sn = newsn
         new.site_network.clear_attributes()
         return new

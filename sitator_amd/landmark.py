@@ -197,6 +197,9 @@ class LandmarkAnalysis(object):
         out_st = SiteTrajectory(out_sn, lmk_lbls, lmk_confs, _ctx=ctx, _comm=comm)
         self.n_multiple_assignments, self.avg_mobile_per_site = out_st.check_multiple_occupancy(
             max_mobile_per_site=self.max_mobile_per_site)
+        # the context is shared with this object (predict() through landmark_vectors rewrites its labels): from here
+        # on the trajectory uploads its own labels before every device-backed operation
+        out_st._labels_shared = True
         out_st.set_real_traj(frames)
         lap("occupancy")
         self.timings = ctx.timers()

@@ -36,6 +36,8 @@ class RecenterTrajectory(object):
     def _apply(ctx, arr, mass_arr, factors, add):
         if arr.dtype != np.float64 or arr.ndim != 3 or arr.shape[2] != 3:
             raise ValueError("Buffer dtype mismatch, expected (n_frames, n_atoms, 3) 'double'")
+        if len(mass_arr) != arr.shape[1] or len(factors) != arr.shape[1]:
+            raise ValueError("masses / static_mask have %i / %i entries for %i atoms" % (len(mass_arr), len(factors), arr.shape[1]))
         if arr.flags.c_contiguous:
             ctx.recenter(arr, mass_arr, factors, add)
         else:

@@ -29,6 +29,7 @@ class SiteTrajectory(object):
         self._real_traj = None
         # device context whose resident assignments equal self._traj (set by LandmarkAnalysis)
         self._ctx = _ctx
+        self._labels_shared = False      # see traj / _device
         self._comm = _comm
 
     # -- container protocol ---------------------------------------------------------------
@@ -51,6 +52,10 @@ class SiteTrajectory(object):
     # -- plain accessors --------------------------------------------------------------------
     @property
     def traj(self):
+        """The site-assignment array itself, writable as in the reference (editing it in place is normal use there).
+        Once it has been handed out the device copy can no longer be trusted: every device-backed operation
+        uploads the labels again from then on (N * 8 bytes)."""
+        self._labels_shared = True
         return self._traj
 
     @property
@@ -105,6 +110,7 @@ class SiteTrajectory(object):
     def trajectory_for_particle(self, i, return_confidences=False):
         if return_confidences and self._confs is None:
             raise ValueError("This SiteTrajectory has no confidences")
+        self._labels_shared = True              # a view of the label array leaves
         if return_confidences:
             return self._traj[:, i], self._confs[:, i]
         return self._traj[:, i]
@@ -127,11 +133,15 @@ class SiteTrajectory(object):
 
     # -- device-backed pieces ----------------------------------------------------------------
     def _device(self):
-        """A context holding this trajectory's labels (uploads them if it has none)."""
+        """A context holding this trajectory's CURRENT labels: a fresh upload if there is no context yet, and again
+        whenever the label array may have been edited by the caller (``traj`` hands out the array itself; a context
+        shared with LandmarkAnalysis may also have been re-predicted)."""
         if self._ctx is None:
             cell = self._sn.structure.cell
             self._ctx = _lib.HipContext(np.asarray(cell, dtype=np.float64))
             self._ctx.set_assignments(self._traj, self._confs)
+        elif getattr(self, "_labels_shared", True):
+            self._ctx.set_assignments(self._traj, self._confs, frame0=self._ctx.frame0)
         return self._ctx
 
     def _invalidate_device(self):
@@ -225,18 +235,24 @@ class SiteTrajectory(object):
                     last_in = last_out
         else:
             rec, _ = ctx.jump_list(unknown_as_jump, None)
-        return rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3]
+        # frames are GLOBAL frame numbers: a shard's frames start at ctx.frame0, and its first frame can hold jumps
+        # too (against the state carried in from the previous shard)
+        return rec[:, 0] + ctx.frame0, rec[:, 1], rec[:, 2], rec[:, 3], ctx.frame0, last_in is not None
 
     def jumps(self, **kwargs):
-        """Yield ``(frame, mobile_atom, from_site, to_site)`` for every jump (reference :307-329)."""
-        f, a, fr, to = self._jump_arrays(**kwargs)
+        """Yield ``(frame, mobile_atom, from_site, to_site)`` for every jump (reference :307-329).  On a frame shard the
+        frames are global frame numbers."""
+        f, a, fr, to, _, _ = self._jump_arrays(**kwargs)
         for i in range(len(f)):
             yield int(f[i]), int(a[i]), int(fr[i]), int(to[i])
 
     def jumps_by_frame(self, **kwargs):
-        """Yield ``(frame, atoms_that_jumped, from_sites, to_sites)`` for frames 1.. (reference :331-345)."""
-        f, a, fr, to = self._jump_arrays(**kwargs)
-        bounds = np.searchsorted(f, np.arange(1, self.n_frames + 1))
-        for frame in range(1, self.n_frames):
-            lo, hi = bounds[frame - 1], bounds[frame]
-            yield frame, a[lo:hi], fr[lo:hi], to[lo:hi]
+        """Yield ``(frame, atoms_that_jumped, from_sites, to_sites)`` for frames 1.. (reference :331-345).  On a frame
+        shard: for this shard's (global) frames, its first frame included when a previous shard exists."""
+        f, a, fr, to, frame0, has_halo = self._jump_arrays(**kwargs)
+        first = frame0 if has_halo else frame0 + 1
+        frames = np.arange(first, frame0 + self.n_frames)
+        lo_b = np.searchsorted(f, frames, side="left")
+        hi_b = np.searchsorted(f, frames, side="right")
+        for i, frame in enumerate(frames):
+            yield int(frame), a[lo_b[i]:hi_b[i]], fr[lo_b[i]:hi_b[i]], to[lo_b[i]:hi_b[i]]

@@ -165,6 +165,10 @@ class FakeContext(object):
         self._normed = bool(normed)
         self.K = len(self._cmat)
 
+    def count_zero_rows(self):
+        z = np.nonzero(~self.X.any(axis=1))[0]
+        return len(z), (int(z[0]) if len(z) else -1)
+
     def predict(self, threshold, fetch=True):
         X = self.X
         labels = np.full(len(X), -1, dtype=np.int64)

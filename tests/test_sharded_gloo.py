@@ -50,7 +50,9 @@ def _worker(rank, world, port, case_name, tag, outdir):
         out.update(labels=st.traj, confs=st.confidences, centers=np.asarray(st.site_network.centers),
                    n_multi=la.n_multiple_assignments, avg=la.avg_mobile_per_site,
                    n_zero=la.n_all_zero_lvecs,
-                   jumps=np.array(list(st.jumps()), dtype=np.int64).reshape(-1, 4))
+                   jumps=np.array(list(st.jumps()), dtype=np.int64).reshape(-1, 4),
+                   jbf=np.array([[f, a_, b_, c_] for f, at, fr, to in st.jumps_by_frame()
+                                 for a_, b_, c_ in zip(at, fr, to)], dtype=np.int64).reshape(-1, 4))
     except (errors.StaticLatticeError, errors.ZeroLandmarkError, errors.MultipleOccupancyError,
             errors.InsufficientSitesError) as e:
         out.update(error=type(e).__name__, frame=getattr(e, "frame", -1),
@@ -84,8 +86,9 @@ def test_two_ranks_reproduce_the_reference(name, tag):
         assert int(o["n_multi"]) == int(exp["n_multiple_assignments"])
         assert float(o["avg"]) == pytest.approx(float(exp["avg_mobile_per_site"]), rel=1e-12)
         assert int(o["n_zero"]) == int(exp["n_all_zero_lvecs"])
-    jumps = np.concatenate([o["jumps"] + np.array([int(o["lo"]), 0, 0, 0]) for o in outs])
+    jumps = np.concatenate([o["jumps"] for o in outs])             # global frame numbers, shard boundaries included
     assert np.array_equal(jumps, exp["jumps"])
+    assert np.array_equal(np.concatenate([o["jbf"] for o in outs]), exp["jumps"]), "jumps_by_frame must agree with jumps"
 
 
 @pytest.mark.parametrize("name,tag", [("err_static_threshold", "default"), ("err_multiple_occupancy", "default"),
