@@ -157,6 +157,48 @@ __device__ __forceinline__ void predict_row_merge(const PredArgs &a, i64 row, in
     finish_predict(a, row, am.result(xn, a.normed != 0));
 }
 
+// The same merge for rows of up to NW entries (ragged bases: C5 rows hold 5-13).  The column heads live in registers
+// (every index below is a compile-time constant after unrolling); a step costs NW - 1 minimum operations and NW
+// predicated advances, against the row x column x row dense look-ups of predict_row_generic.
+template <int NW>
+__device__ __forceinline__ void predict_row_merge_wide(const PredArgs &a, i64 row, int n, double xn)
+{
+    ArgMaxQ am;
+    am.init();
+    const i32 none = 0x7fffffff;
+    i32 q[NW], e[NW], h[NW];
+    double v[NW];
+#pragma unroll
+    for (int s = 0; s < NW; s++) {
+        q[s] = 0; e[s] = 0; h[s] = none; v[s] = 0.0;
+        if (s < n) {
+            const i32 d = a.row_idx[(i64)s * a.N + row];
+            q[s] = a.col_ptr[d]; e[s] = a.col_ptr[d + 1]; v[s] = a.row_val[(i64)s * a.N + row];
+            h[s] = q[s] < e[s] ? a.col_k[q[s]] : none;
+        }
+    }
+    while (true) {
+        i32 cid = h[0];
+#pragma unroll
+        for (int s = 1; s < NW; s++) cid = h[s] < cid ? h[s] : cid;
+        if (cid == none) break;
+        double dot = 0.0;
+        bool first = true;
+#pragma unroll
+        for (int s = 0; s < NW; s++) {
+            if (h[s] == cid) {                                       // ascending dimension order (:176)
+                const double t = a.col_val[q[s]] * v[s];
+                dot = first ? t : dot + t;
+                first = false;
+                q[s]++;
+                h[s] = q[s] < e[s] ? a.col_k[q[s]] : none;
+            }
+        }
+        am.push(dot, cid, xn, a.normed != 0);                       // :177-179
+    }
+    finish_predict(a, row, am.result(xn, a.normed != 0));
+}
+
 __device__ __forceinline__ bool predict_row_head(const PredArgs &a, i64 row, int &n, double &xn)
 {
     n = a.row_nnz[row];
@@ -175,6 +217,8 @@ __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a)
     double xn;
     if (!predict_row_head(a, row, n, xn)) return;
     if (n <= 4) predict_row_merge(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
+    else if (n <= 8) predict_row_merge_wide<8>(a, row, n, xn);
+    else if (n <= 16) predict_row_merge_wide<16>(a, row, n, xn);
     else predict_row_generic(a, row, n, xn);
 }
 

@@ -318,6 +318,9 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
             if ((rc = dev_alloc(c, &c->d_row_nnz, N))) return rc;
             if ((rc = dev_alloc(c, &c->d_row_idx, N * W))) return rc;
             if ((rc = dev_alloc(c, &c->d_row_val, N * W))) return rc;
+            // slots beyond a row's nnz are never written by the fill kernels: give them a defined content once
+            HIP_TRY(c, hipMemsetAsync(c->d_row_idx, 0, (size_t)(N * W > 0 ? N * W : 1) * 4, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->d_row_val, 0, (size_t)(N * W > 0 ? N * W : 1) * 8, c->stream));
             c->rows_W = W; c->rows_N = N;
         }
         if (assign && (!c->d_labels || c->assign_N != N)) {
