@@ -193,6 +193,10 @@ int sit_site_sums(sit_ctx *ctx, int weighted, int64_t K, const double *anchor_pt
 int sit_check_occupancy(sit_ctx *ctx, int64_t K, int64_t max_per_site,
                         int64_t *n_multi, int64_t *total, int64_t *nsites, sit_error *err);
 
+/* np.bincount(traj[traj >= 0], minlength=K) of the device labels: compute_site_occupancies (:187-202) divides it
+ * by the number of frames.                                                                */
+int sit_site_counts(sit_ctx *ctx, int64_t K, int64_t *counts);
+
 /* Upload a label array (and optional confidences) as the context's assignments, for a
  * SiteTrajectory that was not produced on this context (SiteTrajectory.__init__, :15-42).
  * Sets F, M (and the row count) if no frames are resident.                                */

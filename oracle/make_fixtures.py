@@ -403,6 +403,9 @@ def next_tier_cases(ref):
         sn = st.site_network
         for attr in ("n_ij", "p_ij", "jump_lag", "residence_times", "occupancy_freqs", "total_corrected_residences"):
             blob[name + "/ja_" + attr] = np.asarray(getattr(sn, attr))
+        st_occ = make_st(lab, K, M)
+        blob[name + "/occupancies"] = np.asarray(st_occ.compute_site_occupancies())      # SiteTrajectory.py:187-202
+        assert np.array_equal(st_occ.site_network.occupancies, blob[name + "/occupancies"])
         for thr in (1, 3):
             st2 = make_st(lab, K, M)
             res = st2.assign_to_last_known_site(frame_threshold=thr)

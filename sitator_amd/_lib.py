@@ -72,6 +72,7 @@ SIGNATURES = {
     "sit_site_sums": (C.c_int, [_vp, C.c_int, i64, _dp, _dp]),
     "sit_check_occupancy": (C.c_int, [_vp, i64, i64, _ip, _ip, _ip, C.POINTER(SitError)]),
     "sit_set_assignments": (C.c_int, [_vp, _ip, _dp, i64, i64, i64]),
+    "sit_site_counts": (C.c_int, [_vp, i64, _ip]),
     "sit_jump_sources": (C.c_int, [_vp, C.c_int, _ip, _ip, _ip]),
     "sit_jump_list": (C.c_int, [_vp, C.c_int, _ip, i64, _ip, _ip, _ip]),
     "sit_jump_analysis": (C.c_int, [_vp, i64, _ip, _ip, _dp, _dp, _ip, _ip, _ip, _ip, _ip]),
@@ -413,6 +414,11 @@ class HipContext(object):
         c = None if confs is None else _f64(confs)
         self._check(self.lib.sit_set_assignments(self._h, _i(labels), None if c is None else _d(c), F, M, int(frame0)))
         self.F, self.M, self.N, self.frame0 = F, M, F * M, int(frame0)
+
+    def site_counts(self, K):
+        counts = np.zeros(int(K), dtype=np.int64)
+        self._check(self.lib.sit_site_counts(self._h, int(K), _i(counts)))
+        return counts
 
     JUMP_NONE = -(1 << 63)
 

@@ -300,6 +300,28 @@ int sit_label_counts(sit_ctx *c)
     return SIT_OK;
 }
 
+// np.bincount(traj[traj >= 0], minlength=K) of the device-resident labels (SiteTrajectory.compute_site_occupancies,
+// SiteTrajectory.py:187-202, divides it by the number of frames)
+extern "C" int sit_site_counts(sit_ctx *c, i64 K, i64 *counts)
+{
+    if (!c || !counts) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->assign_valid && K > 0, "sit_site_counts: no assignments on the device");
+    SIT_REQUIRE(c, K * 4 <= 150 * 1024, "too many sites for the LDS label histogram");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = ensure_scratch(c, K * 8);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)K * 8, c->stream));
+    if (c->N > 0) {
+        const size_t lds = (size_t)K * 4 + 16;
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_label_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_label_hist<<<dim3((unsigned)((c->N + 8191) / 8192)), dim3(256), lds, c->stream>>>(c->d_labels, c->N, K, (u64 *)c->d_scratch);
+        HIP_TRY(c, hipGetLastError());
+    }
+    HIP_TRY(c, hipMemcpyAsync(counts, c->d_scratch, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
 extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, sit_error *err)
 {
     if (!c || !p) return SIT_ERR_INVALID;

@@ -128,8 +128,21 @@ class SiteTrajectory(object):
         return pts
 
     def compute_site_occupancies(self):
-        """Fraction of frames each site is occupied (can exceed 1 under multiple occupancy)."""
-        return np.true_divide(np.bincount(self._traj[self._traj >= 0], minlength=self._sn.n_sites), self.n_frames)
+        """Occupancy of every site: assignments to it divided by the number of frames (above 1 possible under multiple
+        occupancy); also stored as the site attribute ``occupancies`` (reference :187-202).  The counts come from the
+        device-resident labels; on frame shards they are summed over the ranks."""
+        n_sites = int(self._sn.n_sites)
+        counts = self._device().site_counts(n_sites) if n_sites > 0 else np.zeros(0, dtype=np.int64)
+        n_frames = self.n_frames
+        comm = self._comm
+        if comm is not None and comm.size > 1:
+            counts = comm.allreduce_sum(counts)
+            n_frames = int(comm.allreduce_sum(np.array([n_frames], dtype=np.int64))[0])
+        occ = np.true_divide(counts, n_frames)
+        if self._sn.has_attribute("occupancies"):
+            self._sn.remove_attribute("occupancies")
+        self._sn.add_site_attribute("occupancies", occ)
+        return occ
 
     # -- device-backed pieces ----------------------------------------------------------------
     def _device(self):

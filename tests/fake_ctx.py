@@ -165,6 +165,10 @@ class FakeContext(object):
         self._normed = bool(normed)
         self.K = len(self._cmat)
 
+    def site_counts(self, K):
+        lab = self._labels.reshape(-1)
+        return np.bincount(lab[lab >= 0], minlength=int(K)).astype(np.int64)
+
     def count_zero_rows(self):
         z = np.nonzero(~self.X.any(axis=1))[0]
         return len(z), (int(z[0]) if len(z) else -1)

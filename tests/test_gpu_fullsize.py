@@ -110,3 +110,49 @@ def test_full_size_two_shards_equal_one_pass(c2_full):
         c.set_centers(normed, True)
         labels.append(c.predict(0.8)[0])
     assert np.array_equal(np.concatenate(labels).reshape(100000, 64), st.traj)
+
+
+def test_c3_full_length_properties_and_sampled_oracle(oracle):
+    """BASELINE configs[2] at its stated size: LLZO-like cell, 448 mobile ions, 250 000 frames = 1.12e8 landmark
+    vectors (9.2 GB of frames, resident in HBM).  Size-independent properties, and landmark vectors / labels of a random
+    sample of frames against the CPU oracle."""
+    import psutil
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth
+    if psutil.virtual_memory().available < 30 * 2 ** 30:
+        pytest.skip("needs ~20 GB of host memory for the 9.2 GB trajectory")
+    host = synth.config_host("C3")
+    M, F = 448, 250000
+    gen = synth.TrajectoryGenerator(host, M, seed=3, threads=16)
+    ref = gen.reference_positions()
+    frames = gen.generate(F)
+    sn = SiteNetwork(Structure(ref, host.cell), gen.static_mask, gen.mobile_mask)
+    sn.centers = host.centers
+    sn.vertices = host.vertices
+    la = LandmarkAnalysis(verbose=False)
+    st = la.run(sn, frames)
+    assert st.traj.shape == (F, M) and st.traj.dtype == np.int64
+    K = st.site_network.n_sites
+    assert K >= M and st.traj.max() == K - 1 and st.traj.min() >= -1
+    m = st.traj >= 0
+    assert 0 < np.mean(~m) < 0.05, "hops leave a small unassigned fraction"
+    assert st.confidences[m].min() >= 0.8 and np.all(st.confidences[~m] == 0.0)
+    assert la.n_multiple_assignments == 0 and la.avg_mobile_per_site == 1.0
+    counts = np.bincount(st.traj[m], minlength=K)
+    assert counts.min() >= 1 and np.array_equal(st.compute_site_occupancies() * F, counts)
+    njumps = sum(1 for _ in st.jumps())
+    assert njumps > 1000
+    # sampled parity
+    rng = np.random.default_rng(8)
+    pick = np.sort(rng.choice(F, size=12, replace=False))
+    wrapped = oracle.wrap_points(host.cell, frames[pick])
+    sidx, midx = np.where(gen.static_mask)[0], np.where(gen.mobile_mask)[0]
+    verts, vcd = oracle.site_vertex_distances(host.cell, host.centers, host.vertices, ref[gen.static_mask])
+    exp, _ = oracle.fill(host.cell, wrapped, sidx, midx, ref[gen.static_mask], verts, vcd)
+    for i, f in enumerate(pick):
+        mine = la._ctx.rows_dense(int(f) * M, M)
+        assert np.array_equal(mine != 0, exp[i * M:(i + 1) * M] != 0)
+        np.testing.assert_allclose(mine, exp[i * M:(i + 1) * M], rtol=1e-6, atol=0)
+    lab, conf = oracle.predict(exp, np.asarray(la.cluster_centers_), 0.8, True)
+    assert np.array_equal(lab.reshape(len(pick), M), st.traj[pick])
+    mm = lab >= 0
+    np.testing.assert_allclose(conf[mm], st.confidences[pick].reshape(-1)[mm], rtol=1e-6)

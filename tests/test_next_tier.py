@@ -32,6 +32,8 @@ def test_oracle_next_tier_matches_reference(oracle, name):
     ja = oracle.jump_analysis(lab, K)
     for a in JA:
         assert _eq(ja[a], z()[name + "/ja_" + a]), a
+    occ = np.true_divide(np.bincount(lab[lab >= 0], minlength=K), len(lab))       # SiteTrajectory.py:197
+    assert np.array_equal(occ, z()[name + "/occupancies"])
     for thr in (1, 3):
         t, st = oracle.assign_to_last_known_site(lab, thr)
         assert np.array_equal(t, z()[name + "/alk%d_traj" % thr])
@@ -66,6 +68,10 @@ def _st(lab, K):
 def test_gpu_next_tier_matches_reference(name):
     from sitator_amd import JumpAnalysis, SmoothSiteTrajectory
     lab, K = z()[name + "/labels"], int(z()[name + "/n_sites"])
+    st0 = _st(lab, K)
+    occ = st0.compute_site_occupancies()                               # device histogram of the labels
+    assert np.array_equal(occ, z()[name + "/occupancies"])
+    assert np.array_equal(st0.site_network.occupancies, occ)
     st = JumpAnalysis().run(_st(lab, K))
     for a in JA:
         assert _eq(getattr(st.site_network, a), z()[name + "/ja_" + a]), a
