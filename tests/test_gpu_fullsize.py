@@ -138,7 +138,7 @@ def test_c3_full_length_properties_and_sampled_oracle(oracle):
     assert st.confidences[m].min() >= 0.8 and np.all(st.confidences[~m] == 0.0)
     assert la.n_multiple_assignments == 0 and la.avg_mobile_per_site == 1.0
     counts = np.bincount(st.traj[m], minlength=K)
-    assert counts.min() >= 1 and np.array_equal(st.compute_site_occupancies() * F, counts)
+    assert counts.min() >= 1 and np.array_equal(st.compute_site_occupancies(), np.true_divide(counts, F))
     njumps = sum(1 for _ in st.jumps())
     assert njumps > 1000
     # sampled parity
