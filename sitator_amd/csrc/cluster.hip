@@ -209,15 +209,35 @@ __device__ __forceinline__ bool predict_row_head(const PredArgs &a, i64 row, int
     return true;
 }
 
-__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a)
+// Rows of at most four entries are assigned here; wider rows are listed for k_predict_rows_wide (its register-hungry
+// merges would otherwise set the occupancy of this kernel too: 0.31 -> 0.48 ms at C2, where no row is wide).
+__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a, i32 *wide_list, unsigned *wide_count)
 {
     const i64 row = (i64)blockIdx.x * PRED_BLOCK + threadIdx.x;
-    if (row >= a.N) return;
+    int n = 0;
+    double xn = 0.0;
+    const bool live = row < a.N && predict_row_head(a, row, n, xn);
+    const bool wide = live && n > 4;
+    const unsigned long long wm = __ballot(wide);
+    if (wm) {                                                      // one atomic per wave
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)wm) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(wide_count, (unsigned)__popcll(wm));
+        base = __shfl(base, leader);
+        if (wide) wide_list[base + __popcll(wm & ((1ull << lane) - 1ull))] = (i32)row;
+    }
+    if (live && !wide) predict_row_merge(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
+}
+
+__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_wide(PredArgs a, const i32 *wide_list, const unsigned *wide_count)
+{
+    const i64 q = (i64)blockIdx.x * PRED_BLOCK + threadIdx.x;
+    if (q >= (i64)*wide_count) return;
+    const i64 row = wide_list[q];
     int n;
     double xn;
     if (!predict_row_head(a, row, n, xn)) return;
-    if (n <= 4) predict_row_merge(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
-    else if (n <= 8) predict_row_merge_wide<8>(a, row, n, xn);
+    if (n <= 8) predict_row_merge_wide<8>(a, row, n, xn);
     else if (n <= 16) predict_row_merge_wide<16>(a, row, n, xn);
     else predict_row_generic(a, row, n, xn);
 }
@@ -294,9 +314,15 @@ static int run_predict(sit_ctx *c, double threshold)
     a.labels = c->d_labels; a.confs = c->d_confs;
     a.N = c->rows_N; a.K = c->K; a.D = c->D; a.normed = c->centers_normed; a.threshold = threshold;
     const unsigned grid = (unsigned)((c->N + PRED_BLOCK - 1) / PRED_BLOCK);
+    if ((rc = ensure_scratch(c, c->N * 4 + 64))) return rc;
+    unsigned *wcount = (unsigned *)c->d_scratch;
+    i32 *wlist = (i32 *)c->d_scratch + 16;
     StageTimer t(c, T_PREDICT);
-    if (c->max_col <= PRED_MAXCOL) k_predict_rows<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
-    else k_predict_rows_dense<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
+    if (c->max_col <= PRED_MAXCOL) {
+        HIP_TRY(c, hipMemsetAsync(wcount, 0, 4, c->stream));
+        k_predict_rows<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount);
+        if (c->rows_W > 4) k_predict_rows_wide<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount);
+    } else k_predict_rows_dense<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
     HIP_TRY(c, hipGetLastError());
     if ((rc = sit_label_counts(c))) return rc;      // np.bincount(labels[labels >= 0]) (:92)
     t.stop();

@@ -30,7 +30,7 @@
 
 #define FF_CS 64        // support entries per centre (= lanes of the walking wave)
 #define FF_DC 64        // centres listed per landmark dimension
-#define FF_OC 32        // overlapping centres recorded per row
+#define FF_OC 64        // overlapping centres recorded per row (C5 rows overlap 40-60 centres)
 #define FF_BMAX 65536   // rows per batch
 #define FF_LOG 2048     // support-growth records per walk
 #define FF_NEW (-1)
@@ -52,6 +52,7 @@ struct FFState {
     i32 *dc_n, *dc_list;
     i32 *K;               // device scalar
     i32 *flags;           // [0] capacity overflow
+    i32 *why;             // which capacity: 1 centres per dimension, 2 serial break, 4 centres, 8 support, 16 / 32 decide (dimension list / overlaps)
     i64 D, Kcap;
 };
 
@@ -94,13 +95,13 @@ __device__ int ff_decide(const FFState &s, const FFRows &r, i64 row, double thre
     for (int e = 0; e < n; e++) {
         const i32 d = r.idx[(i64)e * r.stride + row];
         const int m = s.dc_n[d];
-        if (m > FF_DC) return FF_BREAK;
+        if (m > FF_DC) { atomicOr(s.why, 16); return FF_BREAK; }
         for (int q = 0; q < m; q++) {
             const i32 c = s.dc_list[(i64)d * FF_DC + q];
             int p = 0;
             while (p < nov && ovb[p * ovs] < c) p++;
             if (p < nov && ovb[p * ovs] == c) continue;
-            if (nov == FF_OC) return FF_BREAK;
+            if (nov == FF_OC) { atomicOr(s.why, 32); return FF_BREAK; }
             for (int t = nov; t > p; t--) ovb[t * ovs] = ovb[(t - 1) * ovs];
             ovb[p * ovs] = c; nov++;
         }
@@ -681,7 +682,7 @@ __global__ void k_ff_apply_growth(FFState s, FFBatch b)
     if (nl > FF_LOG) nl = FF_LOG;
     for (int q = 0; q < nl; q++) {
         const i32 kk = b.log[3 * q], dd = b.log[3 * q + 1];
-        if (s.dc_n[dd] >= FF_DC) { s.flags[0] = 1; continue; }
+        if (s.dc_n[dd] >= FF_DC) { s.flags[0] = 1; atomicOr(s.why, 1); continue; }
         s.dc_list[(i64)dd * FF_DC + s.dc_n[dd]] = kk; s.dc_n[dd]++;
     }
     *b.log_n = 0;
@@ -704,12 +705,12 @@ __global__ void k_ff_serial(FFState s, FFRows r, FFBatch b, i64 row0, int count,
         int nov;
         double xn;
         int dec = ff_decide(s, r, row, threshold, K, ovl, 1, nov, xn);
-        if (dec == FF_BREAK) { s.flags[0] = 1; break; }
+        if (dec == FF_BREAK) { s.flags[0] = 1; atomicOr(s.why, 2); break; }
         if (dec == FF_NEW) {                                          // :250-260
-            if (K >= s.Kcap || n > FF_CS) { s.flags[0] = 1; break; }
+            if (K >= s.Kcap || n > FF_CS) { s.flags[0] = 1; atomicOr(s.why, K >= s.Kcap ? 4 : 8); break; }
             bool ok = true;
             for (int e = 0; e < n; e++) if (s.dc_n[r.idx[(i64)e * r.stride + row]] >= FF_DC) ok = false;
-            if (!ok) { s.flags[0] = 1; break; }
+            if (!ok) { s.flags[0] = 1; atomicOr(s.why, 1); break; }
             for (int e = 0; e < n; e++) {
                 const i32 d = r.idx[(i64)e * r.stride + row];
                 s.cs_idx[(i64)K * FF_CS + e] = d;
@@ -731,7 +732,7 @@ __global__ void k_ff_serial(FFState s, FFRows r, FFBatch b, i64 row0, int count,
                 for (int i = 0; i < sn; i++) if (ix[i] == d) { in = true; break; }
                 if (!in) { extra++; if (s.dc_n[d] >= FF_DC) extra = FF_CS + 1; }
             }
-            if (sn + extra > FF_CS) { s.flags[0] = 1; break; }
+            if (sn + extra > FF_CS) { s.flags[0] = 1; atomicOr(s.why, 8); break; }
             const double fo = (double)s.c_cnt[c], fn = (double)(s.c_cnt[c] + w);
             for (int i = 0; i < sn; i++) vv[i] *= fo;
             for (int e = 0; e < n; e++) {
@@ -829,6 +830,7 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     f->bt.first_bad = f->bt.first_new + 1;
     f->bt.log_n = f->bt.first_new + 2;
     f->st.flags = f->sh.flags = f->bt.first_new + 3;
+    f->st.why = f->sh.why = f->bt.first_new + 6;
     f->bt.log = (i32 *)carve(p, (size_t)FF_LOG * 12);
     f->bt.lcnt = (i32 *)carve(p, (size_t)(Kcap + 1) * 4);
     f->bt.loff = (i32 *)carve(p, (size_t)(Kcap + 1) * 4);
@@ -950,7 +952,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         const i32 done = ctl[4];
         K = ctl[5];
         pos += done; c->ff_serial_rows += done;
-        if (ctl[3]) f->valid = false;
+        if (ctl[3]) { f->valid = false; c->ff_why = ctl[6]; c->ff_stop_row = pos; }
         return SIT_OK;
     };
     auto commit = [&]() {                     // the walked (shadow) state becomes the state
@@ -981,7 +983,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         HIP_TRY(c, hipGetLastError());
         { int rc = readback(); if (rc) return rc; }
         const i32 fb[4] = {ctl[0], ctl[1], ctl[2], ctl[3]};
-        if (fb[3]) { f->valid = false; break; }              // a capacity was exceeded: state is exact as of `pos`
+        if (fb[3]) { f->valid = false; c->ff_why = ctl[6]; c->ff_stop_row = pos; break; }   // a capacity was exceeded: state is exact as of `pos`
         const int first_new = fb[0] < nb ? fb[0] : nb;       // rows [0, first_new) were walked
         const int first_bad = fb[1];
         if (first_new == 0 || K == 0) {

@@ -113,6 +113,7 @@ struct sit_ctx {
     void *fitfast = nullptr;          // sparse speculative fit state (fitfast.hip)
     bool fit_use_fast = true;         // SITATOR_FIT=serial disables it
     i64 ff_batches = 0, ff_serial_rows = 0, ff_rewalks = 0;
+    i64 ff_why = 0, ff_stop_row = -1;  // capacity that ended the speculative fit (fitfast.hip FFState::why), and where
 
     // RCCL communicator of the frame-sharded path (comm.hip); opaque here
     void *comm = nullptr;
