@@ -9,41 +9,85 @@
 #include "sit_internal.h"
 
 // ---- JumpAnalysis --------------------------------------------------------------------------------------
-// Pass 1 (lane per ion, frames in order): the forward-filled state machine of JumpAnalysis.py:46-92.
+// Pass 1: the forward-filled state machine of JumpAnalysis.py:46-92 per ion, frames in order:
 //   jfrom = last_known, jto = frame value after re-assigning unassigned to last_known (or -1 when either is
 //   unknown), jtime = time_at_current if the ion jumped this frame else 0.
-__global__ void k_ja_scan(const i64 *labels, i64 F, i64 M, const i64 *last_in, const i64 *tac_in,
-                          i32 *jfrom, i32 *jto, i32 *jtime, i64 *last_out, i64 *tac_out, u64 *n_problems)
+// The state (last known site, time at it) is a scan over the frames.  Frames are cut into chunks of DCH:
+// (1) every (chunk, ion) summarises its chunk - first and last known label, the last frame where two consecutive
+// known labels INSIDE the chunk differ; (2) one lane per ion chains the summaries (a few hundred steps) into the
+// state at every chunk's start - whether the chunk's first known label is a jump depends on the carried-in site;
+// (3) every (chunk, ion) replays its chunk from that state.  (Was: one lane per ion walking all F frames.)
+#define DCH 256
+#define D_NONE ((i64)0x8000000000000000ull)
+
+__global__ __launch_bounds__(64) void k_ja_chunk_summary(const i64 *labels, i64 F, i64 M, i64 *first_known, i64 *last_known,
+                                                         i32 *first_pos, i32 *last_jump_pos)
+{
+    const i64 c = blockIdx.x, j = (i64)blockIdx.y * 64 + threadIdx.x;
+    if (j >= M) return;
+    const i64 f0 = c * DCH, f1 = f0 + DCH < F ? f0 + DCH : F;
+    i64 fk = D_NONE, lk = D_NONE;
+    i32 fp = -1, ljp = -1;
+    for (i64 f = f0; f < f1; f++) {
+        const i64 cur = labels[f * M + j];
+        if (cur == -1) continue;
+        if (fk == D_NONE) { fk = cur; fp = (i32)(f - f0); }
+        else if (cur != lk && cur >= 0 && lk >= 0) ljp = (i32)(f - f0);   // :68,:74: both known
+        lk = cur;
+    }
+    first_known[c * M + j] = fk; last_known[c * M + j] = lk;
+    first_pos[c * M + j] = fp; last_jump_pos[c * M + j] = ljp;
+}
+
+// state at the start of every chunk: (last known site, time at current); the final state goes to last_out / tac_out
+__global__ void k_ja_chunk_carry(const i64 *labels, i64 F, i64 M, i64 nch, const i64 *last_in, const i64 *tac_in,
+                                 const i64 *first_known, const i64 *last_known, const i32 *first_pos, const i32 *last_jump_pos,
+                                 i64 *carry_last, i64 *carry_tac, i64 *last_out, i64 *tac_out)
 {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
     i64 last, tac;
     if (last_in) { last = last_in[j]; tac = tac_in[j]; }
     else { last = F > 0 ? labels[j] : -1; tac = 1; }            // :46-49
+    for (i64 c = 0; c < nch; c++) {
+        carry_last[c * M + j] = last; carry_tac[c * M + j] = tac;
+        const i64 len = (c * DCH + DCH < F ? DCH : F - c * DCH);
+        const i64 fk = first_known[c * M + j];
+        i64 jp = last_jump_pos[c * M + j];
+        if (fk != D_NONE) {
+            if (last >= 0 && fk >= 0 && fk != last && jp < first_pos[c * M + j]) jp = first_pos[c * M + j];
+            last = last_known[c * M + j];
+        }
+        tac = jp >= 0 ? len - jp : tac + len;                    // :88-91: 1 after the jump frame, + 1 per frame
+    }
+    last_out[j] = last; tac_out[j] = tac;
+}
+
+__global__ __launch_bounds__(64) void k_ja_chunk_replay(const i64 *labels, i64 F, i64 M, const i64 *carry_last, const i64 *carry_tac,
+                                                        i32 *jfrom, i32 *jto, i32 *jtime, u64 *n_problems)
+{
+    const i64 c = blockIdx.x, j = (i64)blockIdx.y * 64 + threadIdx.x;
     u64 problems = 0;
-    for (i64 f = 0; f < F; f += 8) {
-        i64 cur[8];
-        const int nb = (int)((F - f) < 8 ? (F - f) : 8);
-#pragma unroll
-        for (int q = 0; q < 8; q++) cur[q] = q < nb ? labels[(f + q) * M + j] : -1;
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if (q >= nb) break;
-            const bool unassigned = cur[q] == -1;
-            const i64 fr = unassigned ? last : cur[q];           // :65-67
+    if (j < M) {
+        const i64 f0 = c * DCH, f1 = f0 + DCH < F ? f0 + DCH : F;
+        i64 last = carry_last[c * M + j], tac = carry_tac[c * M + j];
+        for (i64 f = f0; f < f1; f++) {
+            const i64 cur = labels[f * M + j];
+            const bool unassigned = cur == -1;
+            const i64 fr = unassigned ? last : cur;              // :65-67
             const bool fknown = fr >= 0 && last >= 0;            // :68
             if (!fknown) problems++;
             const bool jumped = fknown && fr != last;            // :74
-            const i64 o = (f + q) * M + j;
+            const i64 o = f * M + j;
             jfrom[o] = fknown ? (i32)last : -1;
             jto[o] = fknown ? (i32)fr : -1;
             jtime[o] = jumped ? (i32)tac : 0;
             tac = jumped ? 1 : tac + 1;                          // :88-91
-            if (!unassigned) last = cur[q];                      // :94
+            if (!unassigned) last = cur;                         // :94
         }
     }
-    last_out[j] = last; tac_out[j] = tac;
-    if (problems) atomicAdd(n_problems, problems);
+    for (int off = 32; off > 0; off >>= 1) problems += __shfl_down(problems, off);
+    if (threadIdx.x == 0 && problems) atomicAdd(n_problems, problems);
 }
 
 // Pass 2 (frames in parallel): numpy's fancy-index "+=" semantics of :72-86 -- within ONE frame duplicate
@@ -83,7 +127,8 @@ extern "C" int sit_jump_analysis(sit_ctx *c, i64 K, const i64 *last_known_in, co
     SIT_REQUIRE(c, (last_known_in == nullptr) == (time_at_current_in == nullptr), "sit_jump_analysis: halo arrays come in pairs");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 N = c->N, M = c->M, F = c->F;
-    const i64 bytes = N * 12 + 4 * M * 8 + K * K * 24 + K * 8 + 64;
+    const i64 nch = (F + DCH - 1) / DCH;
+    const i64 bytes = N * 12 + 4 * M * 8 + K * K * 24 + K * 8 + 64 + nch * M * 40 + 64;
     int rc = ensure_scratch(c, bytes + 1024);
     if (rc) return rc;
     char *p = (char *)c->d_scratch;
@@ -98,15 +143,25 @@ extern "C" int sit_jump_analysis(sit_ctx *c, i64 K, const i64 *last_known_in, co
     i64 *d_tout = (i64 *)p; p += M * 8;
     i32 *d_from = (i32 *)p; p += N * 4;
     i32 *d_to = (i32 *)p; p += N * 4;
-    i32 *d_time = (i32 *)p;
+    i32 *d_time = (i32 *)p; p += N * 4;
+    p += (8 - ((size_t)p & 7)) & 7;
+    i64 *d_fk = (i64 *)p; p += nch * M * 8;
+    i64 *d_lk = (i64 *)p; p += nch * M * 8;
+    i64 *d_cl = (i64 *)p; p += nch * M * 8;
+    i64 *d_ct = (i64 *)p; p += nch * M * 8;
+    i32 *d_fp = (i32 *)p; p += nch * M * 4;
+    i32 *d_jp = (i32 *)p;
     HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(K * K * 24 + K * 8 + 64), c->stream));
     if (last_known_in) {
         HIP_TRY(c, hipMemcpyAsync(d_lin, last_known_in, (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(d_tin, time_at_current_in, (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
     }
-    k_ja_scan<<<dim3((unsigned)((M + 63) / 64)), dim3(64), 0, c->stream>>>(
-        c->d_labels, F, M, last_known_in ? d_lin : nullptr, last_known_in ? d_tin : nullptr, d_from, d_to, d_time,
-        d_lout, d_tout, d_np);
+    const dim3 cgrid((unsigned)(nch > 0 ? nch : 1), (unsigned)((M + 63) / 64));
+    if (nch > 0) k_ja_chunk_summary<<<cgrid, dim3(64), 0, c->stream>>>(c->d_labels, F, M, d_fk, d_lk, d_fp, d_jp);
+    k_ja_chunk_carry<<<dim3((unsigned)((M + 63) / 64)), dim3(64), 0, c->stream>>>(
+        c->d_labels, F, M, nch, last_known_in ? d_lin : nullptr, last_known_in ? d_tin : nullptr, d_fk, d_lk, d_fp, d_jp,
+        d_cl, d_ct, d_lout, d_tout);
+    if (nch > 0) k_ja_chunk_replay<<<cgrid, dim3(64), 0, c->stream>>>(c->d_labels, F, M, d_cl, d_ct, d_from, d_to, d_time, d_np);
     if (F > 0) k_ja_accumulate<<<dim3((unsigned)F), dim3(256), 0, c->stream>>>(d_from, d_to, d_time, F, M, K, d_nij, d_ts, d_tn, d_tt);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(n_ij, d_nij, (size_t)(K * K) * 8, hipMemcpyDeviceToHost, c->stream));
@@ -121,31 +176,67 @@ extern "C" int sit_jump_analysis(sit_ctx *c, i64 K, const i64 *last_known_in, co
 }
 
 // ---- assign_to_last_known_site (SiteTrajectory.py:235-304) -----------------------------------------------
-// Lane per ion, frames in order; rewrites the device labels in place.  frame_max[f] = max over ions of the
-// time an ion had been unknown when it became known again at frame f (for the reference's max statistic).
-__global__ void k_assign_last_known(i64 *labels, i64 F, i64 M, i64 threshold, const i64 *last_in, const i64 *tu_in,
-                                    i64 *last_out, i64 *tu_out, i32 *frame_max, u64 *stats)
+// Rewrites the device labels in place.  frame_max[f] = max over ions of the time an ion had been unknown when it
+// became known again at frame f (for the reference's max statistic).  The per-ion state (last known site, frames
+// unknown so far) is a scan over the frames, done in chunks like k_ja_chunk_*: summary (last known label of the
+// chunk, unknown frames after it), carry chain, replay.
+__global__ __launch_bounds__(64) void k_alk_chunk_summary(const i64 *labels, i64 F, i64 M, i64 *last_known, i32 *trailing)
+{
+    const i64 c = blockIdx.x, j = (i64)blockIdx.y * 64 + threadIdx.x;
+    if (j >= M) return;
+    const i64 f0 = c * DCH, f1 = f0 + DCH < F ? f0 + DCH : F;
+    i64 lk = D_NONE;
+    i32 tr = 0;
+    for (i64 f = f0; f < f1; f++) {
+        const i64 cur = labels[f * M + j];
+        if (cur != -1) { lk = cur; tr = 0; } else tr++;
+    }
+    last_known[c * M + j] = lk; trailing[c * M + j] = tr;
+}
+
+__global__ void k_alk_chunk_carry(i64 F, i64 M, i64 nch, const i64 *last_in, const i64 *tu_in, const i64 *last_known,
+                                  const i32 *trailing, i64 *carry_last, i64 *carry_tu, i64 *last_out, i64 *tu_out)
 {
     const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
     i64 last = last_in ? last_in[j] : -1, tu = tu_in ? tu_in[j] : 0;
-    u64 sum_t = 0, n_t = 0, reassigned = 0;
-    for (i64 f = 0; f < F; f++) {
-        const i64 cur = labels[f * M + j];
-        const bool unknown = cur == -1;
-        if (!unknown) {
-            last = cur;                                           // :261
-            if (tu != 0) { sum_t += (u64)tu; n_t++; atomicMax(&frame_max[f], (i32)tu); }   // :263-271
-            tu = 0;                                               // :273
-        } else {
-            if (tu < threshold) { labels[f * M + j] = last; reassigned++; }   // :275-278
-            tu++;                                                 // :279
-        }
+    for (i64 c = 0; c < nch; c++) {
+        carry_last[c * M + j] = last; carry_tu[c * M + j] = tu;
+        const i64 lk = last_known[c * M + j];
+        if (lk != D_NONE) { last = lk; tu = trailing[c * M + j]; }
+        else tu += (c * DCH + DCH < F ? DCH : F - c * DCH);
     }
     last_out[j] = last; tu_out[j] = tu;
-    if (sum_t) atomicAdd(&stats[0], sum_t);
-    if (n_t) atomicAdd(&stats[1], n_t);
-    if (reassigned) atomicAdd(&stats[2], reassigned);
+}
+
+__global__ __launch_bounds__(64) void k_alk_chunk_replay(i64 *labels, i64 F, i64 M, i64 threshold, const i64 *carry_last,
+                                                         const i64 *carry_tu, i32 *frame_max, u64 *stats)
+{
+    const i64 c = blockIdx.x, j = (i64)blockIdx.y * 64 + threadIdx.x;
+    u64 sum_t = 0, n_t = 0, reassigned = 0;
+    if (j < M) {
+        const i64 f0 = c * DCH, f1 = f0 + DCH < F ? f0 + DCH : F;
+        i64 last = carry_last[c * M + j], tu = carry_tu[c * M + j];
+        for (i64 f = f0; f < f1; f++) {
+            const i64 cur = labels[f * M + j];
+            if (cur != -1) {
+                last = cur;                                           // :261
+                if (tu != 0) { sum_t += (u64)tu; n_t++; atomicMax(&frame_max[f], (i32)tu); }   // :263-271
+                tu = 0;                                               // :273
+            } else {
+                if (tu < threshold) { labels[f * M + j] = last; reassigned++; }   // :275-278
+                tu++;                                                 // :279
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sum_t += __shfl_down(sum_t, off); n_t += __shfl_down(n_t, off); reassigned += __shfl_down(reassigned, off);
+    }
+    if (threadIdx.x == 0) {
+        if (sum_t) atomicAdd(&stats[0], sum_t);
+        if (n_t) atomicAdd(&stats[1], n_t);
+        if (reassigned) atomicAdd(&stats[2], reassigned);
+    }
 }
 
 extern "C" int sit_assign_last_known(sit_ctx *c, i64 frame_threshold, const i64 *last_known_in, const i64 *time_unknown_in,
@@ -155,21 +246,29 @@ extern "C" int sit_assign_last_known(sit_ctx *c, i64 frame_threshold, const i64 
     SIT_REQUIRE(c, c->assign_valid, "sit_assign_last_known: assignments needed");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 M = c->M, F = c->F, N = c->N;
-    int rc = ensure_scratch(c, 4 * M * 8 + F * 4 + 64 + 256);
+    const i64 nch = (F + DCH - 1) / DCH;
+    int rc = ensure_scratch(c, 4 * M * 8 + F * 4 + 64 + 256 + nch * M * 28 + 64);
     if (rc) return rc;
     char *p = (char *)c->d_scratch;
     u64 *d_st = (u64 *)p; p += 64;
+    i64 *d_lk = (i64 *)p; p += nch * M * 8;
+    i64 *d_cl = (i64 *)p; p += nch * M * 8;
+    i64 *d_ct = (i64 *)p; p += nch * M * 8;
     i64 *d_lin = (i64 *)p; p += M * 8;
     i64 *d_tin = (i64 *)p; p += M * 8;
     i64 *d_lout = (i64 *)p; p += M * 8;
     i64 *d_tout = (i64 *)p; p += M * 8;
-    i32 *d_fm = (i32 *)p;
+    i32 *d_fm = (i32 *)p; p += (F > 0 ? F : 1) * 4;
+    i32 *d_tr = (i32 *)p;
     HIP_TRY(c, hipMemsetAsync(d_st, 0, 64, c->stream));
     HIP_TRY(c, hipMemsetAsync(d_fm, 0, (size_t)(F > 0 ? F : 1) * 4, c->stream));
     if (last_known_in) HIP_TRY(c, hipMemcpyAsync(d_lin, last_known_in, (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
     if (time_unknown_in) HIP_TRY(c, hipMemcpyAsync(d_tin, time_unknown_in, (size_t)M * 8, hipMemcpyHostToDevice, c->stream));
-    k_assign_last_known<<<dim3((unsigned)((M + 63) / 64)), dim3(64), 0, c->stream>>>(
-        c->d_labels, F, M, frame_threshold, last_known_in ? d_lin : nullptr, time_unknown_in ? d_tin : nullptr, d_lout, d_tout, d_fm, d_st);
+    const dim3 cgrid((unsigned)(nch > 0 ? nch : 1), (unsigned)((M + 63) / 64));
+    if (nch > 0) k_alk_chunk_summary<<<cgrid, dim3(64), 0, c->stream>>>(c->d_labels, F, M, d_lk, d_tr);
+    k_alk_chunk_carry<<<dim3((unsigned)((M + 63) / 64)), dim3(64), 0, c->stream>>>(
+        F, M, nch, last_known_in ? d_lin : nullptr, time_unknown_in ? d_tin : nullptr, d_lk, d_tr, d_cl, d_ct, d_lout, d_tout);
+    if (nch > 0) k_alk_chunk_replay<<<cgrid, dim3(64), 0, c->stream>>>(c->d_labels, F, M, frame_threshold, d_cl, d_ct, d_fm, d_st);
     HIP_TRY(c, hipGetLastError());
     u64 st[3];
     HIP_TRY(c, hipMemcpyAsync(st, d_st, 24, hipMemcpyDeviceToHost, c->stream));
