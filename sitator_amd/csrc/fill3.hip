@@ -253,7 +253,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     const u64 errw = (u64)(S + 1 + M);
 
     if (tid < fpb) fmax[tid] = 0ull;
-    if (tid < F3_EXPN) etab[tid] = h.exptab[tid];
+    double2 etv = make_double2(0.0, 0.0);
+    if (tid < F3_EXPN) etv = h.exptab[tid];                    // in flight beside the frame loads; parked below
     for (int q = lane; q < F3_TCAP; q += 64) ttab[q] = 0u;     // stale entries must stay valid (landmark 0, ion 0)
     if (lane < IW) info[lane] = make_uint4(0u, 0u, 0u, 0u);
     // ---- phase 1a: copy this workgroup's atoms into LDS, eight independent loads per thread in flight ----
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
             }
         }
     }
+    if (tid < F3_EXPN) etab[tid] = etv;
     __syncthreads();
     // ---- phase 1b: wrap in place (Step 0), static-lattice check (helpers.pyx:57-80) ----
     for (int a = tid; a < nf * SM; a += NT) {
@@ -324,13 +326,12 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
         }
     }
     __syncthreads();
+    // fmax[fl] != 0: some static atom of frame fl moved beyond delta -> the frame takes the loose table
     if (tid < nf) {
         bool tight = DYN ? (h.frame_dmax[f0 + tid] * h.frame_dmax[f0 + tid] <= h.delta2) : (fmax[tid] == 0ull);
         if (h.force_loose) tight = false;
-        fmax[tid] = tight ? 1ull : 0ull;
         if (!tight) atomicAdd(&h.scal[2], 1ull);
     }
-    __syncthreads();
     if (h.debug_stop == 1) return;
 
     // phase-2 constants: scalar loads from the device copy of the arguments, issued after the barrier
@@ -359,7 +360,9 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
             j = ion - fl * M;
             double *mp = xyz + 3 * (fl * SM + S + j);
             const double px = mp[0], py = mp[1], pz = mp[2];
-            if (fmax[fl] != 0ull) {
+            bool tight = DYN ? (h.frame_dmax[f0 + fl] * h.frame_dmax[f0 + fl] <= h.delta2) : (fmax[fl] == 0ull);
+            if (h.force_loose) tight = false;
+            if (tight) {
                 const int b = bin_of3<CELL>(P, px, py, pz, g.tG0, g.tG1, g.tG2);
                 const i32 lo = g.t_off[b];
                 nL = g.t_off[b + 1] - lo; mylist = g.t_list + lo; mycrit = g.t_crit + lo;
