@@ -1,42 +1,56 @@
-// fit_centers (util/DotProdClassifier.pyx:199-315), exact AND parallel: "speculate, walk, verify".
+// fit_centers (util/DotProdClassifier.pyx:199-315), exact AND parallel: "speculate, walk, verify, commit".
 //
-// The reference streams rows in order; row i either founds a cluster or joins argmax_k cos(c_k, x_i),
-// updating c_k's running mean -- so every decision depends on all earlier rows.
-// k_fit_stream (cluster.hip) does exactly that with one workgroup.  Here the same result is produced
-// in parallel, for a batch of B rows at a time:
-//   A  speculate  (lane per row)    decide every row against the centres AS OF THE BATCH START; record the
-//                                   centres that share a dimension with the row (only those can score != 0).
-//                                   The batch is cut before the first row that founds a cluster.
-//   B  walk       (wave per centre) centre k applies, IN ROW ORDER, the running-mean updates of the rows that
-//                                   were speculated to join it (bit-for-bit the reference's arithmetic) and
-//                                   publishes every intermediate state as a VERSION, keyed by the joining row.
-//                                   Centres evolve independently given the decisions, so K waves run in
-//                                   parallel, and the sequential chain of a centre is its joins only: multiply,
-//                                   add, divide (norms and scores are computed off the chain, in step C).
-//   C  verify     (lane per row)    score every row against the version of each overlapping centre it sees
-//                                   (the one left by that centre's last join before the row: binary search in
-//                                   the centre's sorted join list) and re-decide it.  By induction the first row whose decision differs from
-//                                   its speculation is the first wrong one: rows before it are exact.  The
-//                                   batch is then re-walked up to that row, committed, and the stream continues
-//                                   from there (state is exact again).
-// Rows that found clusters, rows whose join grows a centre's support (later rows' overlap lists would be
-// stale) and rows exceeding a capacity are applied one at a time by k_ff_serial with the same arithmetic.
-// Centres are kept sparse (sorted support, <= FF_CS entries); dot products sum in ascending dimension
-// order, norms sum in ascending order: identical to dense left-to-right sums (zeros add nothing).
+// The reference streams rows in order; row i either founds a cluster or joins argmax_k cos(c_k, x_i), updating
+// c_k's running mean -- so every decision depends on all earlier rows.  k_fit_stream (cluster.hip)
+// does exactly that with one workgroup.  Here the same result is produced in parallel, a batch of rows at a time,
+// by four kernels per step, enqueued without the host looking at anything in between (all control state lives in a
+// device block, FSCtl; the host reads it back once per chunk of steps):
+//   A  speculate  decide every row of the batch against the centres AS OF THE BATCH START.  A group of lanes per row,
+//                 a lane per (row dimension, centre listed under it): three memory round trips per row.  The row's
+//                 candidates (the centres that share a dimension with it: only those can score != 0) are recorded,
+//                 and the row sets its bit in the joined centre's bitmap (two levels: rows, words).
+//   B  walk       a wave per centre applies, IN ROW ORDER (the bitmap is the sorted join list), the running-mean
+//                 updates of the rows speculated to join it -- bit for bit the reference's arithmetic -- and publishes
+//                 every intermediate state as a VERSION keyed by the joining row.  Centres evolve independently given
+//                 the decisions, and the sequential chain of a centre is its joins only: multiply, add, divide.
+//   C  verify     re-decide every row against the version of each candidate it sees (the one left by that centre's
+//                 last join before the row: highest set bit below the row in the centre's bitmap).  By induction the
+//                 first row whose decision differs from its speculation is the first wrong one; rows before it are
+//                 exact, and so is ITS re-decision.
+//   D  commit     cut = first row that is wrong / founds a cluster.  Every centre takes the version left by its last
+//                 join before the cut (no re-walk); one wave applies row `cut` itself with its verified decision
+//                 (founding a cluster, or a join that may grow the centre's support), publishes support growth to the
+//                 per-dimension lists and writes the control block of the next step.  When the batch was cut at its
+//                 very first row by a founding row, the same wave keeps deciding and applying rows one at a time
+//                 while they found clusters (the first frames of a trajectory, a stream of cluster centres).
+// Centres are kept sparse (sorted support, <= FS_CS entries); dot products sum in ascending dimension order, norms
+// sum in ascending order: identical to dense left-to-right sums (zeros add nothing).  A capacity that does not fit
+// (support, candidates, centres per dimension) stops the stream with the state exact as of that row; the caller
+// continues with the serial dense kernel.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "sit_internal.h"
 
-#define FF_CS 64        // support entries per centre (= lanes of the walking wave)
-#define FF_DC 64        // centres listed per landmark dimension
-#define FF_OC 64        // overlapping centres recorded per row (C5 rows overlap 40-60 centres)
-#define FF_BMAX 65536   // rows per batch
-#define FF_LOG 2048     // support-growth records per walk
-#define FF_NEW (-1)
-#define FF_BREAK (-2)   // row must be applied serially (zero row, capacity)
+#define FS_CS 64                  // support entries per centre (= lanes of the walking wave)
+#define FS_DC 64                  // centres listed per landmark dimension
+#define FS_OC 64                  // candidates recorded per row (C5 rows overlap 40-60 centres)
+#define FS_BMAX 65536             // rows per batch
+#define FS_W0 (FS_BMAX / 64)      // bitmap words per centre, level 0 (bit = batch row)
+#define FS_W1 (FS_W0 / 64)        // level 1 (bit = level-0 word is non-zero)
+#define FS_LOG 2048               // support-growth records per walk
+#define FS_NP 8                   // row entries staged per joining row
+#define FS_TAIL 32                // rows the commit may apply one at a time
+#define FS_NEW (-1)
+#define FS_BREAK (-2)             // row must go the serial way (zero row, capacity)
+#define FS_CHUNK 64               // steps enqueued between two looks at the control block
+#define FS_TRACE_CAP (1 << 20)
 
-struct FFRows {
+namespace {
+
+struct FSRows {
     const i32 *nnz, *idx;
     const double *val;
     const i64 *weights;   // null => 1
@@ -44,89 +58,87 @@ struct FFRows {
     int width;            // slots per row
 };
 
-struct FFState {
-    i32 *cs_n, *cs_idx;
+// control block of one step (two of them: a step reads its own and writes the next one's)
+struct FSCtl {
+    i32 first_new, first_bad, log_n, flags;   // flags: a capacity was exceeded (state exact as of pos)
+    i32 why, K, nb, B;                        // why: 1 centres per dimension, 2 zero row / candidates, 4 centres, 8 support
+    i64 pos, nrows;
+    i32 halt;                                 // 0 running, 1 stream done, 2 centre arrays must grow, 3 capacity (flags)
+    i32 steps, bad_steps, single_rows;
+    i64 trace_n;
+    i32 pad[14];
+};
+static_assert(sizeof(FSCtl) == 128, "FSCtl layout");
+
+struct FS {
+    i32 *cs_n, *cs_idx;       // centres: support size, sorted support [Kcap][FS_CS]
     double *cs_val;
     i64 *c_cnt;
     double *c_nrm;
-    i32 *dc_n, *dc_list;
-    i32 *K;               // device scalar
-    i32 *flags;           // [0] capacity overflow
-    i32 *why;             // which capacity: 1 centres per dimension, 2 serial break, 4 centres, 8 support, 16 / 32 decide (dimension list / overlaps)
+    i32 *dc_n, *dc_list;      // per landmark dimension: the centres holding it
+    i32 *dec, *vdec, *ov_n, *ov_id;
+    double *xn;
+    i32 *vs_n, *vs_idx;       // versions: state of the joined centre right after batch row j joined it
+    double *vs_val, *vs_fn;   // vs_fn: sample count after the join (exact in a double)
+    i32 *log;                 // growth records of the walk: (centre, dimension, batch row)
+    u64 *bm0, *bm1;
+    FSCtl *ctl;               // [2]
+    i64 *trace;               // diagnostics (SITATOR_FF_TRACE), 6 values per step
     i64 D, Kcap;
 };
 
-#define OV(b, j, p) (b).ov_id[(i64)(p) * FF_BMAX + (j)]     // slot-major: coalesced across rows
-struct FFBatch {
-    i32 *dec, *ov_n, *ov_id;
-    double *xn;
-    i32 *vs_n, *vs_idx;       // versions: state of the joined centre right after batch row j joined it
-    double *vs_val;
-    i32 *first_new, *first_bad;
-    i32 *log_n, *log;         // growth log of the last walk: (centre, dimension, batch row) triples
-    i32 *lcnt, *loff, *lcur;  // per-centre join lists of the batch: counts, offsets [K+1], fill cursors
-    i32 *lent;                // batch rows speculated to join each centre, grouped by centre (sorted by the walk)
-};
+#define OV(s, j, p) (s).ov_id[(i64)(p) * FS_BMAX + (j)]     // slot-major: coalesced across rows
 
-// value of centre c at dimension d (0 when d is outside its support); binary search in the sorted support
-__device__ __forceinline__ double ff_at(const FFState &s, i32 c, i32 d)
+// ---- small wave helpers ---------------------------------------------------------------------------------
+__device__ __forceinline__ int bc_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ double bc_d(double v, int src)
 {
-    const i32 *ix = s.cs_idx + (i64)c * FF_CS;
-    int lo = 0, hi = s.cs_n[c];
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (ix[mid] < d) lo = mid + 1; else hi = mid;
-    }
-    return (lo < s.cs_n[c] && ix[lo] == d) ? s.cs_val[(i64)c * FF_CS + lo] : 0.0;
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+__device__ __forceinline__ u64 bc_u(u64 v, int src)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), src);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ int top_bit(u64 v) { return 63 - __clzll((long long)v); }
+
+// what one wave wrote to memory is what its other lanes read next
+__device__ __forceinline__ void wave_mem_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
 }
 
-// The reference's decision for one row against the state `s` (:238-247): overlapping centres into ov[]
-// (ascending id), returns the centre joined, FF_NEW, or FF_BREAK.  `K` centres exist.
-__device__ int ff_decide(const FFState &s, const FFRows &r, i64 row, double threshold, int K,
-                         i32 *ovb, i64 ovs, int &nov, double &xn_out)
+template <int G>
+__device__ __forceinline__ u64 gballot(bool p)
 {
-    const int n = r.nnz[row];
-    nov = 0;
-    double x2 = 0.0;
-    for (int e = 0; e < n; e++) { const double v = r.val[(i64)e * r.stride + row]; x2 += v * v; }
-    const double xn = sqrt(x2);
-    xn_out = xn;
-    if (n == 0) return K == 0 ? FF_NEW : FF_BREAK;       // zero row: NaN argmax semantics, serial path
-    for (int e = 0; e < n; e++) {
-        const i32 d = r.idx[(i64)e * r.stride + row];
-        const int m = s.dc_n[d];
-        if (m > FF_DC) { atomicOr(s.why, 16); return FF_BREAK; }
-        for (int q = 0; q < m; q++) {
-            const i32 c = s.dc_list[(i64)d * FF_DC + q];
-            int p = 0;
-            while (p < nov && ovb[p * ovs] < c) p++;
-            if (p < nov && ovb[p * ovs] == c) continue;
-            if (nov == FF_OC) { atomicOr(s.why, 32); return FF_BREAK; }
-            for (int t = nov; t > p; t--) ovb[t * ovs] = ovb[(t - 1) * ovs];
-            ovb[p * ovs] = c; nov++;
-        }
-    }
-    Best b = best_empty();
-    for (int p = 0; p < nov; p++) {
-        const i32 c = ovb[p * ovs];
-        double dot = 0.0;
-        for (int e = 0; e < n; e++)
-            dot += ff_at(s, c, r.idx[(i64)e * r.stride + row]) * r.val[(i64)e * r.stride + row];
-        dot /= s.c_nrm[c];                                // :239
-        dot /= xn;                                        // :240
-        b = best_merge(b, best_of(dot, c));
-    }
-    if (nov < K) {                                        // every other centre scores exactly 0
-        i32 k0 = 0;
-        for (int p = 0; p < nov && ovb[p * ovs] == k0; p++) k0++;
-        b = best_merge(b, best_of(0.0, k0));
-    }
-    if (b.i < 0) return FF_NEW;
-    if (b.v < threshold) return FF_NEW;                   // :245-247 (NaN: false -> joins)
-    return (int)b.i;
+    const u64 b = __ballot(p);
+    if (G == 64) return b;
+    return (b >> ((threadIdx.x & 63) & ~(G - 1))) & ((1ull << (G & 63)) - 1ull);
 }
 
-// ---- lane-per-row helpers: no dependent chains of global loads -------------------------------------------
+template <int G>
+__device__ __forceinline__ Best greduce(Best b)
+{
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) {
+        Best o;
+        o.v = __shfl_xor(b.v, m); o.i = __shfl_xor((int)b.i, m); o.nan = __shfl_xor(b.nan, m);
+        b = best_merge(b, o);
+    }
+    return b;
+}
+
+template <int G>
+__device__ __forceinline__ int gmax(int v)
+{
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) { const int o = __shfl_xor(v, m); v = o > v ? o : v; }
+    return v;
+}
+
+// ---- lane-local views of a support and of a row ------------------------------------------------------------
 // First NS support entries of a centre (or of one of its versions) in registers, the rest behind pointers.
 // NS = 8 for narrow landmark bases (C2: supports of ~8), 16 for wide ones (FCC-like: ragged rows of 5-13 entries).
 template <int NS>
@@ -189,7 +201,7 @@ struct Row {
 };
 
 template <int NR>
-__device__ __forceinline__ void row_load(Row<NR> &R, const FFRows &r, i64 row)
+__device__ __forceinline__ void row_load(Row<NR> &R, const FSRows &r, i64 row)
 {
     R.n = r.nnz[row];
 #pragma unroll
@@ -199,565 +211,659 @@ __device__ __forceinline__ void row_load(Row<NR> &R, const FFRows &r, i64 row)
     }
 }
 
-// cos numerator: dot of the row with a support, ascending dimension order (:238)
+template <int NR>
+__device__ __forceinline__ i32 row_dim(const Row<NR> &R, const FSRows &r, i64 row, int e)
+{
+    i32 d = R.i[0];
+#pragma unroll
+    for (int q = 1; q < NR; q++) d = e == q ? R.i[q] : d;
+    if (e >= NR) d = r.idx[(i64)e * r.stride + row];
+    return d;
+}
+
+template <int NR>
+__device__ __forceinline__ bool row_has(const Row<NR> &R, const FSRows &r, i64 row, i32 d)
+{
+    bool has = false;
+#pragma unroll
+    for (int e = 0; e < NR; e++) has = has || (e < R.n && R.i[e] == d);
+    for (int e = NR; e < R.n; e++) has = has || r.idx[(i64)e * r.stride + row] == d;
+    return has;
+}
+
+template <int NR>
+__device__ __forceinline__ double row_norm(const Row<NR> &R, const FSRows &r, i64 row)
+{
+    double x2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < NR; e++) if (e < R.n) x2 += R.v[e] * R.v[e];
+    for (int e = NR; e < R.n; e++) { const double v = r.val[(i64)e * r.stride + row]; x2 += v * v; }
+    return sqrt(x2);
+}
+
+// cos numerator: dot of the row with a support, ascending dimension order (:238); first = first row entry the
+// support holds (-1: none)
 template <int NR, int NS>
-__device__ __forceinline__ double row_dot(const Row<NR> &R, const FFRows &r, i64 row, const Sup<NS> &S)
+__device__ __forceinline__ double row_dot(const Row<NR> &R, const FSRows &r, i64 row, const Sup<NS> &S, int &first)
 {
     double dot = 0.0;
+    first = -1;
 #pragma unroll
     for (int e = 0; e < NR; e++)
-        if (e < R.n) { bool hit; const double cv = sup_at(S, R.i[e], hit); if (hit) dot += cv * R.v[e]; }
+        if (e < R.n) {
+            bool hit;
+            const double cv = sup_at(S, R.i[e], hit);
+            if (hit) { dot += cv * R.v[e]; first = first < 0 ? e : first; }
+        }
     for (int e = NR; e < R.n; e++) {
         bool hit;
         const double cv = sup_at(S, r.idx[(i64)e * r.stride + row], hit);
-        if (hit) dot += cv * r.val[(i64)e * r.stride + row];
+        if (hit) { dot += cv * r.val[(i64)e * r.stride + row]; first = first < 0 ? e : first; }
     }
     return dot;
 }
 
-// Sorted set of centre ids: the eight smallest in registers, the rest in a per-thread LDS column (ascending).
-struct OvSet {
-    i32 r[8];
-    int nx;               // entries in the LDS column
-    i32 *x;               // x[p * 256]
-    bool overflow;
-
-    __device__ __forceinline__ void init(i32 *col)
-    {
-#pragma unroll
-        for (int q = 0; q < 8; q++) r[q] = 0x7fffffff;
-        nx = 0; x = col; overflow = false;
-    }
-    __device__ __forceinline__ int size() const
-    {
-        int n = nx;
-#pragma unroll
-        for (int q = 0; q < 8; q++) n += r[q] != 0x7fffffff;
-        return n;
-    }
-    __device__ __forceinline__ void insert(i32 c)
-    {
-#pragma unroll
-        for (int q = 0; q < 8; q++) {           // bubble c through the sorted registers; a duplicate vanishes
-            const i32 cur = r[q];
-            if (c == cur) c = 0x7fffffff;
-            const i32 lo = c < cur ? c : cur, hi = c < cur ? cur : c;
-            r[q] = lo; c = hi;
-        }
-        if (c == 0x7fffffff) return;
-        int p = 0;
-        while (p < nx && x[p * 256] < c) p++;
-        if (p < nx && x[p * 256] == c) return;
-        if (nx == FF_OC - 8) { overflow = true; return; }
-        for (int t = nx; t > p; t--) x[t * 256] = x[(t - 1) * 256];
-        x[p * 256] = c; nx++;
-    }
-    __device__ __forceinline__ i32 at(int p) const
-    {
-        if (p >= 8) return x[(p - 8) * 256];
-        i32 v = r[0];
-#pragma unroll
-        for (int q = 1; q < 8; q++) v = p == q ? r[q] : v;
-        return v;
-    }
-};
-
-// ---- A: speculate ---------------------------------------------------------------------------------
-// ff_decide for a lane per row: the overlap set lives in registers / LDS and supports are fetched with wide
-// loads, so that a row costs a handful of memory round trips instead of a hundred dependent ones.
-template <int NR, int NS>
-__global__ __launch_bounds__(256) void k_ff_speculate(FFState s, FFRows r, FFBatch b, i64 row0, int nb, double threshold)
+// smallest centre id that is not among ovl[0, m): it scores exactly 0 and is the first of the zeros
+template <int G>
+__device__ __forceinline__ i32 group_mex(const i32 *ovl, int m, int gl)
 {
-    __shared__ i32 ovx[(FF_OC - 8) * 256];
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= nb) return;
-    const int K = *s.K;
-    const i64 row = row0 + j;
+    i32 k0 = 0;
+    for (;;) {
+        bool in = false;
+        for (int p = gl; p < m; p += G) in = in || ovl[p] == k0;
+        if (!gballot<G>(in)) return k0;
+        k0++;
+    }
+}
+
+// ---- the reference's decision for one row (:238-247), a group of G lanes on it ----------------------------------
+// Scores the row against the centres as they are in s.cs_* (lane <-> (row entry, slot of the centre list of its
+// dimension)); the candidates go to ovl[0, min(nov, FS_OC)) (LDS, private to the group).  Returns the centre joined,
+// FS_NEW or FS_BREAK, uniform over the group.
+template <int NR, int NS, int G>
+__device__ __forceinline__ int fs_decide(const FS &s, const FSRows &r, i64 row, int K, double threshold, i32 *ovl,
+                                         int gl, int &nov_out, double &xn_out)
+{
     Row<NR> R;
     row_load(R, r, row);
     const int n = R.n;
-    double x2 = 0.0;
-#pragma unroll
-    for (int e = 0; e < NR; e++) if (e < n) x2 += R.v[e] * R.v[e];
-    for (int e = NR; e < n; e++) { const double v = r.val[(i64)e * r.stride + row]; x2 += v * v; }
-    const double xn = sqrt(x2);
-    OvSet ov;
-    ov.init(ovx + threadIdx.x);
-    int dec;
-    if (n == 0) dec = K == 0 ? FF_NEW : FF_BREAK;           // zero row: NaN argmax semantics, serial path
-    else {
-        bool brk = false;
-        for (int e = 0; e < n && !brk; e++) {
-            i32 d = R.i[0];
-#pragma unroll
-            for (int q = 1; q < NR; q++) if (e == q) d = R.i[q];
-            if (e >= NR) d = r.idx[(i64)e * r.stride + row];
-            const int m = s.dc_n[d];
-            if (m > FF_DC) { brk = true; break; }
-            const i32 *dl = s.dc_list + (i64)d * FF_DC;
-            for (int q0 = 0; q0 < m; q0 += 4) {              // rows of dc_list are 256-byte aligned
-                const int4 c4 = *(const int4 *)(dl + q0);
-                ov.insert(c4.x);
-                if (q0 + 1 < m) ov.insert(c4.y);
-                if (q0 + 2 < m) ov.insert(c4.z);
-                if (q0 + 3 < m) ov.insert(c4.w);
-            }
+    const double xn = row_norm(R, r, row);
+    int nov = 0;
+    Best best = best_empty();
+    for (int t0 = 0; (t0 >> 3) < n; t0 += G) {                  // eight slots per entry and round
+        const int t = t0 + gl, e = t >> 3;
+        const bool live = e < n;
+        i32 d = 0, c0 = 0;
+        int m = 0;
+        if (live) {
+            d = row_dim(R, r, row, e);
+            m = s.dc_n[d];
+            c0 = s.dc_list[(i64)d * FS_DC + (t & 7)];           // in flight beside the length
         }
-        if (brk || ov.overflow) dec = FF_BREAK;
-        else {
-            const int nov = ov.size();
-            Best best = best_empty();
-            for (int p = 0; p < nov; p++) {
-                const i32 c = ov.at(p);
+        const int mmax = gmax<G>(m);
+        for (int q0 = 0; q0 < mmax; q0 += 8) {
+            const int q = q0 + (t & 7);
+            bool uniq = false;
+            i32 c = 0;
+            if (live && q < m) {
+                c = q0 == 0 ? c0 : s.dc_list[(i64)d * FS_DC + q];
                 Sup<NS> S;
-                sup_load(S, s.cs_idx + (i64)c * FF_CS, s.cs_val + (i64)c * FF_CS, s.cs_n[c]);
-                double dot = row_dot(R, r, row, S);
-                dot /= s.c_nrm[c];                            // :239
-                dot /= xn;                                    // :240
-                best = best_merge(best, best_of(dot, c));
+                sup_load(S, s.cs_idx + (i64)c * FS_CS, s.cs_val + (i64)c * FS_CS, s.cs_n[c]);
+                const double nrm = s.c_nrm[c];
+                int first;
+                double dot = row_dot(R, r, row, S, first);
+                uniq = first == e;                              // a centre met under an earlier entry is scored there
+                if (uniq) {
+                    dot /= nrm;                                 // :239
+                    dot /= xn;                                  // :240
+                    best = best_merge(best, best_of(dot, c));
+                }
             }
-            if (nov < K) {                                    // every other centre scores exactly 0
-                i32 k0 = 0;
-                for (int p = 0; p < nov && ov.at(p) == k0; p++) k0++;
-                best = best_merge(best, best_of(0.0, k0));
+            const u64 ub = gballot<G>(uniq);
+            if (uniq) {
+                const int p = nov + __popcll(ub & ((1ull << gl) - 1ull));
+                if (p < FS_OC) ovl[p] = c;
             }
-            dec = (best.i < 0 || best.v < threshold) ? FF_NEW : (int)best.i;   // :245-247 (NaN: false -> joins)
-            if (dec >= 0) {                                   // the joined centre must be in the list step C reads
-                ov.insert(dec);
-                if (ov.overflow) dec = FF_BREAK;
-            }
+            nov += __popcll(ub);
         }
     }
-    const int nov = ov.size();
-    for (int p = 0; p < nov; p++) OV(b, j, p) = ov.at(p);
-    b.dec[j] = dec; b.ov_n[j] = nov; b.xn[j] = xn;
-    if (dec >= 0) atomicAdd(&b.lcnt[dec], 1);
-    if (dec < 0) atomicMin(b.first_new, j);
+    __builtin_amdgcn_wave_barrier();
+    best = greduce<G>(best);
+    nov_out = nov; xn_out = xn;
+    if (n == 0) return K == 0 ? FS_NEW : FS_BREAK;              // zero row: NaN argmax semantics, serial path
+    if (nov > FS_OC) return FS_BREAK;
+    if (nov < K) best = best_merge(best, best_of(0.0, group_mex<G>(ovl, nov, gl)));   // every other centre scores exactly 0
+    return (best.i < 0 || best.v < threshold) ? FS_NEW : (int)best.i;                  // :245-247 (NaN: false -> joins)
 }
 
-// wave-uniform broadcasts from a lane known to be uniform (v_readlane instead of an LDS permute)
-__device__ __forceinline__ int bc_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
-__device__ __forceinline__ double bc_d(double v, int src)
+// ---- A: speculate ---------------------------------------------------------------------------------
+template <int NR, int NS, int G>
+__device__ __forceinline__ void fs_speculate(const FS &s, const FSRows &r, FSCtl *ctl, int nb, int K, i64 pos,
+                                             double threshold, i32 *ovl)
 {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
-}
-__device__ __forceinline__ i64 bc_l(i64 v, int src)
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffll), src);
-    const int hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
-    return ((i64)hi << 32) | lo;
+    const int gl = threadIdx.x & (G - 1);
+    const int j = (int)(((i64)blockIdx.x * 256 + threadIdx.x) / G);
+    if (j >= nb) return;                                        // uniform over the group
+    int nov;
+    double xn;
+    const int dec = fs_decide<NR, NS, G>(s, r, pos + j, K, threshold, ovl, gl, nov, xn);
+    const int keep = nov < FS_OC ? nov : FS_OC;
+    for (int p = gl; p < keep; p += G) OV(s, j, p) = ovl[p];
+    if (gl == 0) {
+        s.dec[j] = dec; s.ov_n[j] = nov; s.xn[j] = xn;
+        if (dec >= 0) {
+            atomicOr((unsigned long long *)&s.bm0[(i64)dec * FS_W0 + (j >> 6)], 1ull << (j & 63));
+            atomicOr((unsigned long long *)&s.bm1[(i64)dec * FS_W1 + (j >> 12)], 1ull << ((j >> 6) & 63));
+        } else atomicMin(&ctl->first_new, j);
+    }
 }
 
-#ifdef FF_PROFILE
-__device__ unsigned long long ff_prof[8];   // cycles: sort, group-head, joins; counts: joins, groups, waves; max wave cycles
-#define FF_T(x) const long long x = clock64()
-#define FF_ACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&ff_prof[i], (unsigned long long)(v)); } while (0)
-extern "C" void sit_debug_ff_prof(unsigned long long *out, int reset)
+template <int NR, int NS>
+__global__ __launch_bounds__(256) void k_fs_speculate(FS s, FSRows r, int par, double threshold)
 {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_prof), sizeof(ff_prof));
-    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(ff_prof), z, sizeof(z)); }
+    __shared__ i32 ovl[16 * FS_OC];
+    FSCtl *ctl = s.ctl + par;
+    if (ctl->halt) return;
+    const int nb = ctl->nb, K = ctl->K;
+    const i64 pos = ctl->pos;
+    // small batches: a wave per row (latency); large ones: sixteen lanes per row (throughput)
+    if (nb <= 16384) fs_speculate<NR, NS, 64>(s, r, ctl, nb, K, pos, threshold, ovl + (threadIdx.x >> 6) * FS_OC);
+    else fs_speculate<NR, NS, 16>(s, r, ctl, nb, K, pos, threshold, ovl + (threadIdx.x >> 4) * FS_OC);
 }
-#else
-#define FF_T(x)
-#define FF_ACC(i, v)
-#endif
+
+// ---- the join lists: bitmaps --------------------------------------------------------------------------------
+// last batch row < cut that was speculated to join centre k (-1: none).  l1 = this lane's level-1 word (lanes
+// < FS_W1, else 0).  Wave-uniform result.
+__device__ __forceinline__ int last_join_below(const FS &s, int k, int cut, u64 l1, int lane)
+{
+    if (cut <= 0) return -1;
+    const int wcut = (cut - 1) >> 6;                            // last word holding rows < cut
+    const int lw = lane * 64;                                   // first word under this lane's level-1 word
+    u64 m = l1;
+    if (lane >= FS_W1 || lw > wcut) m = 0;
+    else if (lw + 63 > wcut) m &= (2ull << (wcut - lw)) - 1ull;
+    for (int it = 0; it < 3; it++) {
+        const u64 nz = __ballot(m != 0);
+        if (!nz) return -1;
+        const int hl = top_bit(nz);
+        const int hb = top_bit(bc_u(m, hl));
+        const int W = hl * 64 + hb;
+        u64 word = s.bm0[(i64)k * FS_W0 + W];
+        if (W == wcut) { const int top = (cut - 1) & 63; if (top < 63) word &= (2ull << top) - 1ull; }
+        if (word) return W * 64 + top_bit(word);
+        if (lane == hl) m &= ~(1ull << hb);
+    }
+    return -1;
+}
+
+// one lane's version of the same question, for row j of the verify step: rows strictly below j
+__device__ __forceinline__ int lane_last_join_below(const FS &s, i32 k, int j)
+{
+    const u64 *b0 = s.bm0 + (i64)k * FS_W0, *b1 = s.bm1 + (i64)k * FS_W1;
+    const int w = j >> 6;
+    const u64 here = b0[w] & ((1ull << (j & 63)) - 1ull);
+    if (here) return w * 64 + top_bit(here);
+    int l = w >> 6;
+    u64 x = b1[l] & ((1ull << (w & 63)) - 1ull);
+    while (!x && l > 0) { l--; x = b1[l]; }
+    if (!x) return -1;
+    const int w2 = l * 64 + top_bit(x);
+    return w2 * 64 + top_bit(b0[w2]);
+}
 
 // ---- B: walk ----------------------------------------------------------------------------------------
-// One wave per centre; lane i holds support entry i.  The walked state goes to the shadow arrays.
+// One wave per centre; lane i holds support entry i.
 struct Walker {
     i32 idx;
     double val;
     int sn, k, lane;
     double cnt;            // sample count, exact in a double (< 2^53)
-    i64 cnt_i;
-    double nrm;
-    bool touched;
 
-    __device__ __forceinline__ void load(const FFState &s, int k_, int lane_)
+    __device__ __forceinline__ void load_state(const FS &s, int k_, int lane_)
     {
         k = k_; lane = lane_;
         sn = s.cs_n[k];
-        idx = lane < sn ? s.cs_idx[(i64)k * FF_CS + lane] : 0x7fffffff;
-        val = lane < sn ? s.cs_val[(i64)k * FF_CS + lane] : 0.0;
-        cnt_i = s.c_cnt[k];
-        cnt = (double)cnt_i;
-        nrm = s.c_nrm[k];
-        touched = false;
+        idx = lane < sn ? s.cs_idx[(i64)k * FS_CS + lane] : 0x7fffffff;
+        val = lane < sn ? s.cs_val[(i64)k * FS_CS + lane] : 0.0;
+        cnt = (double)s.c_cnt[k];
     }
-    __device__ __forceinline__ void store(const FFState &o)
+    __device__ __forceinline__ void load_version(const FS &s, int k_, int lane_, int pj)
     {
-        if (touched) {                                      // norm of the final state (:288), ascending sum
-            double s2 = 0.0;
-            for (int i = 0; i < sn; i++) { const double vi = bc_d(val, i); s2 += vi * vi; }
-            nrm = sqrt(s2);
-        }
-        if (lane < sn) { o.cs_idx[(i64)k * FF_CS + lane] = idx; o.cs_val[(i64)k * FF_CS + lane] = val; }
-        if (lane == 0) { o.cs_n[k] = sn; o.c_cnt[k] = cnt_i; o.c_nrm[k] = nrm; }
+        k = k_; lane = lane_;
+        sn = s.vs_n[pj];
+        idx = lane < sn ? s.vs_idx[(i64)pj * FS_CS + lane] : 0x7fffffff;
+        val = lane < sn ? s.vs_val[(i64)pj * FS_CS + lane] : 0.0;
+        cnt = s.vs_fn[pj];
     }
-    // Row jj (all arguments wave-uniform) joins this centre: running-mean update (:283-288), then the new state
-    // is published as version jj.  false = a capacity was hit (the walk is void from jj on).
-    // MODE 0: rows of at most four entries, all in registers.  MODE 1: up to twelve, entries 4..11 staged in LDS by
-    // group().  MODE 2: anything, entries beyond the fourth read from memory.  Modes 0 and 1 have no global load in
-    // them: on gfx9 stores and loads share vmcnt, so a single load anywhere in the join loop would make every join
-    // wait for the previous join's version stores.
-    template <int MODE>
-    __device__ __forceinline__ bool join(const FFRows &r, const FFBatch &b, i64 row, int jj, int n, i64 w,
-                                         i32 qi0, i32 qi1, i32 qi2, i32 qi3, double qv0, double qv1, double qv2, double qv3,
-                                         const i32 *xi, const double *xv)
+    __device__ __forceinline__ void store_state(const FS &s)
     {
-#define ROW_IDX(e) ((e) == 0 ? qi0 : (e) == 1 ? qi1 : (e) == 2 ? qi2 : (MODE == 0 || (e) == 3) ? qi3 : MODE == 1 ? xi[(e) - 4] : r.idx[(i64)(e) * r.stride + row])
-#define ROW_VAL(e) ((e) == 0 ? qv0 : (e) == 1 ? qv1 : (e) == 2 ? qv2 : (MODE == 0 || (e) == 3) ? qv3 : MODE == 1 ? xv[(e) - 4] : r.val[(i64)(e) * r.stride + row])
-        const double fo = cnt, fn = cnt + (double)w;          // exact: integers below 2^53
-        val *= fo;
+        double s2 = 0.0;                                        // norm of the state (:288), ascending sum
+        for (int i = 0; i < sn; i++) { const double vi = bc_d(val, i); s2 += vi * vi; }
+        if (lane < sn) { s.cs_idx[(i64)k * FS_CS + lane] = idx; s.cs_val[(i64)k * FS_CS + lane] = val; }
+        if (lane == 0) { s.cs_n[k] = sn; s.c_cnt[k] = (i64)cnt; s.c_nrm[k] = sqrt(s2); }
+    }
+    __device__ __forceinline__ void publish(const FS &s, int jj)
+    {
+        if (lane < sn) { s.vs_idx[(i64)jj * FS_CS + lane] = idx; s.vs_val[(i64)jj * FS_CS + lane] = val; }
+        if (lane == 0) { s.vs_n[jj] = sn; s.vs_fn[jj] = cnt; }
+    }
+    // The general join (:283-288): batch row jj (n entries, the first FS_NP of them at ri / rv, weight fn - fo) joins
+    // this centre and may add dimensions to its support.  LOGGED: growth goes to the walk's log (published at the
+    // commit); otherwise straight into the per-dimension lists.  false = a capacity was hit and the centre is
+    // unchanged (the walk is void from jj on / the stream stops before this row).
+    template <bool LOGGED>
+    __device__ __forceinline__ bool join_general(const FS &s, const FSRows &r, FSCtl *ctl, i64 row, int jj, int n,
+                                                 double fo, double fn, const i32 *ri, const double *rv)
+    {
+        int extra = 0;                                          // capacity first: how many dimensions are new?
+        bool dcfull = false;
         for (int e = 0; e < n; e++) {
-            const i32 d = ROW_IDX(e);
-            const double v = ROW_VAL(e);
-            const unsigned long long hit = __ballot(idx == d);
-            if (hit) { if (idx == d) val += v; continue; }
-            // the centre gains dimension d (0 * fo + v): sorted insertion across the lanes, and a log
-            // record so that later rows holding d without listing this centre are invalidated
-            int slot_l = 0;
-            if (lane == 0) slot_l = atomicAdd(b.log_n, 1);
-            slot_l = __builtin_amdgcn_readfirstlane(slot_l);
-            if (sn == FF_CS || slot_l >= FF_LOG) {
-                if (lane == 0) atomicMin(b.first_bad, jj);       // capacity: this row goes the serial way
-                return false;
+            const i32 d = e < FS_NP ? ri[e] : r.idx[(i64)e * r.stride + row];
+            if (!__ballot(idx == d)) { extra++; if (!LOGGED && s.dc_n[d] >= FS_DC) dcfull = true; }
+        }
+        int slot0 = 0;
+        if (LOGGED && extra && sn + extra <= FS_CS) {
+            if (lane == 0) slot0 = atomicAdd(&ctl->log_n, extra);
+            slot0 = __builtin_amdgcn_readfirstlane(slot0);
+            if (slot0 + extra > FS_LOG) {                       // the records that fit must not be read as growth
+                if (lane == 0) for (int q = slot0; q < FS_LOG; q++) s.log[3 * q + 2] = 0x7fffffff;
+                extra = FS_CS + 1;
             }
-            if (lane == 0) { b.log[3 * slot_l] = k; b.log[3 * slot_l + 1] = d; b.log[3 * slot_l + 2] = jj; }
+        }
+        if (sn + extra > FS_CS || dcfull) {
+            if (LOGGED) { if (lane == 0) atomicMin(&ctl->first_bad, jj); }
+            else if (lane == 0) { ctl->flags = 1; atomicOr(&ctl->why, dcfull ? 1 : 8); }
+            return false;
+        }
+        double t = val * fo;
+        for (int e = 0; e < n; e++) {
+            const i32 d = e < FS_NP ? ri[e] : r.idx[(i64)e * r.stride + row];
+            const double v = e < FS_NP ? rv[e] : r.val[(i64)e * r.stride + row];
+            if (__ballot(idx == d)) { if (idx == d) t += v; continue; }
+            // the centre gains dimension d (0 * fo + v): sorted insertion across the lanes
+            if (lane == 0) {
+                if (LOGGED) { s.log[3 * slot0] = k; s.log[3 * slot0 + 1] = d; s.log[3 * slot0 + 2] = jj; }
+                else { s.dc_list[(i64)d * FS_DC + s.dc_n[d]] = k; s.dc_n[d]++; }
+            }
+            slot0++;
             const int p = __popcll(__ballot(idx < d));
             const i32 idx_up = __shfl_up(idx, 1);
-            const double val_up = __shfl_up(val, 1);
-            if (lane > p) { idx = idx_up; val = val_up; }
-            else if (lane == p) { idx = d; val = v; }
+            const double t_up = __shfl_up(t, 1);
+            if (lane > p) { idx = idx_up; t = t_up; }
+            else if (lane == p) { idx = d; t = v; }
             sn++;
         }
-        val /= fn;
-        cnt = fn; cnt_i += w;
-        touched = true;
-        if (lane < sn) { b.vs_idx[(i64)jj * FF_CS + lane] = idx; b.vs_val[(i64)jj * FF_CS + lane] = val; }
-        if (lane == 0) b.vs_n[jj] = sn;
-        return true;
-#undef ROW_IDX
-#undef ROW_VAL
-    }
-
-    // One group of <= 64 joining rows, ascending by lane.
-    // xi / xv: wave-private LDS staging, [64][8] each, for row entries 4..11
-    __device__ __forceinline__ bool group(const FFRows &r, const FFBatch &b, i64 row0, int j, bool isjoin, i32 *xi, double *xv)
-    {
-        FF_T(t0);
-        int n = 0;
-        i64 w = 1;
-        i32 i0 = 0, i1 = 0, i2 = 0, i3 = 0;
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        if (isjoin) {
-            const i64 row = row0 + j;
-            n = r.nnz[row];
-            if (r.weights) w = r.weights[row];
-            i0 = r.idx[row]; v0 = r.val[row];
-            if (r.width > 1) { i1 = r.idx[r.stride + row]; v1 = r.val[r.stride + row]; }
-            if (r.width > 2) { i2 = r.idx[2 * r.stride + row]; v2 = r.val[2 * r.stride + row]; }
-            if (r.width > 3) { i3 = r.idx[3 * r.stride + row]; v3 = r.val[3 * r.stride + row]; }
-        }
-        unsigned long long jm = __ballot(isjoin);
-        FF_ACC(3, __popcll(jm)); FF_ACC(4, 1);
-        // every load of this group has landed before the join loop starts (no vmcnt wait inside it)
-        asm volatile("" :: "v"(n), "v"(w), "v"(i0), "v"(i1), "v"(i2), "v"(i3), "v"(v0), "v"(v1), "v"(v2), "v"(v3));
-        FF_T(t1);
-        FF_ACC(1, t1 - t0);
-        const unsigned long long over4 = __ballot(n > 4), over12 = __ballot(n > 12);
-        if (over4 == 0) {
-            while (jm) {
-                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)jm) - 1);
-                jm &= jm - 1;
-                const int jj = bc_i(j, src);
-                if (!join<0>(r, b, row0 + jj, jj, bc_i(n, src), bc_l(w, src), bc_i(i0, src), bc_i(i1, src), bc_i(i2, src),
-                             bc_i(i3, src), bc_d(v0, src), bc_d(v1, src), bc_d(v2, src), bc_d(v3, src), nullptr, nullptr)) return false;
-            }
-        } else if (over12 == 0) {
-            // stage entries 4..11 of every joining row in LDS (one trip to memory for the whole group)
-            if (isjoin)
-                for (int e = 4; e < n; e++) {
-                    xi[lane * 8 + e - 4] = r.idx[(i64)e * r.stride + row0 + j];
-                    xv[lane * 8 + e - 4] = r.val[(i64)e * r.stride + row0 + j];
-                }
-            __builtin_amdgcn_s_waitcnt(0);                      // vmcnt(0) expcnt(0) lgkmcnt(0): staged before the loop
-            __builtin_amdgcn_wave_barrier();
-            while (jm) {
-                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)jm) - 1);
-                jm &= jm - 1;
-                const int jj = bc_i(j, src);
-                if (!join<1>(r, b, row0 + jj, jj, bc_i(n, src), bc_l(w, src), bc_i(i0, src), bc_i(i1, src), bc_i(i2, src),
-                             bc_i(i3, src), bc_d(v0, src), bc_d(v1, src), bc_d(v2, src), bc_d(v3, src), xi + src * 8, xv + src * 8)) return false;
-            }
-        } else {
-            while (jm) {
-                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)jm) - 1);
-                jm &= jm - 1;
-                const int jj = bc_i(j, src);
-                if (!join<2>(r, b, row0 + jj, jj, bc_i(n, src), bc_l(w, src), bc_i(i0, src), bc_i(i1, src), bc_i(i2, src),
-                             bc_i(i3, src), bc_d(v0, src), bc_d(v1, src), bc_d(v2, src), bc_d(v3, src), nullptr, nullptr)) return false;
-            }
-        }
-        FF_T(t2);
-        FF_ACC(2, t2 - t1);
+        val = t / fn;
+        cnt = fn;
         return true;
     }
 };
 
-#define FF_LCAP 8192       // LDS sort buffer (entries) of the walk
-
-// The batch rows speculated to join centre k were grouped by k_ff_scatter (in arbitrary order): the workgroup sorts
-// them in LDS (bitonic), writes the sorted list back (step C searches it) and wave 0 applies the joins in order.
-__global__ __launch_bounds__(256) void k_ff_walk(FFState s, FFState o, FFRows r, FFBatch b, i64 row0, int nb)
+__device__ __forceinline__ int wave_excl_scan(int x, int lane, int &total)
 {
-    __shared__ i32 ent[FF_LCAP];
-    __shared__ i32 xi[64 * 8];
-    __shared__ double xv[64 * 8];
-    {   // the batch ends before the first row that founds a cluster (speculation ran just before)
-        const int fn = *b.first_new;
-        if (fn < nb) nb = fn;
-    }
-    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    FF_T(tw0);
-    const int lo = b.loff[k], n_ent = b.loff[k + 1] - lo;
+    int v = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
+    total = __shfl(v, 63);
+    return v - x;
+}
+
+__device__ __forceinline__ double wave_incl_scan(double x, int lane)      // exact: integers below 2^53
+{
+    double v = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(v, o); if (lane >= o) v += t; }
+    return v;
+}
+
+struct WalkLds {
+    unsigned short lst[4096];        // joining rows of the current 4096-row chunk, ascending
+    double addm[64 * FS_CS];         // [join][support slot]: what the joining row adds to the slot
+    double scf[64 * 4];              // per join: fo, fn, 1 / fn, -
+    i32 jl[64], nl[64];              // per join: batch row, entries
+    i32 supl[FS_CS];                 // the support, for the joins to look their dimensions up
+    i32 rowi[64 * FS_NP];            // first entries of the joining rows
+    double rowv[64 * FS_NP];
+};
+
+__device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSCtl *ctl, WalkLds &L, int k, int jlim, i64 pos, int lane)
+{
+    unsigned short *lst = L.lst;
+    double *addm = L.addm, *scf = L.scf, *rowv = L.rowv;
+    i32 *jl = L.jl, *nl = L.nl, *supl = L.supl, *rowi = L.rowi;
+    const u64 l1 = lane < FS_W1 ? s.bm1[(i64)k * FS_W1 + lane] : 0ull;
+    if (!__ballot(l1 != 0)) return;
     Walker wk;
-    if (n_ent == 0) {                                       // untouched centre: the shadow state is a copy
-        if (tid < 64) { wk.load(s, k, lane); wk.store(o); }
-        return;
-    }
-    if (n_ent > FF_LCAP) {
-        // too many joins for the LDS buffer: wave 0 finds them by scanning the decisions (already in row order)
-        if (tid >= 64) return;
-        wk.load(s, k, lane);
-        int filled = 0;
-        bool dead = false;                                  // a capacity was hit: keep listing, stop joining
-        for (int j0 = 0; j0 < nb; j0 += 64) {
-            const int j = j0 + lane;
-            const bool isjoin = j < nb && b.dec[j] == k;
-            const unsigned long long jm = __ballot(isjoin);
-            if (isjoin) b.lent[lo + filled + __popcll(jm & ((1ull << lane) - 1ull))] = j;
-            filled += __popcll(jm);
-            if (dead || !jm) continue;
-            if (j0 > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;   // void rows
-            dead = !wk.group(r, b, row0, j, isjoin, xi, xv);
-        }
-        // joins past the cut of the batch are not listed: step C never looks past the cut either
-        for (int t = filled + lane; t < n_ent; t += 64) b.lent[lo + t] = 0x7fffffff;
-        if (!dead) wk.store(o);
-        return;
-    }
-    int P = 64;
-    while (P < n_ent) P <<= 1;
-    for (int t = tid; t < P; t += 256) ent[t] = t < n_ent ? b.lent[lo + t] : 0x7fffffff;
-    __syncthreads();
-    for (int k2 = 2; k2 <= P; k2 <<= 1)
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-            for (int t = tid; t < P; t += 256) {
-                const int x = t ^ j2;
-                if (x > t) {
-                    const i32 a = ent[t], c = ent[x];
-                    if ((a > c) == ((t & k2) == 0)) { ent[t] = c; ent[x] = a; }
-                }
+    wk.load_state(s, k, lane);
+    const int nwords = (jlim + 63) >> 6;
+    for (int ch = 0; ch * 64 < nwords; ch++) {
+        const u64 l1c = bc_u(l1, ch);
+        if (!l1c) continue;
+        const int wi = ch * 64 + lane;
+        u64 word = ((l1c >> lane) & 1ull) ? s.bm0[(i64)k * FS_W0 + wi] : 0ull;
+        const int base = wi * 64;
+        if (base + 64 > jlim) word = base >= jlim ? 0ull : word & ((1ull << (jlim - base)) - 1ull);
+        int T;
+        int p = wave_excl_scan(__popcll(word), lane, T);
+        if (T == 0) continue;
+        while (word) { lst[p++] = (unsigned short)(lane * 64 + __ffsll((long long)word) - 1); word &= word - 1; }
+        __builtin_amdgcn_wave_barrier();
+        for (int g0 = 0; g0 < T; g0 += 64) {
+            const bool isj = g0 + lane < T;
+            const int j = isj ? ch * 4096 + lst[g0 + lane] : 0x7fffffff;
+            const int Tg = T - g0 < 64 ? T - g0 : 64;
+            // rows beyond the first row known to be wrong are void
+            if (bc_i(j, 0) > __hip_atomic_load(&ctl->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            // the joining rows, a lane each
+            const i64 row = pos + (isj ? j : 0);
+            int n = 0;
+            double wd = 0.0;
+            if (isj) {
+                n = r.nnz[row];
+                wd = r.weights ? (double)r.weights[row] : 1.0;
+#pragma unroll
+                for (int e = 0; e < FS_NP; e++)
+                    if (e < r.width) {
+                        rowi[lane * FS_NP + e] = r.idx[(i64)e * r.stride + row];
+                        rowv[lane * FS_NP + e] = r.val[(i64)e * r.stride + row];
+                    }
             }
-            __syncthreads();
+            const double fn = wk.cnt + wave_incl_scan(wd, lane), fo = fn - wd;
+            scf[4 * lane] = fo; scf[4 * lane + 1] = fn; scf[4 * lane + 2] = 1.0 / fn;
+            jl[lane] = j; nl[lane] = n;
+            int s0 = 0;
+            for (;;) {
+                // joins s0.. look their dimensions up in the support as it is now
+                const int SW = wk.sn;
+                if (lane < SW) supl[lane] = wk.idx;
+                __builtin_amdgcn_wave_barrier();
+                bool grow = false;
+                if (isj && lane >= s0) {
+                    for (int i = 0; i < SW; i++) addm[lane * SW + i] = 0.0;
+                    for (int e = 0; e < n; e++) {
+                        const i32 d = e < FS_NP ? rowi[lane * FS_NP + e] : r.idx[(i64)e * r.stride + row];
+                        const double v = e < FS_NP ? rowv[lane * FS_NP + e] : r.val[(i64)e * r.stride + row];
+                        int lo = 0, hi = SW;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (supl[mid] < d) lo = mid + 1; else hi = mid; }
+                        if (lo < SW && supl[lo] == d) addm[lane * SW + lo] = v; else grow = true;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const u64 gm = __ballot(grow);
+                const int s1 = gm ? __ffsll((long long)gm) - 1 : Tg;
+                // the chain: per join multiply, add, divide (a / b as RN(a * RN(1 / b)) with one exact-residual
+                // correction: bit-identical to the IEEE quotient) and the version
+#pragma unroll 4
+                for (int q = s0; q < s1; q++) {
+                    const double a = lane < SW ? addm[q * SW + lane] : 0.0;
+                    const double qfo = scf[4 * q], qfn = scf[4 * q + 1], qy = scf[4 * q + 2];
+                    const int jj = jl[q];
+                    const double t = wk.val * qfo + a;
+                    const double q0 = t * qy;
+                    wk.val = __builtin_fma(__builtin_fma(-q0, qfn, t), qy, q0);
+                    wk.cnt = qfn;
+                    wk.publish(s, jj);
+                }
+                if (s1 == Tg) break;
+                // join s1 adds a dimension to the support: the general way, then the rest is looked up again
+                if (!wk.join_general<true>(s, r, ctl, pos + jl[s1], jl[s1], nl[s1], scf[4 * s1], scf[4 * s1 + 1],
+                                           rowi + s1 * FS_NP, rowv + s1 * FS_NP)) return;
+                wk.publish(s, jl[s1]);
+                s0 = s1 + 1;
+                if (s0 == Tg) break;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-    for (int t = tid; t < n_ent; t += 256) b.lent[lo + t] = ent[t];
-    if (tid >= 64) return;
-    wk.load(s, k, lane);
-    FF_T(tw1);
-    FF_ACC(0, tw1 - tw0);
-    for (int base = 0; base < n_ent; base += 64) {
-        const int j = base + lane < n_ent ? ent[base + lane] : 0x7fffffff;
-        const bool valid = j < nb;
-        const int nvalid = __popcll(__ballot(valid));      // sorted by row: the valid entries are a prefix
-        if (nvalid == 0) break;
-        if (bc_i(j, 0) > __hip_atomic_load(b.first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        if (!wk.group(r, b, row0, j, valid, xi, xv)) return;
-        if (nvalid < 64) break;
     }
-    wk.store(o);
-#ifdef FF_PROFILE
-    { FF_T(tw2); FF_ACC(5, 1); if (threadIdx.x == 0) atomicMax(&ff_prof[6], (unsigned long long)(tw2 - tw0)); FF_ACC(7, tw2 - tw0); }
-#endif
 }
 
-// offsets of the per-centre join lists (single block) and the scatter that fills them
-__global__ __launch_bounds__(256) void k_ff_list_offsets(FFState s, FFBatch b)
+__global__ __launch_bounds__(64) void k_fs_walk(FS s, FSRows r, int par)
 {
-    __shared__ int part[256];
-    const int K = *s.K, t = threadIdx.x;
-    const int per = (K + 255) / 256;
-    int sum = 0;
-    for (int i = t * per; i < (t + 1) * per && i < K; i++) sum += b.lcnt[i];
-    part[t] = sum;
-    __syncthreads();
-    if (t == 0) { int acc = 0; for (int i = 0; i < 256; i++) { const int v = part[i]; part[i] = acc; acc += v; } b.loff[K] = acc; }
-    __syncthreads();
-    int acc = part[t];
-    for (int i = t * per; i < (t + 1) * per && i < K; i++) { b.loff[i] = acc; acc += b.lcnt[i]; b.lcur[i] = 0; b.lcnt[i] = 0; }
-}
-
-__global__ __launch_bounds__(256) void k_ff_scatter(FFBatch b, int nb)
-{
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= nb) return;
-    const i32 c = b.dec[j];
-    if (c < 0) return;
-    b.lent[b.loff[c] + atomicAdd(&b.lcur[c], 1)] = j;
+    __shared__ WalkLds L;
+    FSCtl *ctl = s.ctl + par;
+    if (ctl->halt) return;
+    const int K = ctl->K, lane = threadIdx.x;
+    int jlim = ctl->nb;
+    { const int fnw = ctl->first_new; if (fnw < jlim) jlim = fnw; }   // the batch ends before the first founding row
+    if (jlim <= 0) return;
+    const i64 pos = ctl->pos;
+    for (int k = blockIdx.x; k < K; k += gridDim.x) {
+        fs_walk_centre(s, r, ctl, L, k, jlim, pos, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // ---- C: verify ---------------------------------------------------------------------------------------
+// score of centre cc as row j sees it: against the version left by cc's last join before j, or the batch-start state
 template <int NR, int NS>
-__global__ __launch_bounds__(256) void k_ff_verify(FFState s, FFRows r, FFBatch b, i64 row0, int nb, double threshold)
+__device__ __forceinline__ Best fs_score_seen(const FS &s, const FSRows &r, const Row<NR> &R, i64 row, int j, i32 cc, double xn)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    {
-        const int fn = *b.first_new;
-        if (fn < nb) nb = fn;
+    const int pj = lane_last_join_below(s, cc, j);
+    Sup<NS> S;
+    double nrm;
+    if (pj < 0) {
+        sup_load(S, s.cs_idx + (i64)cc * FS_CS, s.cs_val + (i64)cc * FS_CS, s.cs_n[cc]);
+        nrm = s.c_nrm[cc];
+    } else {
+        sup_load(S, s.vs_idx + (i64)pj * FS_CS, s.vs_val + (i64)pj * FS_CS, s.vs_n[pj]);
+        nrm = sup_norm(S);
     }
-    if (j >= nb) return;
-    const int K = *s.K;
-    const int m = b.ov_n[j];
-    const i64 row = row0 + j;
+    int first;
+    double dot = row_dot(R, r, row, S, first);
+    dot /= nrm;                                                 // :239
+    dot /= xn;                                                  // :240
+    return best_of(dot, cc);
+}
+
+template <int NR, int NS, int G>
+__device__ __forceinline__ void fs_verify(const FS &s, const FSRows &r, FSCtl *ctl, int jlast, int K, i64 pos,
+                                          double threshold, i32 *ovl)
+{
+    const int gl = threadIdx.x & (G - 1);
+    const int j = (int)(((i64)blockIdx.x * 256 + threadIdx.x) / G);
+    if (j > jlast) return;                                      // uniform over the group
+    const i64 row = pos + j;
     Row<NR> R;
     row_load(R, r, row);
     const int n = R.n;
-    const double xn = b.xn[j];
-    Best best = best_empty();
-    for (int p = 0; p < m; p++) {
-        const i32 cc = OV(b, j, p);
-        // the state of centre cc as row j sees it: left by its last join before j (binary search in its sorted
-        // join list), or the batch-start state
-        int pj = -1;
-        {
-            const i32 *jl = b.lent + b.loff[cc];
-            int lo = 0, hi = b.loff[cc + 1] - b.loff[cc];
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (jl[mid] < j) lo = mid + 1; else hi = mid; }
-            if (lo > 0) pj = jl[lo - 1];
+    const double xn = s.xn[j];
+    int m = s.ov_n[j];
+    int vdec;
+    if (n == 0) vdec = K == 0 ? FS_NEW : FS_BREAK;
+    else if (m > FS_OC) vdec = FS_BREAK;
+    else {
+        Best best = best_empty();
+        for (int p = gl; p < m; p += G) {
+            const i32 cc = OV(s, j, p);
+            ovl[p] = cc;
+            best = best_merge(best, fs_score_seen<NR, NS>(s, r, R, row, j, cc, xn));
         }
-        Sup<NS> S;
-        double nrm;
-        if (pj < 0) {
-            sup_load(S, s.cs_idx + (i64)cc * FF_CS, s.cs_val + (i64)cc * FF_CS, s.cs_n[cc]);
-            nrm = s.c_nrm[cc];
-        } else {
-            sup_load(S, b.vs_idx + (i64)pj * FF_CS, b.vs_val + (i64)pj * FF_CS, b.vs_n[pj]);
-            nrm = sup_norm(S);
-        }
-        double dot = row_dot(R, r, row, S);
-        dot /= nrm;                                           // :239
-        dot /= xn;                                            // :240
-        best = best_merge(best, best_of(dot, cc));
-    }
-    if (m < K) {
-        i32 k0 = 0;
-        for (int p = 0; p < m && OV(b, j, p) == k0; p++) k0++;
-        best = best_merge(best, best_of(0.0, k0));
-    }
-    int dec = (best.i < 0 || best.v < threshold) ? FF_NEW : (int)best.i;
-    if (dec != b.dec[j]) atomicMin(b.first_bad, j);
-    // a centre that gained a dimension earlier in this batch overlaps me now, but I did not list it
-    int nl = *b.log_n;
-    if (nl > FF_LOG) nl = FF_LOG;
-    if (nl > 0) {
-        for (int q = 0; q < nl; q++) {
-            if (b.log[3 * q + 2] >= j) continue;
-            const i32 kk = b.log[3 * q], dd = b.log[3 * q + 1];
-            bool has = false;
-            for (int e = 0; e < n; e++) if (r.idx[(i64)e * r.stride + row] == dd) { has = true; break; }
-            if (!has) continue;
+        __builtin_amdgcn_wave_barrier();
+        // centres that gained one of my dimensions earlier in this batch overlap me now without being listed
+        int nlg = ctl->log_n;
+        if (nlg > FS_LOG) nlg = FS_LOG;
+        bool over = false;
+        for (int q = 0; q < nlg; q++) {
+            if (s.log[3 * q + 2] >= j) continue;
+            const i32 kk = s.log[3 * q], dd = s.log[3 * q + 1];
+            if (!row_has(R, r, row, dd)) continue;
             bool listed = false;
-            for (int p = 0; p < m; p++) if (OV(b, j, p) == kk) { listed = true; break; }
-            if (!listed) { atomicMin(b.first_bad, j); break; }
+            for (int p = gl; p < m; p += G) listed = listed || ovl[p] == kk;
+            if (gballot<G>(listed)) continue;
+            if (m == FS_OC) { over = true; break; }
+            if (gl == 0) { ovl[m] = kk; best = best_merge(best, fs_score_seen<NR, NS>(s, r, R, row, j, kk, xn)); }
+            m++;
+            __builtin_amdgcn_wave_barrier();
         }
+        if (over) vdec = FS_BREAK;
+        else {
+            best = greduce<G>(best);
+            if (m < K) best = best_merge(best, best_of(0.0, group_mex<G>(ovl, m, gl)));
+            vdec = (best.i < 0 || best.v < threshold) ? FS_NEW : (int)best.i;
+        }
+    }
+    if (gl == 0) {
+        s.vdec[j] = vdec;
+        if (vdec != s.dec[j]) atomicMin(&ctl->first_bad, j);
     }
 }
 
-// after a commit: the centres that gained dimensions become visible in the per-dimension lists
-__global__ void k_ff_apply_growth(FFState s, FFBatch b)
+template <int NR, int NS>
+__global__ __launch_bounds__(256) void k_fs_verify(FS s, FSRows r, int par, double threshold)
 {
-    if (threadIdx.x || blockIdx.x) return;
-    int nl = *b.log_n;
-    if (nl > FF_LOG) nl = FF_LOG;
-    for (int q = 0; q < nl; q++) {
-        const i32 kk = b.log[3 * q], dd = b.log[3 * q + 1];
-        if (s.dc_n[dd] >= FF_DC) { s.flags[0] = 1; atomicOr(s.why, 1); continue; }
-        s.dc_list[(i64)dd * FF_DC + s.dc_n[dd]] = kk; s.dc_n[dd]++;
-    }
-    *b.log_n = 0;
-    *b.first_new = 0x7fffffff; *b.first_bad = 0x7fffffff;       // ready for the next batch
+    __shared__ i32 ovl[16 * FS_OC];
+    FSCtl *ctl = s.ctl + par;
+    if (ctl->halt) return;
+    const int nb = ctl->nb, K = ctl->K;
+    if (nb <= 0) return;
+    int jlast = nb - 1;                                          // the first founding row is re-decided too
+    { const int fnw = ctl->first_new; if (fnw < jlast) jlast = fnw; }
+    if (nb <= 16384) fs_verify<NR, NS, 64>(s, r, ctl, jlast, K, ctl->pos, threshold, ovl + (threadIdx.x >> 6) * FS_OC);
+    else fs_verify<NR, NS, 16>(s, r, ctl, jlast, K, ctl->pos, threshold, ovl + (threadIdx.x >> 4) * FS_OC);
 }
 
-// ---- serial application of rows (founding rows, support growth, capacity breakers) -------------------
-// One thread, `count` rows in order, same arithmetic.  Stops (status) when a capacity is exceeded.
-__global__ void k_ff_serial(FFState s, FFRows r, FFBatch b, i64 row0, int count, double threshold, i32 *scratch_ov)
+// ---- D: commit -----------------------------------------------------------------------------------------
+__device__ __forceinline__ void fs_clear_bitmaps(const FS &s, int k, int nb, int lane)
 {
-    __shared__ i32 ovl[FF_OC];        // overlap list of the row being decided (LDS: the insertion sort is latency-bound)
-    (void)scratch_ov;
-    if (threadIdx.x || blockIdx.x) return;
-    int K = *s.K;
-    int processed = 0;
-    for (int q = 0; q < count; q++, processed++) {
-        const i64 row = row0 + q;
-        const int n = r.nnz[row];
-        const i64 w = r.weights ? r.weights[row] : 1;
-        int nov;
-        double xn;
-        int dec = ff_decide(s, r, row, threshold, K, ovl, 1, nov, xn);
-        if (dec == FF_BREAK) { s.flags[0] = 1; atomicOr(s.why, 2); break; }
-        if (dec == FF_NEW) {                                          // :250-260
-            if (K >= s.Kcap || n > FF_CS) { s.flags[0] = 1; atomicOr(s.why, K >= s.Kcap ? 4 : 8); break; }
-            bool ok = true;
-            for (int e = 0; e < n; e++) if (s.dc_n[r.idx[(i64)e * r.stride + row]] >= FF_DC) ok = false;
-            if (!ok) { s.flags[0] = 1; atomicOr(s.why, 1); break; }
-            for (int e = 0; e < n; e++) {
-                const i32 d = r.idx[(i64)e * r.stride + row];
-                s.cs_idx[(i64)K * FF_CS + e] = d;
-                s.cs_val[(i64)K * FF_CS + e] = r.val[(i64)e * r.stride + row];
-                s.dc_list[(i64)d * FF_DC + s.dc_n[d]] = K; s.dc_n[d]++;
-            }
-            s.cs_n[K] = n; s.c_cnt[K] = w; s.c_nrm[K] = xn;
-            K++;
-        } else {                                                      // :283-288, support may grow
-            const i32 c = dec;
-            i32 *ix = s.cs_idx + (i64)c * FF_CS;
-            double *vv = s.cs_val + (i64)c * FF_CS;
-            int sn = s.cs_n[c];
-            // merged support size
-            int extra = 0;
-            for (int e = 0; e < n; e++) {
-                const i32 d = r.idx[(i64)e * r.stride + row];
-                bool in = false;
-                for (int i = 0; i < sn; i++) if (ix[i] == d) { in = true; break; }
-                if (!in) { extra++; if (s.dc_n[d] >= FF_DC) extra = FF_CS + 1; }
-            }
-            if (sn + extra > FF_CS) { s.flags[0] = 1; atomicOr(s.why, 8); break; }
-            const double fo = (double)s.c_cnt[c], fn = (double)(s.c_cnt[c] + w);
-            for (int i = 0; i < sn; i++) vv[i] *= fo;
-            for (int e = 0; e < n; e++) {
-                const i32 d = r.idx[(i64)e * r.stride + row];
-                const double v = r.val[(i64)e * r.stride + row];
-                int p = 0;
-                while (p < sn && ix[p] < d) p++;
-                if (p < sn && ix[p] == d) vv[p] += v;
-                else {
-                    for (int t = sn; t > p; t--) { ix[t] = ix[t - 1]; vv[t] = vv[t - 1]; }
-                    ix[p] = d; vv[p] = v;                             // 0 * fo + v
-                    sn++;
-                    s.dc_list[(i64)d * FF_DC + s.dc_n[d]] = c; s.dc_n[d]++;
-                }
-            }
-            double s2 = 0.0;
-            for (int i = 0; i < sn; i++) { vv[i] /= fn; s2 += vv[i] * vv[i]; }
-            s.cs_n[c] = sn; s.c_cnt[c] += w; s.c_nrm[c] = sqrt(s2);
+    const int nwords = (nb + 63) >> 6;
+    for (int w = lane; w < nwords; w += 64) s.bm0[(i64)k * FS_W0 + w] = 0ull;
+    if (lane < FS_W1) s.bm1[(i64)k * FS_W1 + lane] = 0ull;
+}
+
+// Applies one row with its exact decision to the live state (the wave that ends the step).  pj: the version the
+// joined centre is at (-1: its stored state).  Returns false when a capacity stopped it (flags are set).
+__device__ __forceinline__ bool fs_apply_row(const FS &s, const FSRows &r, FSCtl *ctl, i64 row, int jj, int dec, int pj,
+                                             double xn, int &K, i32 *ri, double *rv, int lane)
+{
+    const int n = r.nnz[row];
+    const i64 w = r.weights ? r.weights[row] : 1;
+    if (dec == FS_BREAK) { if (lane == 0) { ctl->flags = 1; atomicOr(&ctl->why, 2); } return false; }
+    if (dec == FS_NEW) {                                          // :250-260
+        i32 d = 0;
+        double v = 0.0;
+        bool full = false;
+        if (lane < n && lane < FS_CS) { d = r.idx[(i64)lane * r.stride + row]; v = r.val[(i64)lane * r.stride + row]; full = s.dc_n[d] >= FS_DC; }
+        const bool anyfull = __ballot(full) != 0;
+        if (K >= s.Kcap || n > FS_CS || anyfull) {
+            if (lane == 0) { ctl->flags = 1; atomicOr(&ctl->why, anyfull ? 1 : (K >= s.Kcap ? 4 : 8)); }
+            return false;
+        }
+        if (lane < n) {
+            s.cs_idx[(i64)K * FS_CS + lane] = d; s.cs_val[(i64)K * FS_CS + lane] = v;
+            s.dc_list[(i64)d * FS_DC + s.dc_n[d]] = K; s.dc_n[d]++;
+        }
+        if (lane == 0) { s.cs_n[K] = n; s.c_cnt[K] = w; s.c_nrm[K] = xn; }
+        K++;
+        return true;
+    }
+    Walker wk;                                                    // :283-288 on the committed state of the centre
+    if (pj >= 0) wk.load_version(s, dec, lane, pj); else wk.load_state(s, dec, lane);
+    if (lane < FS_NP && lane < r.width) { ri[lane] = r.idx[(i64)lane * r.stride + row]; rv[lane] = r.val[(i64)lane * r.stride + row]; }
+    __builtin_amdgcn_wave_barrier();
+    const double fo = wk.cnt, fn = wk.cnt + (double)w;
+    const bool ok = wk.join_general<false>(s, r, ctl, row, jj, n, fo, fn, ri, rv);
+    if (ok || pj >= 0) wk.store_state(s);                         // not applied: the centre still takes its version
+    return ok;
+}
+
+template <int NR, int NS>
+__global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, double threshold)
+{
+    __shared__ i32 ri[FS_NP];
+    __shared__ double rv[FS_NP];
+    __shared__ i32 ovl[FS_OC];
+    FSCtl *ctl = s.ctl + par, *nxt = s.ctl + (par ^ 1);
+    const int lane = threadIdx.x;
+    if (ctl->halt) {
+        if (blockIdx.x == 0 && lane < 32) ((i32 *)nxt)[lane] = ((const i32 *)ctl)[lane];
+        return;
+    }
+    const int nb = ctl->nb, K = ctl->K;
+    int cut = nb;
+    { const int a = ctl->first_new, b = ctl->first_bad; if (a < cut) cut = a; if (b < cut) cut = b; }
+    const int single = cut < nb ? s.vdec[cut] : FS_BREAK - 1;    // verified decision of the row at the cut
+    if (blockIdx.x > 0) {
+        // centre k takes the version left by its last join before the cut
+        for (int k = blockIdx.x - 1; k < K; k += gridDim.x - 1) {
+            if (k == single) continue;
+            const u64 l1 = lane < FS_W1 ? s.bm1[(i64)k * FS_W1 + lane] : 0ull;
+            if (!__ballot(l1 != 0)) continue;
+            const int pj = last_join_below(s, k, cut, l1, lane);
+            if (pj >= 0) { Walker wk; wk.load_version(s, k, lane, pj); wk.store_state(s); }
+            fs_clear_bitmaps(s, k, nb, lane);
+        }
+        return;
+    }
+    // ---- the wave that ends the step ----
+    const i64 pos = ctl->pos;
+    int Kn = K;
+    // support growth of the committed joins becomes visible in the per-dimension lists
+    if (lane == 0) {
+        int nlg = ctl->log_n;
+        if (nlg > FS_LOG) nlg = FS_LOG;
+        for (int q = 0; q < nlg; q++) {
+            if (s.log[3 * q + 2] >= cut) continue;
+            const i32 kk = s.log[3 * q], dd = s.log[3 * q + 1];
+            if (s.dc_n[dd] >= FS_DC) { ctl->flags = 1; atomicOr(&ctl->why, 1); continue; }
+            s.dc_list[(i64)dd * FS_DC + s.dc_n[dd]] = kk; s.dc_n[dd]++;
         }
     }
-    *s.K = K;
-    // report (read back in one copy with the batch scalars) and reset the scalars for the next batch
-    b.first_new[4] = processed; b.first_new[5] = K;
-    *b.first_new = 0x7fffffff; *b.first_bad = 0x7fffffff; *b.log_n = 0;
+    wave_mem_sync();
+    int applied = 0;
+    if (cut < nb && !ctl->flags) {
+        int pj = -1;
+        if (single >= 0) {
+            const u64 l1 = lane < FS_W1 ? s.bm1[(i64)single * FS_W1 + lane] : 0ull;
+            if (__ballot(l1 != 0)) {
+                pj = last_join_below(s, single, cut, l1, lane);
+                fs_clear_bitmaps(s, single, nb, lane);
+            }
+        }
+        if (fs_apply_row(s, r, ctl, pos + cut, cut, single, pj, s.xn[cut], Kn, ri, rv, lane)) applied = 1;
+        // a batch cut at its first row by a founding row: keep going one row at a time while rows found clusters
+        if (applied && cut == 0 && single == FS_NEW) {
+            const i64 left = ctl->nrows - pos;
+            for (int q = 1; q < FS_TAIL && q < left; q++) {
+                wave_mem_sync();
+                if (Kn >= s.Kcap) break;
+                int nov;
+                double xn;
+                const int dec = fs_decide<NR, NS, 64>(s, r, pos + q, Kn, threshold, ovl, lane, nov, xn);
+                if (dec == FS_BREAK) break;                       // the next step meets it at its own first row
+                if (!fs_apply_row(s, r, ctl, pos + q, q, dec, -1, xn, Kn, ri, rv, lane)) break;
+                applied++;
+                if (dec != FS_NEW) break;
+            }
+        }
+    }
+    wave_mem_sync();
+    if (lane == 0) {
+        const int flags = ctl->flags;
+        const i64 pos2 = pos + cut + applied;
+        int B = ctl->B;
+        if (cut == nb) B = B * 2 > FS_BMAX ? FS_BMAX : B * 2;                 // every decision verified
+        else if (single != FS_NEW)                                            // a wrong speculation: the next one is
+            B = cut * 2 < 256 ? 256 : (cut * 2 > FS_BMAX ? FS_BMAX : cut * 2);  // probably about as far away
+        const i64 left = ctl->nrows - pos2;
+        int halt = 0;
+        if (flags) halt = 3;
+        else if (left <= 0) halt = 1;
+        else if (Kn + 64 > s.Kcap) halt = 2;
+        if (s.trace && ctl->trace_n < FS_TRACE_CAP) {
+            i64 *t = s.trace + 6 * ctl->trace_n;
+            t[0] = pos; t[1] = nb; t[2] = ctl->first_new < nb ? ctl->first_new : -1; t[3] = ctl->first_bad < nb ? ctl->first_bad : -1;
+            t[4] = ctl->log_n; t[5] = K;
+        }
+        nxt->first_new = 0x7fffffff; nxt->first_bad = 0x7fffffff; nxt->log_n = 0; nxt->flags = flags;
+        nxt->why = ctl->why; nxt->K = Kn; nxt->nb = halt ? 0 : (int)(left < B ? left : B); nxt->B = B;
+        nxt->pos = pos2; nxt->nrows = ctl->nrows; nxt->halt = halt;
+        nxt->steps = ctl->steps + 1; nxt->bad_steps = ctl->bad_steps + (cut < nb && single != FS_NEW ? 1 : 0);
+        nxt->single_rows = ctl->single_rows + applied;
+        nxt->trace_n = ctl->trace_n + 1;
+    }
 }
+
+}   // namespace
 
 // ---- host side ------------------------------------------------------------------------------------------
 
@@ -765,11 +871,10 @@ struct FitFast {
     bool ready = false;       // device arrays allocated for this D
     bool valid = false;       // the sparse state is the current truth (else the dense one is)
     i64 D = 0, Kcap = 0;
-    FFState st, sh;           // main + shadow (walk output)
-    FFBatch bt;
-    i32 *d_scr = nullptr;     // [FF_OC + 8]: serial scratch
-    i32 *h_ctl = nullptr;     // pinned: read-back of the batch scalars {first_new, first_bad, log_n, flags, done, K}
+    FS st;
+    FSCtl *h_ctl = nullptr;   // pinned: read-back of a control block
     void *blob = nullptr;
+    i64 *d_trace = nullptr;
 };
 
 static FitFast *ff_of(sit_ctx *c)
@@ -783,6 +888,7 @@ void fitfast_free(sit_ctx *c)
     if (!c->fitfast) return;
     FitFast *f = (FitFast *)c->fitfast;
     if (f->blob) (void)hipFree(f->blob);
+    if (f->d_trace) (void)hipFree(f->d_trace);
     if (f->h_ctl) (void)hipHostFree(f->h_ctl);
     delete f;
     c->fitfast = nullptr;
@@ -799,85 +905,88 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
 {
     if (f->blob) { (void)hipFree(f->blob); f->blob = nullptr; }
     const i64 D = c->D;
-    size_t per_state = (size_t)Kcap * (4 + FF_CS * 12 + 16) + 4096;
-    size_t total = 2 * per_state + (size_t)D * (4 + FF_DC * 4) + 8192
-                 + (size_t)FF_BMAX * (4 + 4 + 4 + FF_OC * 4 + 8 + 4 + 4 + FF_CS * 12) + (size_t)Kcap * 12 + 65536 + (size_t)FF_LOG * 12 + 4096;
+    const size_t total = (size_t)Kcap * (4 + FS_CS * 12 + 16 + FS_W0 * 8 + FS_W1 * 8) + (size_t)D * (4 + FS_DC * 4)
+                       + (size_t)FS_BMAX * (4 + 4 + 4 + FS_OC * 4 + 8 + 4 + 8 + FS_CS * 12) + (size_t)FS_LOG * 12 + 65536;
     HIP_TRY(c, hipMalloc(&f->blob, total));
-    if (!f->h_ctl) HIP_TRY(c, hipHostMalloc((void **)&f->h_ctl, 64));
+    if (!f->h_ctl) HIP_TRY(c, hipHostMalloc((void **)&f->h_ctl, sizeof(FSCtl)));
     HIP_TRY(c, hipMemsetAsync(f->blob, 0, total, c->stream));
     char *p = (char *)f->blob;
-    FFState *ss[2] = {&f->st, &f->sh};
-    i32 *dc_n = (i32 *)carve(p, (size_t)D * 4);
-    i32 *dc_list = (i32 *)carve(p, (size_t)D * FF_DC * 4);
-    i32 *Kp = (i32 *)carve(p, 64);
-    i32 *flags = nullptr;     // placed next to first_new below (read back with it)
-    for (FFState *s : ss) {
-        s->cs_n = (i32 *)carve(p, (size_t)Kcap * 4);
-        s->cs_idx = (i32 *)carve(p, (size_t)Kcap * FF_CS * 4);
-        s->cs_val = (double *)carve(p, (size_t)Kcap * FF_CS * 8);
-        s->c_cnt = (i64 *)carve(p, (size_t)Kcap * 8);
-        s->c_nrm = (double *)carve(p, (size_t)Kcap * 8);
-        s->dc_n = dc_n; s->dc_list = dc_list; s->K = Kp; s->flags = flags; s->D = D; s->Kcap = Kcap;
-    }
-    f->bt.dec = (i32 *)carve(p, (size_t)FF_BMAX * 4);
-    f->bt.ov_n = (i32 *)carve(p, (size_t)FF_BMAX * 4);
-    f->bt.ov_id = (i32 *)carve(p, (size_t)FF_BMAX * FF_OC * 4);
-    f->bt.vs_n = (i32 *)carve(p, (size_t)FF_BMAX * 4);
-    f->bt.vs_idx = (i32 *)carve(p, (size_t)FF_BMAX * FF_CS * 4);
-    f->bt.vs_val = (double *)carve(p, (size_t)FF_BMAX * FF_CS * 8);
-    f->bt.xn = (double *)carve(p, (size_t)FF_BMAX * 8);
-    f->bt.first_new = (i32 *)carve(p, 64);
-    f->bt.first_bad = f->bt.first_new + 1;
-    f->bt.log_n = f->bt.first_new + 2;
-    f->st.flags = f->sh.flags = f->bt.first_new + 3;
-    f->st.why = f->sh.why = f->bt.first_new + 6;
-    f->bt.log = (i32 *)carve(p, (size_t)FF_LOG * 12);
-    f->bt.lcnt = (i32 *)carve(p, (size_t)(Kcap + 1) * 4);
-    f->bt.loff = (i32 *)carve(p, (size_t)(Kcap + 1) * 4);
-    f->bt.lcur = (i32 *)carve(p, (size_t)(Kcap + 1) * 4);
-    f->bt.lent = (i32 *)carve(p, (size_t)FF_BMAX * 4);
-    f->d_scr = (i32 *)carve(p, 256);
+    FS &s = f->st;
+    s.dc_n = (i32 *)carve(p, (size_t)D * 4);
+    s.dc_list = (i32 *)carve(p, (size_t)D * FS_DC * 4);
+    s.cs_n = (i32 *)carve(p, (size_t)Kcap * 4);
+    s.cs_idx = (i32 *)carve(p, (size_t)Kcap * FS_CS * 4);
+    s.cs_val = (double *)carve(p, (size_t)Kcap * FS_CS * 8);
+    s.c_cnt = (i64 *)carve(p, (size_t)Kcap * 8);
+    s.c_nrm = (double *)carve(p, (size_t)Kcap * 8);
+    s.bm0 = (u64 *)carve(p, (size_t)Kcap * FS_W0 * 8);
+    s.bm1 = (u64 *)carve(p, (size_t)Kcap * FS_W1 * 8);
+    s.dec = (i32 *)carve(p, (size_t)FS_BMAX * 4);
+    s.vdec = (i32 *)carve(p, (size_t)FS_BMAX * 4);
+    s.ov_n = (i32 *)carve(p, (size_t)FS_BMAX * 4);
+    s.ov_id = (i32 *)carve(p, (size_t)FS_BMAX * FS_OC * 4);
+    s.xn = (double *)carve(p, (size_t)FS_BMAX * 8);
+    s.vs_n = (i32 *)carve(p, (size_t)FS_BMAX * 4);
+    s.vs_fn = (double *)carve(p, (size_t)FS_BMAX * 8);
+    s.vs_idx = (i32 *)carve(p, (size_t)FS_BMAX * FS_CS * 4);
+    s.vs_val = (double *)carve(p, (size_t)FS_BMAX * FS_CS * 8);
+    s.log = (i32 *)carve(p, (size_t)FS_LOG * 12);
+    s.ctl = (FSCtl *)carve(p, 2 * sizeof(FSCtl));
+    s.D = D; s.Kcap = Kcap;
+    s.trace = nullptr;
+    if ((size_t)(p - (char *)f->blob) > total) { c->msg = "fit: arena layout"; return SIT_ERR_CAPACITY; }
     f->D = D; f->Kcap = Kcap; f->ready = true; f->valid = false;
     return SIT_OK;
 }
 
-// dense [K,D] + counts  ->  sparse state.  Returns false when a capacity does not fit (stay dense).
+// dense [K,D] + counts  ->  sparse state.  *fits = false when a capacity does not fit (stay dense).
 static int ff_from_dense(sit_ctx *c, FitFast *f, const double *cen, const i64 *cnt, i64 K, bool *fits)
 {
     const i64 D = c->D;
     *fits = false;
-    i64 need = K + 1024;
+    const i64 need = K + 1024;
     if (!f->ready || f->D != D || f->Kcap < need) { int rc = ff_alloc(c, f, need * 2); if (rc) return rc; }
-    std::vector<i32> cs_n((size_t)K, 0), cs_idx((size_t)(K * FF_CS), 0), dc_n((size_t)D, 0), dc_list((size_t)(D * FF_DC), 0);
-    std::vector<double> cs_val((size_t)(K * FF_CS), 0.0), nrm((size_t)K, 0.0);
+    std::vector<i32> cs_n((size_t)K, 0), cs_idx((size_t)(K * FS_CS), 0), dc_n((size_t)D, 0), dc_list((size_t)(D * FS_DC), 0);
+    std::vector<double> cs_val((size_t)(K * FS_CS), 0.0), nrm((size_t)K, 0.0);
     for (i64 k = 0; k < K; k++) {
         int n = 0;
         double s2 = 0.0;
         for (i64 d = 0; d < D; d++) {
             const double v = cen[k * D + d];
             if (v != 0.0) {
-                if (n == FF_CS || dc_n[(size_t)d] == FF_DC) return SIT_OK;
-                cs_idx[(size_t)(k * FF_CS + n)] = (i32)d; cs_val[(size_t)(k * FF_CS + n)] = v; n++;
-                dc_list[(size_t)(d * FF_DC + dc_n[(size_t)d])] = (i32)k; dc_n[(size_t)d]++;
+                if (n == FS_CS || dc_n[(size_t)d] == FS_DC) return SIT_OK;
+                cs_idx[(size_t)(k * FS_CS + n)] = (i32)d; cs_val[(size_t)(k * FS_CS + n)] = v; n++;
+                dc_list[(size_t)(d * FS_DC + dc_n[(size_t)d])] = (i32)k; dc_n[(size_t)d]++;
                 s2 += v * v;
             }
         }
         cs_n[(size_t)k] = n; nrm[(size_t)k] = std::sqrt(s2);
     }
-    const i32 K32 = (i32)K, zero = 0;
+    FS &s = f->st;
     if (K > 0) {
-        HIP_TRY(c, hipMemcpyAsync(f->st.cs_n, cs_n.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(f->st.cs_idx, cs_idx.data(), (size_t)K * FF_CS * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(f->st.cs_val, cs_val.data(), (size_t)K * FF_CS * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(f->st.c_cnt, cnt, (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(f->st.c_nrm, nrm.data(), (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(s.cs_n, cs_n.data(), (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(s.cs_idx, cs_idx.data(), (size_t)K * FS_CS * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(s.cs_val, cs_val.data(), (size_t)K * FS_CS * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(s.c_cnt, cnt, (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(s.c_nrm, nrm.data(), (size_t)K * 8, hipMemcpyHostToDevice, c->stream));
     }
-    HIP_TRY(c, hipMemcpyAsync(f->st.dc_n, dc_n.data(), (size_t)D * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(f->st.dc_list, dc_list.data(), (size_t)D * FF_DC * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(f->st.K, &K32, 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(f->st.flags, &zero, 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(s.dc_n, dc_n.data(), (size_t)D * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(s.dc_list, dc_list.data(), (size_t)D * FS_DC * 4, hipMemcpyHostToDevice, c->stream));
+    FSCtl z;
+    memset(&z, 0, sizeof(z));
+    z.K = (i32)K; z.halt = 1;
+    HIP_TRY(c, hipMemcpyAsync(s.ctl, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *fits = true;
+    return SIT_OK;
+}
+
+// the centre count lives in control block 0 between streams
+static int ff_read_K(sit_ctx *c, FitFast *f, i32 *K)
+{
+    HIP_TRY(c, hipMemcpyAsync(f->h_ctl, f->st.ctl, sizeof(FSCtl), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *K = f->h_ctl->K;
     return SIT_OK;
 }
 
@@ -886,22 +995,21 @@ int fitfast_to_dense(sit_ctx *c, std::vector<double> &cen, std::vector<i64> &cnt
 {
     FitFast *f = ff_of(c);
     i32 K32 = 0;
-    HIP_TRY(c, hipMemcpyAsync(&K32, f->st.K, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rc = ff_read_K(c, f, &K32); if (rc) return rc; }
     const i64 K = K32, D = c->D;
     *Kout = K;
     cen.assign((size_t)(K * D), 0.0); cnt.assign((size_t)K, 0);
     if (K == 0) return SIT_OK;
-    std::vector<i32> cs_n((size_t)K), cs_idx((size_t)(K * FF_CS));
-    std::vector<double> cs_val((size_t)(K * FF_CS));
+    std::vector<i32> cs_n((size_t)K), cs_idx((size_t)(K * FS_CS));
+    std::vector<double> cs_val((size_t)(K * FS_CS));
     HIP_TRY(c, hipMemcpyAsync(cs_n.data(), f->st.cs_n, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(cs_idx.data(), f->st.cs_idx, (size_t)K * FF_CS * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(cs_val.data(), f->st.cs_val, (size_t)K * FF_CS * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cs_idx.data(), f->st.cs_idx, (size_t)K * FS_CS * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cs_val.data(), f->st.cs_val, (size_t)K * FS_CS * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(cnt.data(), f->st.c_cnt, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (i64 k = 0; k < K; k++)
         for (int i = 0; i < cs_n[(size_t)k]; i++)
-            cen[(size_t)(k * D + cs_idx[(size_t)(k * FF_CS + i)])] = cs_val[(size_t)(k * FF_CS + i)];
+            cen[(size_t)(k * D + cs_idx[(size_t)(k * FS_CS + i)])] = cs_val[(size_t)(k * FS_CS + i)];
     return SIT_OK;
 }
 
@@ -925,95 +1033,95 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
 {
     FitFast *f = ff_of(c);
     *consumed = 0;
-    if (!f->valid) return SIT_OK;
-    FFRows r; r.nnz = nnz; r.idx = idx; r.val = val; r.weights = weights; r.stride = stride; r.width = width;
-    i64 pos = 0;
-    int B = 256;
-    i32 K = 0;
-    // wide landmark bases (ragged rows, supports beyond eight entries): the lane-per-row kernels keep 8 row entries
-    // and 16 support entries in registers instead of 4 and 8
+    if (!f->valid || nrows <= 0) return SIT_OK;
+    // wide landmark bases (ragged rows, supports beyond eight entries): the lane-per-candidate kernels keep 8 row
+    // entries and 16 support entries in registers instead of 4 and 8
     const bool wide = width > 6 && (c->W_tight > 8 || (c->W_tight == 0 && width > 12));
-    HIP_TRY(c, hipMemcpyAsync(&K, f->st.K, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const i32 big2[3] = {0x7fffffff, 0x7fffffff, 0};     // first_new, first_bad, log_n
-    // the scalars are reset here once; afterwards by the kernel that ends each step (k_ff_apply_growth, k_ff_serial)
-    HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 12, hipMemcpyHostToDevice, c->stream));
-    volatile i32 *ctl = f->h_ctl;
-    auto readback = [&]() -> int {
-        HIP_TRY(c, hipMemcpyAsync(f->h_ctl, f->bt.first_new, 32, hipMemcpyDeviceToHost, c->stream));
+    i32 K = 0;
+    { int rc = ff_read_K(c, f, &K); if (rc) return rc; }
+    const char *tp = getenv("SITATOR_FF_TRACE");              // diagnostics: one line per step
+    if (tp && !f->d_trace) HIP_TRY(c, hipMalloc((void **)&f->d_trace, (size_t)FS_TRACE_CAP * 48));
+    i64 base = 0;                                             // rows consumed before the current control chain
+    int B = 256;
+    for (;;) {
+        FS s = f->st;
+        s.trace = tp ? f->d_trace : nullptr;
+        FSCtl z;
+        memset(&z, 0, sizeof(z));
+        z.first_new = z.first_bad = 0x7fffffff;
+        z.K = K; z.B = B; z.pos = 0; z.nrows = nrows - base;
+        z.nb = (i32)(z.nrows < B ? z.nrows : B);
+        HIP_TRY(c, hipMemcpyAsync(s.ctl, &z, sizeof(z), hipMemcpyHostToDevice, c->stream));
+        FSRows rb;                                            // the row arrays, addressed from `base`
+        rb.nnz = nnz + base; rb.idx = idx + base; rb.val = val + base; rb.weights = weights ? weights + base : nullptr;
+        rb.stride = stride; rb.width = width;
+        int par = 0, chunk = 8;
+        FSCtl st = z;
+        while (!st.halt) {
+            i64 bb = st.B < 256 ? 256 : st.B;                 // upper bound of the batch the device may be at by step i
+            for (int i = 0; i < chunk; i++) {
+                const i64 nbmax = bb > FS_BMAX ? FS_BMAX : bb;
+                const i64 lanes = nbmax <= 16384 ? nbmax * 64 : (i64)FS_BMAX * 16;
+                const unsigned grows = (unsigned)((lanes + 255) / 256), gk = (unsigned)(st.K + 64);
+#define FS_LAUNCH(name, kern, grid, block, ...)                                                         \
+    do {                                                                                                \
+        kern<<<dim3(grid), dim3(block), 0, c->stream>>>(__VA_ARGS__);                                    \
+        if (hipGetLastError() != hipSuccess) { c->msg = "fit: launch of " name " failed"; return SIT_ERR_HIP; } \
+    } while (0)
+                if (wide) {
+                    FS_LAUNCH("speculate", (k_fs_speculate<8, 16>), grows, 256, s, rb, par, threshold);
+                    FS_LAUNCH("walk", k_fs_walk, gk, 64, s, rb, par);
+                    FS_LAUNCH("verify", (k_fs_verify<8, 16>), grows, 256, s, rb, par, threshold);
+                    FS_LAUNCH("commit", (k_fs_commit<8, 16>), gk + 1, 64, s, rb, par, threshold);
+                } else {
+                    FS_LAUNCH("speculate", (k_fs_speculate<4, 8>), grows, 256, s, rb, par, threshold);
+                    FS_LAUNCH("walk", k_fs_walk, gk, 64, s, rb, par);
+                    FS_LAUNCH("verify", (k_fs_verify<4, 8>), grows, 256, s, rb, par, threshold);
+                    FS_LAUNCH("commit", (k_fs_commit<4, 8>), gk + 1, 64, s, rb, par, threshold);
+                }
+#undef FS_LAUNCH
+                par ^= 1;
+                bb = bb * 2 > FS_BMAX ? FS_BMAX : bb * 2;
+            }
+            HIP_TRY(c, hipMemcpyAsync(f->h_ctl, s.ctl + par, sizeof(FSCtl), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const i64 before = st.pos;
+            st = *f->h_ctl;
+            if (!st.halt && st.pos <= before) { c->msg = "fit: the step chain made no progress"; return SIT_ERR_CAPACITY; }
+            chunk = FS_CHUNK;
+        }
+        c->ff_batches += st.steps; c->ff_rewalks += st.bad_steps; c->ff_serial_rows += st.single_rows;
+        if (tp && st.trace_n > 0) {
+            const i64 nt = st.trace_n < FS_TRACE_CAP ? st.trace_n : FS_TRACE_CAP;
+            std::vector<i64> t((size_t)nt * 6);
+            HIP_TRY(c, hipMemcpy(t.data(), f->d_trace, (size_t)nt * 48, hipMemcpyDeviceToHost));
+            if (FILE *fp = fopen(tp, "a")) {
+                for (i64 q = 0; q < nt; q++)
+                    fprintf(fp, "%lld %lld %lld %lld %lld %lld\n", (long long)(t[6 * q] + base), (long long)t[6 * q + 1], (long long)t[6 * q + 2],
+                            (long long)t[6 * q + 3], (long long)t[6 * q + 4], (long long)t[6 * q + 5]);
+                fclose(fp);
+            }
+        }
+        K = st.K; B = st.B;
+        base += st.pos;
+        // the next stream (and fitfast_to_dense) finds the centre count in control block 0
+        FSCtl keep;
+        memset(&keep, 0, sizeof(keep));
+        keep.K = K; keep.halt = 1;
+        HIP_TRY(c, hipMemcpyAsync(f->st.ctl, &keep, sizeof(keep), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        return SIT_OK;
-    };
-    auto serial = [&](int count) -> int {     // apply `count` rows one by one (exact), refresh K
-        k_ff_serial<<<dim3(1), dim3(64), 0, c->stream>>>(f->st, r, f->bt, pos, count, threshold, f->d_scr);
-        HIP_TRY(c, hipGetLastError());
-        int rc = readback();
+        if (st.halt == 1) break;
+        if (st.halt == 3) { f->valid = false; c->ff_why = st.why; c->ff_stop_row = base; break; }
+        // halt == 2: the centre arrays must grow: export, reallocate, import
+        std::vector<double> cen; std::vector<i64> cnt; i64 Kd;
+        int rc = fitfast_to_dense(c, cen, cnt, &Kd);
         if (rc) return rc;
-        const i32 done = ctl[4];
-        K = ctl[5];
-        pos += done; c->ff_serial_rows += done;
-        if (ctl[3]) { f->valid = false; c->ff_why = ctl[6]; c->ff_stop_row = pos; }
-        return SIT_OK;
-    };
-    auto commit = [&]() {                     // the walked (shadow) state becomes the state
-        FFState t = f->st; f->st = f->sh; f->sh = t;
-        k_ff_apply_growth<<<dim3(1), dim3(64), 0, c->stream>>>(f->st, f->bt);
-    };
-    while (pos < nrows && f->valid) {
-        if (K + 64 > f->Kcap) {          // grow: export, reallocate, import
-            std::vector<double> cen; std::vector<i64> cnt; i64 Kd;
-            int rc = fitfast_to_dense(c, cen, cnt, &Kd);
-            if (rc) return rc;
-            bool fits;
-            f->ready = false;
-            if ((rc = ff_from_dense(c, f, cen.data(), cnt.data(), Kd, &fits))) return rc;
-            if (!fits) { f->valid = false; break; }
-            HIP_TRY(c, hipMemcpyAsync(f->bt.first_new, big2, 12, hipMemcpyHostToDevice, c->stream));
-        }
-        const int nb = (int)((nrows - pos) < B ? (nrows - pos) : B);
-        if (wide) k_ff_speculate<8, 16><<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
-        else k_ff_speculate<4, 8><<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
-        if (K > 0) {
-            k_ff_list_offsets<<<dim3(1), dim3(256), 0, c->stream>>>(f->st, f->bt);
-            k_ff_scatter<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->bt, nb);
-            k_ff_walk<<<dim3((unsigned)K), dim3(256), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, nb);
-            if (wide) k_ff_verify<8, 16><<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
-            else k_ff_verify<4, 8><<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(f->st, r, f->bt, pos, nb, threshold);
-        }
-        HIP_TRY(c, hipGetLastError());
-        { int rc = readback(); if (rc) return rc; }
-        const i32 fb[4] = {ctl[0], ctl[1], ctl[2], ctl[3]};
-        if (fb[3]) { f->valid = false; c->ff_why = ctl[6]; c->ff_stop_row = pos; break; }   // a capacity was exceeded: state is exact as of `pos`
-        const int first_new = fb[0] < nb ? fb[0] : nb;       // rows [0, first_new) were walked
-        const int first_bad = fb[1];
-        if (first_new == 0 || K == 0) {
-            // the row at `pos` founds a cluster (or needs the serial path): apply a few rows one by one
-            int rc = serial((int)((nrows - pos) < 32 ? (nrows - pos) : 32));
-            if (rc) return rc;
-            continue;
-        }
-        if (first_bad >= first_new) {                        // every decision verified
-            commit();
-            pos += first_new; c->ff_batches++;
-            if (first_new < nb) { int rc = serial(1); if (rc) return rc; }
-            else B = B * 2 > FF_BMAX ? FF_BMAX : B * 2;
-            continue;
-        }
-        // first wrong speculation (or support growth) at row first_bad: rows before it are exact
-        c->ff_rewalks++;
-        if (first_bad > 0) {
-            // FF_BREAK / founding rows inside [0, first_bad) cannot exist (first_bad < first_new)
-            HIP_TRY(c, hipMemsetAsync(f->bt.log_n, 0, 4, c->stream));      // the re-walk logs its growth afresh
-            k_ff_walk<<<dim3((unsigned)K), dim3(256), 0, c->stream>>>(f->st, f->sh, r, f->bt, pos, first_bad);
-            HIP_TRY(c, hipGetLastError());
-            commit();
-            pos += first_bad; c->ff_batches++;
-        }
-        int rc = serial(1);
-        if (rc) return rc;
-        // the next event is probably about as far away as this one was
-        B = first_bad * 2 < 256 ? 256 : (first_bad * 2 > FF_BMAX ? FF_BMAX : first_bad * 2);
+        bool fits;
+        f->ready = false;
+        if ((rc = ff_from_dense(c, f, cen.data(), cnt.data(), Kd, &fits))) return rc;
+        if (!fits) { f->valid = false; break; }
+        if (base >= nrows) break;
     }
-    *consumed = pos;
+    *consumed = base;
     return SIT_OK;
 }
