@@ -19,5 +19,8 @@ ctx.synchronize()
 print("fit wall %.3f s" % (time.time() - t), ctx.info())
 lib.sit_debug_ff_prof(out, 0)
 v = [int(x) for x in out]
-print("cycles: sort %.3g  group-head %.3g  joins %.3g | joins %d groups %d waves %d | max wave %.3g  sum wave %.3g" % tuple(v[:3] + v[3:6] + v[6:8]))
-print("per join cycles %.0f; per group head cycles %.0f; sort per wave %.0f" % (v[2] / max(v[3], 1), v[1] / max(v[4], 1), v[0] / max(v[5], 1)))
+names = ["listing", "group set-up", "look-ups", "join loops", "general joins"]
+joins, groups, waves = v[5], v[6], v[7]
+print("joins %d groups %d waves-with-joins %d" % (joins, groups, waves))
+for n, c in zip(names, v[:5]):
+    print("%-14s %.3g cycles  (%.0f per join, %.0f per group, %.0f per wave)" % (n, c, c / max(joins, 1), c / max(groups, 1), c / max(waves, 1)))

@@ -34,14 +34,16 @@
 
 #include "sit_internal.h"
 
-#define FS_CS 64                  // support entries per centre (= lanes of the walking wave)
+#define FS_CS 64                  // lanes of the walking wave = slots of a stored support
+#define FS_SMAX (FS_CS - 1)       // support entries per centre (a version keeps one slot for its header)
 #define FS_DC 64                  // centres listed per landmark dimension
 #define FS_OC 64                  // candidates recorded per row (C5 rows overlap 40-60 centres)
 #define FS_BMAX 65536             // rows per batch
 #define FS_W0 (FS_BMAX / 64)      // bitmap words per centre, level 0 (bit = batch row)
 #define FS_W1 (FS_W0 / 64)        // level 1 (bit = level-0 word is non-zero)
 #define FS_LOG 2048               // support-growth records per walk
-#define FS_NP 8                   // row entries staged per joining row
+#define FS_NP 16                  // row entries staged per joining row
+#define FS_LCAP 8192              // joining rows listed at a time by a walking wave
 #define FS_TAIL 32                // rows the commit may apply one at a time
 #define FS_NEW (-1)
 #define FS_BREAK (-2)             // row must go the serial way (zero row, capacity)
@@ -70,6 +72,11 @@ struct FSCtl {
 };
 static_assert(sizeof(FSCtl) == 128, "FSCtl layout");
 
+// A version is written once per join, by the chain itself, with one 16-byte store per lane: lanes below the support
+// size hold its entries, the lane after them the sample count after the join (exact in a double); every lane repeats
+// the support size, so that entry 0 tells it.  (Supports stop at FS_SMAX entries for that lane to exist.)
+struct __attribute__((aligned(16))) VsEnt { i32 idx, sn; double val; };
+
 struct FS {
     i32 *cs_n, *cs_idx;       // centres: support size, sorted support [Kcap][FS_CS]
     double *cs_val;
@@ -78,8 +85,7 @@ struct FS {
     i32 *dc_n, *dc_list;      // per landmark dimension: the centres holding it
     i32 *dec, *vdec, *ov_n, *ov_id;
     double *xn;
-    i32 *vs_n, *vs_idx;       // versions: state of the joined centre right after batch row j joined it
-    double *vs_val, *vs_fn;   // vs_fn: sample count after the join (exact in a double)
+    VsEnt *vs_ent;            // versions: state of the joined centre right after batch row j joined it [FS_BMAX][FS_CS]
     i32 *log;                 // growth records of the walk: (centre, dimension, batch row)
     u64 *bm0, *bm1;
     FSCtl *ctl;               // [2]
@@ -145,7 +151,7 @@ template <int NS>
 struct Sup {
     i32 ix[NS];
     double vv[NS];
-    int sn;
+    int sn, sti, stv;          // strides of the entries behind the pointers (1, 1: a stored state; 4, 2: a version)
     const i32 *pix;
     const double *pvv;
 };
@@ -153,7 +159,7 @@ struct Sup {
 template <int NS>
 __device__ __forceinline__ void sup_load(Sup<NS> &S, const i32 *ix, const double *vv, int sn)
 {
-    // rows of cs_idx / vs_idx are 256-byte aligned, rows of cs_val / vs_val 512-byte aligned
+    // rows of cs_idx are 256-byte aligned, rows of cs_val 512-byte aligned
 #pragma unroll
     for (int q = 0; q < NS; q += 4) {
         const int4 a = *(const int4 *)(ix + q);
@@ -161,7 +167,20 @@ __device__ __forceinline__ void sup_load(Sup<NS> &S, const i32 *ix, const double
         S.ix[q] = a.x; S.ix[q + 1] = a.y; S.ix[q + 2] = a.z; S.ix[q + 3] = a.w;
         S.vv[q] = v0.x; S.vv[q + 1] = v0.y; S.vv[q + 2] = v1.x; S.vv[q + 3] = v1.y;
     }
-    S.sn = sn; S.pix = ix; S.pvv = vv;
+    S.sn = sn; S.pix = ix; S.pvv = vv; S.sti = 1; S.stv = 1;
+}
+
+template <int NS>
+__device__ __forceinline__ void sup_load_version(Sup<NS> &S, const VsEnt *ent)
+{
+    int sn = 0;
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+        const int4 a = *(const int4 *)(ent + q);
+        S.ix[q] = a.x; S.vv[q] = __hiloint2double(a.w, a.z);
+        if (q == 0) sn = a.y;
+    }
+    S.sn = sn; S.pix = &ent->idx; S.pvv = &ent->val; S.sti = 4; S.stv = 2;
 }
 
 // value of the support at dimension d; hit = false when d is outside it
@@ -174,8 +193,8 @@ __device__ __forceinline__ double sup_at(const Sup<NS> &S, i32 d, bool &hit)
     for (int q = 0; q < NS; q++) if (q < S.sn && S.ix[q] == d) { cv = S.vv[q]; hit = true; }
     if (!hit && S.sn > NS && d > S.ix[NS - 1])
         for (int q = NS; q < S.sn; q++) {
-            const i32 t = S.pix[q];
-            if (t == d) { cv = S.pvv[q]; hit = true; break; }
+            const i32 t = S.pix[q * S.sti];
+            if (t == d) { cv = S.pvv[q * S.stv]; hit = true; break; }
             if (t > d) break;
         }
     return cv;
@@ -188,7 +207,7 @@ __device__ __forceinline__ double sup_norm(const Sup<NS> &S)
     double s2 = 0.0;
 #pragma unroll
     for (int q = 0; q < NS; q++) if (q < S.sn) s2 += S.vv[q] * S.vv[q];
-    for (int q = NS; q < S.sn; q++) { const double v = S.pvv[q]; s2 += v * v; }
+    for (int q = NS; q < S.sn; q++) { const double v = S.pvv[q * S.stv]; s2 += v * v; }
     return sqrt(s2);
 }
 
@@ -430,10 +449,11 @@ struct Walker {
     __device__ __forceinline__ void load_version(const FS &s, int k_, int lane_, int pj)
     {
         k = k_; lane = lane_;
-        sn = s.vs_n[pj];
-        idx = lane < sn ? s.vs_idx[(i64)pj * FS_CS + lane] : 0x7fffffff;
-        val = lane < sn ? s.vs_val[(i64)pj * FS_CS + lane] : 0.0;
-        cnt = s.vs_fn[pj];
+        const VsEnt e = s.vs_ent[(i64)pj * FS_CS + lane];
+        sn = bc_i(e.sn, 0);
+        cnt = bc_d(e.val, sn);
+        idx = lane < sn ? e.idx : 0x7fffffff;
+        val = lane < sn ? e.val : 0.0;
     }
     __device__ __forceinline__ void store_state(const FS &s)
     {
@@ -444,8 +464,11 @@ struct Walker {
     }
     __device__ __forceinline__ void publish(const FS &s, int jj)
     {
-        if (lane < sn) { s.vs_idx[(i64)jj * FS_CS + lane] = idx; s.vs_val[(i64)jj * FS_CS + lane] = val; }
-        if (lane == 0) { s.vs_n[jj] = sn; s.vs_fn[jj] = cnt; }
+        if (lane <= sn) {
+            VsEnt e;
+            e.idx = idx; e.sn = sn; e.val = lane == sn ? cnt : val;
+            (s.vs_ent + (size_t)jj * FS_CS)[lane] = e;           // jj is uniform: scalar base, lane offset
+        }
     }
     // The general join (:283-288): batch row jj (n entries, the first FS_NP of them at ri / rv, weight fn - fo) joins
     // this centre and may add dimensions to its support.  LOGGED: growth goes to the walk's log (published at the
@@ -462,7 +485,7 @@ struct Walker {
             if (!__ballot(idx == d)) { extra++; if (!LOGGED && s.dc_n[d] >= FS_DC) dcfull = true; }
         }
         int slot0 = 0;
-        if (LOGGED && extra && sn + extra <= FS_CS) {
+        if (LOGGED && extra && sn + extra <= FS_SMAX) {
             if (lane == 0) slot0 = atomicAdd(&ctl->log_n, extra);
             slot0 = __builtin_amdgcn_readfirstlane(slot0);
             if (slot0 + extra > FS_LOG) {                       // the records that fit must not be read as growth
@@ -470,7 +493,7 @@ struct Walker {
                 extra = FS_CS + 1;
             }
         }
-        if (sn + extra > FS_CS || dcfull) {
+        if (sn + extra > FS_SMAX || dcfull) {
             if (LOGGED) { if (lane == 0) atomicMin(&ctl->first_bad, jj); }
             else if (lane == 0) { ctl->flags = 1; atomicOr(&ctl->why, dcfull ? 1 : 8); }
             return false;
@@ -499,6 +522,17 @@ struct Walker {
     }
 };
 
+#ifdef FF_PROFILE
+// cycles of the walking waves: [0] listing, [1] group set-up, [2] look-ups, [3] join loops, [4] general joins;
+// counts: [5] joins, [6] groups, [7] waves with joins
+__device__ unsigned long long ff_prof[8];
+#define FF_T(x) const long long x = clock64()
+#define FF_ACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&ff_prof[i], (unsigned long long)(v)); } while (0)
+#else
+#define FF_T(x)
+#define FF_ACC(i, v)
+#endif
+
 __device__ __forceinline__ int wave_excl_scan(int x, int lane, int &total)
 {
     int v = x;
@@ -517,63 +551,116 @@ __device__ __forceinline__ double wave_incl_scan(double x, int lane)      // exa
 }
 
 struct WalkLds {
-    unsigned short lst[4096];        // joining rows of the current 4096-row chunk, ascending
+    unsigned short lst[FS_LCAP];     // joining rows (batch row numbers), ascending
     double addm[64 * FS_CS];         // [join][support slot]: what the joining row adds to the slot
-    double scf[64 * 4];              // per join: fo, fn, 1 / fn, -
-    i32 jl[64], nl[64];              // per join: batch row, entries
     i32 supl[FS_CS];                 // the support, for the joins to look their dimensions up
     i32 rowi[64 * FS_NP];            // first entries of the joining rows
     double rowv[64 * FS_NP];
+    double zero;
 };
 
+// the rows of one group of joins, a lane each, on their way from memory
+struct JoinRows {
+    int n;
+    double wd;
+    i32 i[FS_NP];
+    double v[FS_NP];
+};
+
+__device__ __forceinline__ void join_rows_load(JoinRows &J, const FSRows &r, i64 row, bool isj)
+{
+    J.n = 0; J.wd = 0.0;
+#pragma unroll
+    for (int e = 0; e < FS_NP; e++) { J.i[e] = 0; J.v[e] = 0.0; }
+    if (isj) {
+        J.n = r.nnz[row];
+        J.wd = r.weights ? (double)r.weights[row] : 1.0;
+#pragma unroll
+        for (int e = 0; e < FS_NP; e++)
+            if (e < r.width) { J.i[e] = r.idx[(i64)e * r.stride + row]; J.v[e] = r.val[(i64)e * r.stride + row]; }
+    }
+}
+
+// The joins of centre k among batch rows [0, jlim), in order.  The wave lists them from the centre's bitmap (lane l
+// takes WPL consecutive words; at most FS_LCAP joins are listed at a time), then applies them in groups of 64: the
+// rows of a group are fetched by a lane each while the previous group is being applied.
 __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSCtl *ctl, WalkLds &L, int k, int jlim, i64 pos, int lane)
 {
     unsigned short *lst = L.lst;
-    double *addm = L.addm, *scf = L.scf, *rowv = L.rowv;
-    i32 *jl = L.jl, *nl = L.nl, *supl = L.supl, *rowi = L.rowi;
+    double *addm = L.addm, *rowv = L.rowv;
+    i32 *supl = L.supl, *rowi = L.rowi;
     const u64 l1 = lane < FS_W1 ? s.bm1[(i64)k * FS_W1 + lane] : 0ull;
     if (!__ballot(l1 != 0)) return;
+    FF_T(t_list0);
+    const int nwords = (jlim + 63) >> 6;
+    const int WPL = (nwords + 63) >> 6;                         // words per lane, <= 16
+    u64 wv[FS_W1];
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < FS_W1; q++) {
+        wv[q] = 0ull;
+        const int w = lane * WPL + q;
+        if (q >= WPL) continue;                                 // uniform
+        const u64 lw = __shfl(l1, (w >> 6) & (FS_W1 - 1));      // every lane takes part in the exchange
+        if (w < nwords) {
+            if ((lw >> (w & 63)) & 1ull) {
+                u64 word = s.bm0[(i64)k * FS_W0 + w];
+                if (w * 64 + 64 > jlim) word &= (1ull << (jlim - w * 64)) - 1ull;      // w * 64 < jlim
+                wv[q] = word;
+                mine += __popcll(word);
+            }
+        }
+    }
+    int T;
+    const int P = wave_excl_scan(mine, lane, T);
+    if (T == 0) return;
     Walker wk;
     wk.load_state(s, k, lane);
-    const int nwords = (jlim + 63) >> 6;
-    for (int ch = 0; ch * 64 < nwords; ch++) {
-        const u64 l1c = bc_u(l1, ch);
-        if (!l1c) continue;
-        const int wi = ch * 64 + lane;
-        u64 word = ((l1c >> lane) & 1ull) ? s.bm0[(i64)k * FS_W0 + wi] : 0ull;
-        const int base = wi * 64;
-        if (base + 64 > jlim) word = base >= jlim ? 0ull : word & ((1ull << (jlim - base)) - 1ull);
-        int T;
-        int p = wave_excl_scan(__popcll(word), lane, T);
-        if (T == 0) continue;
-        while (word) { lst[p++] = (unsigned short)(lane * 64 + __ffsll((long long)word) - 1); word &= word - 1; }
+    int a = 0, Pa = 0;                                          // lanes [a, b) are listed next; Pa joins precede them
+    while (a < 64) {
+        // as many whole lanes as fit the list (one lane holds at most 1024 joins)
+        const int b = a + __popcll(__ballot(lane >= a && P + mine - Pa <= FS_LCAP));
+        const int Pb = b < 64 ? bc_i(P, b) : T;
+        if (lane >= a && lane < b) {
+            int p = P - Pa;
+#pragma unroll
+            for (int q = 0; q < FS_W1; q++) {
+                u64 word = wv[q];
+                const int w0 = (lane * WPL + q) * 64;
+                while (word) { lst[p++] = (unsigned short)(w0 + __ffsll((long long)word) - 1); word &= word - 1; }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
-        for (int g0 = 0; g0 < T; g0 += 64) {
-            const bool isj = g0 + lane < T;
-            const int j = isj ? ch * 4096 + lst[g0 + lane] : 0x7fffffff;
-            const int Tg = T - g0 < 64 ? T - g0 : 64;
+        const int Ts = Pb - Pa;
+        FF_T(t_list1);
+        FF_ACC(0, t_list1 - t_list0); FF_ACC(7, 1); FF_ACC(5, Ts);
+        JoinRows J;
+        join_rows_load(J, r, pos + (lane < Ts ? lst[lane] : 0), lane < Ts);
+        for (int g0 = 0; g0 < Ts; g0 += 64) {
+            const bool isj = g0 + lane < Ts;
+            const int j = isj ? lst[g0 + lane] : 0x7fffffff;
+            const int Tg = Ts - g0 < 64 ? Ts - g0 : 64;
             // rows beyond the first row known to be wrong are void
             if (bc_i(j, 0) > __hip_atomic_load(&ctl->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-            // the joining rows, a lane each
+            FF_T(t_g0);
+            FF_ACC(6, 1);
             const i64 row = pos + (isj ? j : 0);
-            int n = 0;
-            double wd = 0.0;
-            if (isj) {
-                n = r.nnz[row];
-                wd = r.weights ? (double)r.weights[row] : 1.0;
+            const int n = J.n;
+            const double wd = J.wd;
 #pragma unroll
-                for (int e = 0; e < FS_NP; e++)
-                    if (e < r.width) {
-                        rowi[lane * FS_NP + e] = r.idx[(i64)e * r.stride + row];
-                        rowv[lane * FS_NP + e] = r.val[(i64)e * r.stride + row];
-                    }
+            for (int e = 0; e < FS_NP; e++) { rowi[lane * FS_NP + e] = J.i[e]; rowv[lane * FS_NP + e] = J.v[e]; }
+            const double fn = wk.cnt + wave_incl_scan(wd, lane), fo = fn - wd, fy = 1.0 / fn;
+            // the next group's rows are on their way while this group is applied
+            {
+                const bool nj = g0 + 64 + lane < Ts;
+                join_rows_load(J, r, pos + (nj ? lst[g0 + 64 + lane] : 0), nj);
             }
-            const double fn = wk.cnt + wave_incl_scan(wd, lane), fo = fn - wd;
-            scf[4 * lane] = fo; scf[4 * lane + 1] = fn; scf[4 * lane + 2] = 1.0 / fn;
-            jl[lane] = j; nl[lane] = n;
             int s0 = 0;
+            FF_T(t_g1);
+            FF_ACC(1, t_g1 - t_g0);
             for (;;) {
                 // joins s0.. look their dimensions up in the support as it is now
+                FF_T(t_l0);
                 const int SW = wk.sn;
                 if (lane < SW) supl[lane] = wk.idx;
                 __builtin_amdgcn_wave_barrier();
@@ -592,28 +679,50 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
                 const u64 gm = __ballot(grow);
                 const int s1 = gm ? __ffsll((long long)gm) - 1 : Tg;
                 // the chain: per join multiply, add, divide (a / b as RN(a * RN(1 / b)) with one exact-residual
-                // correction: bit-identical to the IEEE quotient) and the version
-#pragma unroll 4
-                for (int q = s0; q < s1; q++) {
-                    const double a = lane < SW ? addm[q * SW + lane] : 0.0;
-                    const double qfo = scf[4 * q], qfn = scf[4 * q + 1], qy = scf[4 * q + 2];
-                    const int jj = jl[q];
-                    const double t = wk.val * qfo + a;
-                    const double q0 = t * qy;
-                    wk.val = __builtin_fma(__builtin_fma(-q0, qfn, t), qy, q0);
-                    wk.cnt = qfn;
-                    wk.publish(s, jj);
+                // correction: bit-identical to the IEEE quotient) and the version.  The join's constants come out of
+                // its lane's registers; what it adds to my slot is read from LDS one join ahead.
+#define FS_JOIN_STEP(q, a)                                                                              \
+                {                                                                                               \
+                    const double qfn = bc_d(fn, q), qy = bc_d(fy, q);     /* fo of this join = fn of the one before */ \
+                    const int jj = bc_i(j, q);                                                                  \
+                    const double t = wk.val * qfo + (a);                                                        \
+                    const double q0 = t * qy;                                                                   \
+                    wk.val = __builtin_fma(__builtin_fma(-q0, qfn, t), qy, q0);                                 \
+                    wk.cnt = qfn;                                                                               \
+                    wk.publish(s, jj);                                                                          \
+                    qfo = qfn;                                                                                  \
                 }
+                const int u0 = __builtin_amdgcn_readfirstlane(s0), u1 = __builtin_amdgcn_readfirstlane(s1);
+                const double *col = lane < SW ? addm + lane : &L.zero;      // lanes outside the support add 0 to their 0
+                const int stp = lane < SW ? SW : 0;
+                double a0 = u0 < u1 ? col[u0 * stp] : 0.0, a1 = 0.0;
+                double qfo = bc_d(fo, u0 < 64 ? u0 : 0);
+                int q = u0;
+                for (; q + 1 < u1; q += 2) {
+                    a1 = col[(q + 1) * stp];
+                    FS_JOIN_STEP(q, a0)
+                    a0 = q + 2 < u1 ? col[(q + 2) * stp] : 0.0;
+                    FS_JOIN_STEP(q + 1, a1)
+                }
+                if (q < u1) FS_JOIN_STEP(q, a0)
+#undef FS_JOIN_STEP
+                FF_T(t_l2);
+                FF_ACC(3, t_l2 - t_l1);
                 if (s1 == Tg) break;
                 // join s1 adds a dimension to the support: the general way, then the rest is looked up again
-                if (!wk.join_general<true>(s, r, ctl, pos + jl[s1], jl[s1], nl[s1], scf[4 * s1], scf[4 * s1 + 1],
-                                           rowi + s1 * FS_NP, rowv + s1 * FS_NP)) return;
-                wk.publish(s, jl[s1]);
+                {
+                    const int jj = bc_i(j, s1);
+                    if (!wk.join_general<true>(s, r, ctl, pos + jj, jj, bc_i(n, s1), bc_d(fo, s1), bc_d(fn, s1),
+                                               rowi + s1 * FS_NP, rowv + s1 * FS_NP)) return;
+                    wk.publish(s, jj);
+                }
+                FF_ACC(4, clock64() - t_l2);
                 s0 = s1 + 1;
                 if (s0 == Tg) break;
             }
             __builtin_amdgcn_wave_barrier();
         }
+        a = b; Pa = Pb;
     }
 }
 
@@ -627,6 +736,8 @@ __global__ __launch_bounds__(64) void k_fs_walk(FS s, FSRows r, int par)
     { const int fnw = ctl->first_new; if (fnw < jlim) jlim = fnw; }   // the batch ends before the first founding row
     if (jlim <= 0) return;
     const i64 pos = ctl->pos;
+    if (lane == 0) L.zero = 0.0;
+    __builtin_amdgcn_wave_barrier();
     for (int k = blockIdx.x; k < K; k += gridDim.x) {
         fs_walk_centre(s, r, ctl, L, k, jlim, pos, lane);
         __builtin_amdgcn_wave_barrier();
@@ -645,7 +756,7 @@ __device__ __forceinline__ Best fs_score_seen(const FS &s, const FSRows &r, cons
         sup_load(S, s.cs_idx + (i64)cc * FS_CS, s.cs_val + (i64)cc * FS_CS, s.cs_n[cc]);
         nrm = s.c_nrm[cc];
     } else {
-        sup_load(S, s.vs_idx + (i64)pj * FS_CS, s.vs_val + (i64)pj * FS_CS, s.vs_n[pj]);
+        sup_load_version(S, s.vs_ent + (i64)pj * FS_CS);
         nrm = sup_norm(S);
     }
     int first;
@@ -744,7 +855,7 @@ __device__ __forceinline__ bool fs_apply_row(const FS &s, const FSRows &r, FSCtl
         bool full = false;
         if (lane < n && lane < FS_CS) { d = r.idx[(i64)lane * r.stride + row]; v = r.val[(i64)lane * r.stride + row]; full = s.dc_n[d] >= FS_DC; }
         const bool anyfull = __ballot(full) != 0;
-        if (K >= s.Kcap || n > FS_CS || anyfull) {
+        if (K >= s.Kcap || n > FS_SMAX || anyfull) {
             if (lane == 0) { ctl->flags = 1; atomicOr(&ctl->why, anyfull ? 1 : (K >= s.Kcap ? 4 : 8)); }
             return false;
         }
@@ -842,8 +953,12 @@ __global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, doubl
         const i64 pos2 = pos + cut + applied;
         int B = ctl->B;
         if (cut == nb) B = B * 2 > FS_BMAX ? FS_BMAX : B * 2;                 // every decision verified
-        else if (single != FS_NEW)                                            // a wrong speculation: the next one is
-            B = cut * 2 < 256 ? 256 : (cut * 2 > FS_BMAX ? FS_BMAX : cut * 2);  // probably about as far away
+        else {
+            // cut short (a founding row, a wrong speculation): rows speculated beyond the cut were wasted, so the
+            // batch follows the distance between such rows (twice the last one, averaged with what it was)
+            B = (B + 2 * cut) / 2;
+            B = B < 256 ? 256 : (B > FS_BMAX ? FS_BMAX : B);
+        }
         const i64 left = ctl->nrows - pos2;
         int halt = 0;
         if (flags) halt = 3;
@@ -864,6 +979,14 @@ __global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, doubl
 }
 
 }   // namespace
+
+#ifdef FF_PROFILE
+extern "C" void sit_debug_ff_prof(unsigned long long *out, int reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_prof), sizeof(ff_prof));
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(ff_prof), z, sizeof(z)); }
+}
+#endif
 
 // ---- host side ------------------------------------------------------------------------------------------
 
@@ -906,7 +1029,7 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     if (f->blob) { (void)hipFree(f->blob); f->blob = nullptr; }
     const i64 D = c->D;
     const size_t total = (size_t)Kcap * (4 + FS_CS * 12 + 16 + FS_W0 * 8 + FS_W1 * 8) + (size_t)D * (4 + FS_DC * 4)
-                       + (size_t)FS_BMAX * (4 + 4 + 4 + FS_OC * 4 + 8 + 4 + 8 + FS_CS * 12) + (size_t)FS_LOG * 12 + 65536;
+                       + (size_t)FS_BMAX * (4 + 4 + 4 + FS_OC * 4 + 8 + FS_CS * 16) + (size_t)FS_LOG * 12 + 65536;
     HIP_TRY(c, hipMalloc(&f->blob, total));
     if (!f->h_ctl) HIP_TRY(c, hipHostMalloc((void **)&f->h_ctl, sizeof(FSCtl)));
     HIP_TRY(c, hipMemsetAsync(f->blob, 0, total, c->stream));
@@ -926,10 +1049,7 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     s.ov_n = (i32 *)carve(p, (size_t)FS_BMAX * 4);
     s.ov_id = (i32 *)carve(p, (size_t)FS_BMAX * FS_OC * 4);
     s.xn = (double *)carve(p, (size_t)FS_BMAX * 8);
-    s.vs_n = (i32 *)carve(p, (size_t)FS_BMAX * 4);
-    s.vs_fn = (double *)carve(p, (size_t)FS_BMAX * 8);
-    s.vs_idx = (i32 *)carve(p, (size_t)FS_BMAX * FS_CS * 4);
-    s.vs_val = (double *)carve(p, (size_t)FS_BMAX * FS_CS * 8);
+    s.vs_ent = (VsEnt *)carve(p, (size_t)FS_BMAX * FS_CS * sizeof(VsEnt));
     s.log = (i32 *)carve(p, (size_t)FS_LOG * 12);
     s.ctl = (FSCtl *)carve(p, 2 * sizeof(FSCtl));
     s.D = D; s.Kcap = Kcap;
@@ -954,7 +1074,7 @@ static int ff_from_dense(sit_ctx *c, FitFast *f, const double *cen, const i64 *c
         for (i64 d = 0; d < D; d++) {
             const double v = cen[k * D + d];
             if (v != 0.0) {
-                if (n == FS_CS || dc_n[(size_t)d] == FS_DC) return SIT_OK;
+                if (n == FS_SMAX || dc_n[(size_t)d] == FS_DC) return SIT_OK;
                 cs_idx[(size_t)(k * FS_CS + n)] = (i32)d; cs_val[(size_t)(k * FS_CS + n)] = v; n++;
                 dc_list[(size_t)(d * FS_DC + dc_n[(size_t)d])] = (i32)k; dc_n[(size_t)d]++;
                 s2 += v * v;
