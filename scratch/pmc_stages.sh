@@ -4,13 +4,13 @@ out=$1; F=${2:-20000}; cfg=${3:-C2}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/$out
-for stop in 1 4 0; do
+for stop in 1 2 3 4 5 0; do
   export SITATOR_DEBUG_STOP=$stop
   rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/$out/stop$stop -o run -- python3 $R/scratch/prof_fill_raw.py $F $cfg > $R/$out/stop$stop.log 2>&1 || exit 1
 done
 python3 - <<PY
 import csv, glob, collections
-for stop in (1, 4, 0):
+for stop in (1, 2, 3, 4, 5, 0):
     for f in glob.glob("$R/$out/stop%d/**/*counter_collection.csv" % stop, recursive=True):
         agg = collections.defaultdict(float); n = collections.Counter()
         for r in csv.DictReader(open(f)):

@@ -400,9 +400,10 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
             // ---- D0: one lane per task tests the task's CRITICAL vertex (the one with the least room in this ion's
             //      bin, candidates.hip); the tasks that pass are compacted in place ----
             int t_end = 0;
-            for (int t0 = 0; t0 < nlt; t0 += 64) {
+            const int nlt0 = h.debug_stop == 2 ? 0 : nlt;        // ablation: stop after the task table
+            for (int t0 = 0; t0 < nlt0; t0 += 64) {
                 const int t = t0 + lane;
-                const bool act = t < nlt;
+                const bool act = t < nlt0;
                 const unsigned tk = ttab[act ? t : 0];
                 const unsigned k = tk & 0x3fffffu, cv = (tk >> 22) & 7u;
                 const uint4 iv = info[tk >> 26];
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 t_end += __popcll(km);
             }
             if (h.debug_stop == 9 && lane == 0) atomicAdd(&h.scal[4], (u64)t_end);
+            if (h.debug_stop == 3) t_end = 0;                     // ablation: stop after the critical-vertex test
             __builtin_amdgcn_wave_barrier();
             const int pend = (t_end + TPP - 1) / TPP;           // passes of TPP tasks over [0, t_end)
             int cursor = 0;
@@ -493,6 +495,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                         if (i < items) sd2[i] = c[u].y != 0.0 ? f : 1.0;
                     }
                 }
+                if (h.debug_stop == 5) cnt = 0;                   // ablation: stop after the logistic factors
                 __builtin_amdgcn_wave_barrier();
                 // ---- T: ci *= temp in vertex order (helpers.pyx:208) and the n-th root (:212), one lane per
                 //      survivor; the row entry of a component is the number of earlier non-zero components of its
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < nib) {
-            const int nnz = h.debug_stop == 4 ? 1 : (int)nzc[lane];
+            const int nnz = h.debug_stop >= 2 && h.debug_stop <= 5 ? 1 : (int)nzc[lane];
             const i64 row = (f0 + fl) * M + j;
             g.row_nnz[row] = nnz < g.W ? nnz : g.W;
             if (nnz == 0) {                                               // helpers.pyx:116-120
