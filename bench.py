@@ -88,25 +88,60 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries the one JSON line and nothing else: whatever the libraries print (gloo's connection notes, RCCL's
+    # version banner) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     backend = os.environ.get("SITATOR_BENCH_BACKEND", "rccl")     # "gloo": rehearsal of the N>1 path on a 1-GPU box
     import numpy as np
     from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth, _lib, sharding
 
     comm = None
+    exchange = "none (single process)"
     if world > 1:
+        # control plane: a gloo group (CPU, TCP) carries the RCCL unique id and the agreement on whether every rank
+        # got its communicator; it is also the fallback for the (tiny) exchange steps if RCCL cannot come up
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        ndev = _lib.device_count()
+        if backend != "rccl" or os.environ.get("SITATOR_BENCH_SHARE_GPU") == "1":      # rehearsal: several ranks on one GPU
+            local = local % max(ndev, 1)
+        why = ""
         if backend == "rccl":
-            ndev = _lib.device_count()
-            if os.environ.get("SITATOR_BENCH_SHARE_GPU") == "1":      # rehearsal: several ranks on one GPU
-                local = local % max(ndev, 1)
-            if local >= ndev:
-                raise RuntimeError("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local, ndev))
-            comm = sharding.RcclComm.from_env(device=local)
-            print("[rank %d/%d] RCCL communicator up on GPU %d" % (rank, world, local), file=sys.stderr, flush=True)
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                try:
+                    uid = torch.from_numpy(np.frombuffer(_lib.comm_unique_id(), dtype=np.uint8).copy())
+                except Exception as e:      # noqa: BLE001
+                    why = "%s: %s" % (type(e).__name__, e)
+            dist.broadcast(uid, src=0)          # every rank takes part whatever happened on rank 0
+            try:
+                if not bool(uid.any()):
+                    raise RuntimeError("no unique id from rank 0")
+                if local >= ndev:
+                    raise RuntimeError("LOCAL_RANK %d but only %d GPU(s) visible" % (local, ndev))
+                comm = sharding.RcclComm(local, rank, world, uid.numpy().tobytes())
+            except Exception as e:      # noqa: BLE001 - reported, and the run goes on over gloo
+                why = why or "%s: %s" % (type(e).__name__, e)
+                comm = None
+            ok = torch.tensor([1 if comm is not None else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                exchange = "rccl"
+                print("[rank %d/%d] RCCL communicator up on GPU %d" % (rank, world, local), file=sys.stderr, flush=True)
+            else:
+                if comm is not None:
+                    comm.close()
+                reasons = [None] * world
+                dist.all_gather_object(reasons, why)
+                exchange = "gloo (no RCCL communicator: %s)" % "; ".join(sorted({r for r in reasons if r}))[:300]
+                comm = sharding.TorchComm(device="cpu")
+                print("[rank %d/%d] %s" % (rank, world, exchange), file=sys.stderr, flush=True)
         else:
-            import torch.distributed as dist
-            local = local % max(_lib.device_count(), 1)
-            dist.init_process_group(backend)
             comm = sharding.TorchComm(device="cpu")
+            exchange = "gloo"
 
     host = synth.config_host(args.config)
     M = synth.CONFIG_MOBILE[args.config]
@@ -144,7 +179,7 @@ def main():
            "wall_s": {k: round(v, 4) for k, v in la.wall_timings.items()},
            "sites": int(st_full.site_network.n_sites), "unassigned_frac": float(st_full.percent_unassigned),
            "fit": {k: v for k, v in la._ctx.info().items() if k.startswith("fit_")},
-           "exchange": "none (single process)" if comm is None else ("rccl" if backend == "rccl" else backend)}
+           "exchange": exchange}
     e2e_labels = st_full.traj.reshape(-1)
 
     # --- resident context for the timed pass ---
@@ -252,7 +287,8 @@ def main():
             out["ab_kernels"] = ab
         if args.cpu_frames > 0 and world == 1:          # a reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(host, gen, frames, ref, fit_ctx_centers, M, args.cpu_frames, ncpu)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()
         if hasattr(comm, "close"):
