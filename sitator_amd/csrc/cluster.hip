@@ -4,6 +4,8 @@
 #include <cstring>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <algorithm>
+
 #include "sit_internal.h"
 
 __device__ __forceinline__ Best wave_best(Best b)
@@ -45,7 +47,7 @@ struct PredArgs {
 
 // b = numpy argmax of |normed_centres . x| (/ |x|) over the centres that overlap the row; every
 // other centre scores exactly 0, so when nothing beats 0 the dense argmax is index 0.
-__device__ __forceinline__ void finish_predict(const PredArgs &a, i64 row, Best b)
+__device__ __forceinline__ i64 finish_predict(const PredArgs &a, i64 row, Best b)
 {
     i64 to; double conf;
     if (b.i < 0 || (!b.nan && b.v == 0.0)) { to = 0; conf = 0.0; }
@@ -53,6 +55,7 @@ __device__ __forceinline__ void finish_predict(const PredArgs &a, i64 row, Best 
     if (conf < a.threshold) { to = -1; conf = 0.0; }                  // :184-186 (NaN: false)
     a.labels[row] = to;
     a.confs[row] = conf;
+    return to;
 }
 
 // Running argmax of fabs(dot_k) / xn over centres visited in ASCENDING id (numpy argmax: first maximum, NaN first).
@@ -92,7 +95,7 @@ struct ArgMaxQ {
 // are independent of each other, and summing c[k][d_e] * x_e over the row's entries in ascending dimension order
 // is the reference's dense dot product with its exact zeros left out (a stored 0.0 contributes +0.0).
 // Centres come in no particular order, hence the index-aware best_merge.
-__device__ void predict_row_generic(const PredArgs &a, i64 row, int n, double xn)
+__device__ i64 predict_row_generic(const PredArgs &a, i64 row, int n, double xn)
 {
     Best b = best_empty();
     for (int e = 0; e < n; e++) {
@@ -121,13 +124,13 @@ __device__ void predict_row_generic(const PredArgs &a, i64 row, int n, double xn
             b = best_merge(b, best_of(fabs(dot), cid));                  // :179
         }
     }
-    finish_predict(a, row, b);
+    return finish_predict(a, row, b);
 }
 
 // One row with at most four entries: a 4-way merge of the (centre-sorted) CSC columns of the row's dimensions.
 // Each step takes the smallest pending centre id and sums its terms in ascending dimension order.  The CSC arrays
 // may live in global memory or (k_predict_rows_lds) in LDS.
-__device__ __forceinline__ void predict_row_merge(const PredArgs &a, i64 row, int n, double xn, const i32 *col_ptr,
+__device__ __forceinline__ i64 predict_row_merge(const PredArgs &a, i64 row, int n, double xn, const i32 *col_ptr,
                                                   const i32 *col_k, const double *col_val)
 {
     ArgMaxQ am;
@@ -154,14 +157,14 @@ __device__ __forceinline__ void predict_row_merge(const PredArgs &a, i64 row, in
         if (h3 == cid) { const double t = col_val[q3] * v3; dot = first ? t : dot + t; first = false; q3++; h3 = q3 < e3 ? col_k[q3] : none; }
         am.push(dot, cid, xn, a.normed != 0);                       // :177-179
     }
-    finish_predict(a, row, am.result(xn, a.normed != 0));
+    return finish_predict(a, row, am.result(xn, a.normed != 0));
 }
 
 // The same merge for rows of up to NW entries (ragged bases: C5 rows hold 5-13).  The column heads live in registers
 // (every index below is a compile-time constant after unrolling); a step costs NW - 1 minimum operations and NW
 // predicated advances, against the row x column x row dense look-ups of predict_row_generic.
 template <int NW>
-__device__ __forceinline__ void predict_row_merge_wide(const PredArgs &a, i64 row, int n, double xn)
+__device__ __forceinline__ i64 predict_row_merge_wide(const PredArgs &a, i64 row, int n, double xn)
 {
     ArgMaxQ am;
     am.init();
@@ -196,7 +199,7 @@ __device__ __forceinline__ void predict_row_merge_wide(const PredArgs &a, i64 ro
         }
         am.push(dot, cid, xn, a.normed != 0);                       // :177-179
     }
-    finish_predict(a, row, am.result(xn, a.normed != 0));
+    return finish_predict(a, row, am.result(xn, a.normed != 0));
 }
 
 __device__ __forceinline__ bool predict_row_head(const PredArgs &a, i64 row, int &n, double &xn)
@@ -229,17 +232,64 @@ __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a, i32 *wi
     if (live && !wide) predict_row_merge(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
 }
 
-__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_wide(PredArgs a, const i32 *wide_list, const unsigned *wide_count)
+// The same with the centres' CSC arrays resident in LDS (they are a few tens of KB: 480 centres of ~8 landmarks at
+// C2).  The merge makes ~35 scattered 4-8 byte reads per row; from global memory each is a 64-address vector load and
+// the kernel is bound by the texture-address path, from LDS they cost a few cycles.  Workgroups are persistent (the
+// arrays are staged once per workgroup) and walk the rows in blocks of PRED_LDS_BLOCK.
+#define PRED_LDS_BLOCK 512
+// hist_K > 0: the labels are counted on the way (np.bincount of :92) - per workgroup in LDS, flushed once.
+__global__ __launch_bounds__(PRED_LDS_BLOCK) void k_predict_rows_lds(PredArgs a, i32 *wide_list, unsigned *wide_count, int nnzc,
+                                                                    int hist_K, u64 *counts)
 {
-    const i64 q = (i64)blockIdx.x * PRED_BLOCK + threadIdx.x;
-    if (q >= (i64)*wide_count) return;
-    const i64 row = wide_list[q];
-    int n;
-    double xn;
-    if (!predict_row_head(a, row, n, xn)) return;
-    if (n <= 8) predict_row_merge_wide<8>(a, row, n, xn);
-    else if (n <= 16) predict_row_merge_wide<16>(a, row, n, xn);
-    else predict_row_generic(a, row, n, xn);
+    extern __shared__ __attribute__((aligned(16))) char pl_smem[];
+    double *l_val = (double *)pl_smem;
+    i32 *l_ptr = (i32 *)(l_val + nnzc);
+    i32 *l_k = l_ptr + (a.D + 1);
+    unsigned *hist = (unsigned *)(l_k + nnzc);
+    for (int q = threadIdx.x; q < hist_K; q += PRED_LDS_BLOCK) hist[q] = 0u;
+    for (int q = threadIdx.x; q < nnzc; q += PRED_LDS_BLOCK) { l_val[q] = a.col_val[q]; l_k[q] = a.col_k[q]; }
+    for (int q = threadIdx.x; q <= (int)a.D; q += PRED_LDS_BLOCK) l_ptr[q] = a.col_ptr[q];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (i64 r0 = (i64)blockIdx.x * PRED_LDS_BLOCK; r0 < a.N; r0 += (i64)gridDim.x * PRED_LDS_BLOCK) {
+        const i64 row = r0 + threadIdx.x;
+        int n = 0;
+        double xn = 0.0;
+        const bool live = row < a.N && predict_row_head(a, row, n, xn);
+        const bool wide = live && n > 4;
+        const unsigned long long wm = __ballot(wide);
+        if (wm) {                                                  // one atomic per wave
+            const int leader = __ffsll((long long)wm) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(wide_count, (unsigned)__popcll(wm));
+            base = __shfl(base, leader);
+            if (wide) wide_list[base + __popcll(wm & ((1ull << lane) - 1ull))] = (i32)row;
+        }
+        if (live && !wide) {
+            const i64 to = predict_row_merge(a, row, n, xn, l_ptr, l_k, l_val);
+            if (hist_K > 0 && to >= 0) atomicAdd(&hist[to], 1u);
+        }
+    }
+    if (hist_K > 0) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < hist_K; q += PRED_LDS_BLOCK) { const unsigned v = hist[q]; if (v) atomicAdd(&counts[q], (u64)v); }
+    }
+}
+
+__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_wide(PredArgs a, const i32 *wide_list, const unsigned *wide_count, u64 *counts)
+{
+    const i64 nw = (i64)*wide_count;
+    for (i64 q = (i64)blockIdx.x * PRED_BLOCK + threadIdx.x; q < nw; q += (i64)gridDim.x * PRED_BLOCK) {
+        const i64 row = wide_list[q];
+        int n;
+        double xn;
+        if (!predict_row_head(a, row, n, xn)) continue;
+        i64 to;
+        if (n <= 8) to = predict_row_merge_wide<8>(a, row, n, xn);
+        else if (n <= 16) to = predict_row_merge_wide<16>(a, row, n, xn);
+        else to = predict_row_generic(a, row, n, xn);
+        if (counts && to >= 0) atomicAdd(&counts[to], 1ull);       // the narrow rows were counted by k_predict_rows_lds
+    }
 }
 
 // Dense fallback: every centre, sparse row against the dense (normalised) centre matrix.
@@ -260,7 +310,7 @@ __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_dense(PredArgs a)
         if (a.normed) dot /= xn;
         b = best_merge(b, best_of(fabs(dot), k));
     }
-    finish_predict(a, row, b);
+    (void)finish_predict(a, row, b);
 }
 
 extern "C" int sit_set_centers(sit_ctx *c, const double *centers, i64 K, int normed)
@@ -285,6 +335,7 @@ extern "C" int sit_set_centers(sit_ctx *c, const double *centers, i64 K, int nor
     if ((rc = dev_upload(c, &c->d_col_k, ks.data(), (i64)ks.size()))) return rc;
     if ((rc = dev_upload(c, &c->d_col_val, vals.data(), (i64)vals.size()))) return rc;
     c->K = K; c->centers_normed = normed;
+    c->csc_nnz = (i64)vals.size();
     c->max_col = 0;
     for (i64 d = 0; d < D; d++) if (ptr[(size_t)d + 1] - ptr[(size_t)d] > c->max_col) c->max_col = ptr[(size_t)d + 1] - ptr[(size_t)d];
     if ((rc = dev_alloc(c, &c->d_counts, K))) return rc;
@@ -318,13 +369,31 @@ static int run_predict(sit_ctx *c, double threshold)
     unsigned *wcount = (unsigned *)c->d_scratch;
     i32 *wlist = (i32 *)c->d_scratch + 16;
     StageTimer t(c, T_PREDICT);
+    bool counted = false;
     if (c->max_col <= PRED_MAXCOL) {
         HIP_TRY(c, hipMemsetAsync(wcount, 0, 4, c->stream));
-        k_predict_rows<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount);
-        if (c->rows_W > 4) k_predict_rows_wide<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount);
+        const size_t lds = (size_t)c->csc_nnz * 12 + (size_t)(c->D + 1) * 4 + (size_t)c->K * 4 + 16;
+        static const bool no_lds = getenv("SITATOR_PREDICT_LDS") && getenv("SITATOR_PREDICT_LDS")[0] == '0';
+        // wide rows are few (none at C2): a small grid walks their list
+        const unsigned gw = (unsigned)std::min<i64>((c->N + PRED_BLOCK - 1) / PRED_BLOCK, 16384);
+        if (lds <= 52 * 1024 && !no_lds) {
+            // three or four workgroups of 512 threads per CU; the labels are counted on the way
+            int ncu = 256;
+            { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+            const i64 blocks = (c->N + PRED_LDS_BLOCK - 1) / PRED_LDS_BLOCK;
+            const unsigned g2 = (unsigned)std::min<i64>(blocks, (i64)ncu * (lds <= 36 * 1024 ? 4 : 3));
+            HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
+            HIP_TRY(c, hipFuncSetAttribute((const void *)k_predict_rows_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_predict_rows_lds<<<dim3(g2), dim3(PRED_LDS_BLOCK), lds, c->stream>>>(a, wlist, wcount, (int)c->csc_nnz, (int)c->K, (u64 *)c->d_counts);
+            if (c->rows_W > 4) k_predict_rows_wide<<<dim3(gw), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, (u64 *)c->d_counts);
+            counted = true;
+        } else {
+            k_predict_rows<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount);
+            if (c->rows_W > 4) k_predict_rows_wide<<<dim3(gw), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, nullptr);
+        }
     } else k_predict_rows_dense<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
     HIP_TRY(c, hipGetLastError());
-    if ((rc = sit_label_counts(c))) return rc;      // np.bincount(labels[labels >= 0]) (:92)
+    if (!counted && (rc = sit_label_counts(c))) return rc;      // np.bincount(labels[labels >= 0]) (:92)
     t.stop();
     c->assign_valid = true;
     return SIT_OK;

@@ -100,6 +100,7 @@ struct sit_ctx {
     i64 K = 0;
     int centers_normed = 1;
     i64 max_col = 0;                  // longest CSC column
+    i64 csc_nnz = 0;                  // entries of the CSC arrays
     i32 *d_col_ptr = nullptr, *d_col_k = nullptr;
     double *d_col_val = nullptr;
     double *d_cen_dense = nullptr;    // [K,D] the same matrix, dense (fallback predict)
