@@ -378,8 +378,11 @@ static int run_predict(sit_ctx *c, double threshold)
         const unsigned gw = (unsigned)std::min<i64>((c->N + PRED_BLOCK - 1) / PRED_BLOCK, 16384);
         if (lds <= 52 * 1024 && !no_lds) {
             // three or four workgroups of 512 threads per CU; the labels are counted on the way
-            int ncu = 256;
-            { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, c->device) == hipSuccess && pr.multiProcessorCount > 0) ncu = pr.multiProcessorCount; }
+            if (c->num_cu <= 0) {
+                int v = 0;
+                c->num_cu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0 ? v : 256;
+            }
+            const int ncu = c->num_cu;
             const i64 blocks = (c->N + PRED_LDS_BLOCK - 1) / PRED_LDS_BLOCK;
             const unsigned g2 = (unsigned)std::min<i64>(blocks, (i64)ncu * (lds <= 36 * 1024 ? 4 : 3));
             HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));

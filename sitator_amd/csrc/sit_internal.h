@@ -28,6 +28,7 @@ enum { T_FILL = 0, T_FIT = 1, T_PREDICT = 2, T_GRAM = 3, T_CENTERS = 4, T_OCC = 
 
 struct sit_ctx {
     int device = 0;
+    int num_cu = 0;                                            // compute units of the device (queried once)
     hipStream_t stream = nullptr;
     hipEvent_t tev0[T_N] = {nullptr}, tev1[T_N] = {nullptr};   // per-stage event pairs
     bool tpending[T_N] = {false};                              // recorded, not yet read
