@@ -373,7 +373,8 @@ static int run_predict(sit_ctx *c, double threshold)
     if (c->max_col <= PRED_MAXCOL) {
         HIP_TRY(c, hipMemsetAsync(wcount, 0, 4, c->stream));
         const size_t lds = (size_t)c->csc_nnz * 12 + (size_t)(c->D + 1) * 4 + (size_t)c->K * 4 + 16;
-        static const bool no_lds = getenv("SITATOR_PREDICT_LDS") && getenv("SITATOR_PREDICT_LDS")[0] == '0';
+        const char *pl = getenv("SITATOR_PREDICT_LDS");                 // "0": keep the centres in global memory (A/B, tests)
+        const bool no_lds = pl && pl[0] == '0';
         // wide rows are few (none at C2): a small grid walks their list
         const unsigned gw = (unsigned)std::min<i64>((c->N + PRED_BLOCK - 1) / PRED_BLOCK, 16384);
         if (lds <= 52 * 1024 && !no_lds) {

@@ -142,6 +142,30 @@ def test_fused_assign_equals_fill_then_predict(oracle):
     np.testing.assert_allclose(conf_b[m], conf_o[m], rtol=1e-6)
 
 
+@pytest.mark.parametrize("cfg,M,F", [("C2", 64, 400), ("C5", 160, 120)])
+def test_predict_with_centres_in_lds_equals_predict_from_global_memory(oracle, cfg, M, F):
+    """The site assignment keeps the centres' CSC arrays in LDS when they fit and counts the labels on the way; the
+    kernels that read them from global memory (larger centre sets) must give the same labels, confidences and
+    counts - narrow rows (C2) and rows wide enough for the wide-row kernel (C5)."""
+    from sitator_amd import synth
+    host = synth.config_host(cfg)
+    ctx, frames, sm, mm, ref = _setup(host, M, F, seed=41)
+    assert ctx.fill()[0] == 0
+    X = ctx.rows_dense()
+    centers = oracle.fit_centers(X, 0.45)
+    ctx.set_centers(centers / np.linalg.norm(centers, axis=1)[:, None], True)
+    lab_a, conf_a, cnt_a = ctx.predict(0.8)
+    os.environ["SITATOR_PREDICT_LDS"] = "0"
+    try:
+        lab_b, conf_b, cnt_b = ctx.predict(0.8)
+    finally:
+        os.environ.pop("SITATOR_PREDICT_LDS", None)
+    assert np.array_equal(lab_a, lab_b) and np.array_equal(conf_a, conf_b) and np.array_equal(cnt_a, cnt_b)
+    assert np.array_equal(cnt_a, np.bincount(lab_a[lab_a >= 0], minlength=len(centers)))
+    lab_o, conf_o = oracle.predict(X, centers, 0.8, True)
+    assert np.array_equal(lab_o, lab_a)
+
+
 def test_frames_beyond_sampled_displacement_fall_back_and_match_oracle(oracle):
     from sitator_amd import synth
     host = synth.config_host("C2")
