@@ -164,7 +164,8 @@ __device__ __forceinline__ i64 predict_row_merge(const PredArgs &a, i64 row, int
 // (every index below is a compile-time constant after unrolling); a step costs NW - 1 minimum operations and NW
 // predicated advances, against the row x column x row dense look-ups of predict_row_generic.
 template <int NW>
-__device__ __forceinline__ i64 predict_row_merge_wide(const PredArgs &a, i64 row, int n, double xn)
+__device__ __forceinline__ i64 predict_row_merge_wide(const PredArgs &a, i64 row, int n, double xn, const i32 *col_ptr,
+                                                      const i32 *col_k, const double *col_val)
 {
     ArgMaxQ am;
     am.init();
@@ -176,8 +177,8 @@ __device__ __forceinline__ i64 predict_row_merge_wide(const PredArgs &a, i64 row
         q[s] = 0; e[s] = 0; h[s] = none; v[s] = 0.0;
         if (s < n) {
             const i32 d = a.row_idx[(i64)s * a.N + row];
-            q[s] = a.col_ptr[d]; e[s] = a.col_ptr[d + 1]; v[s] = a.row_val[(i64)s * a.N + row];
-            h[s] = q[s] < e[s] ? a.col_k[q[s]] : none;
+            q[s] = col_ptr[d]; e[s] = col_ptr[d + 1]; v[s] = a.row_val[(i64)s * a.N + row];
+            h[s] = q[s] < e[s] ? col_k[q[s]] : none;
         }
     }
     while (true) {
@@ -190,11 +191,11 @@ __device__ __forceinline__ i64 predict_row_merge_wide(const PredArgs &a, i64 row
 #pragma unroll
         for (int s = 0; s < NW; s++) {
             if (h[s] == cid) {                                       // ascending dimension order (:176)
-                const double t = a.col_val[q[s]] * v[s];
+                const double t = col_val[q[s]] * v[s];
                 dot = first ? t : dot + t;
                 first = false;
                 q[s]++;
-                h[s] = q[s] < e[s] ? a.col_k[q[s]] : none;
+                h[s] = q[s] < e[s] ? col_k[q[s]] : none;
             }
         }
         am.push(dot, cid, xn, a.normed != 0);                       // :177-179
@@ -285,10 +286,38 @@ __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_wide(PredArgs a, co
         double xn;
         if (!predict_row_head(a, row, n, xn)) continue;
         i64 to;
-        if (n <= 8) to = predict_row_merge_wide<8>(a, row, n, xn);
-        else if (n <= 16) to = predict_row_merge_wide<16>(a, row, n, xn);
+        if (n <= 8) to = predict_row_merge_wide<8>(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
+        else if (n <= 16) to = predict_row_merge_wide<16>(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
         else to = predict_row_generic(a, row, n, xn);
         if (counts && to >= 0) atomicAdd(&counts[to], 1ull);       // the narrow rows were counted by k_predict_rows_lds
+    }
+}
+
+// The wide rows with the CSC arrays in LDS: one persistent workgroup per CU (the wide merge's registers allow three
+// waves per SIMD anyway, so up to ~150 KB of LDS cost no occupancy).  C5: 645 centres x ~12 landmarks = 93 KB.
+#define PRED_WIDE_LDS_BLOCK 768
+__global__ __launch_bounds__(PRED_WIDE_LDS_BLOCK) void k_predict_rows_wide_lds(PredArgs a, const i32 *wide_list, const unsigned *wide_count,
+                                                                              int nnzc, u64 *counts)
+{
+    extern __shared__ __attribute__((aligned(16))) char pl_smem[];
+    double *l_val = (double *)pl_smem;
+    i32 *l_ptr = (i32 *)(l_val + nnzc);
+    i32 *l_k = l_ptr + (a.D + 1);
+    const i64 nw = (i64)*wide_count;
+    if ((i64)blockIdx.x * PRED_WIDE_LDS_BLOCK >= nw) return;     // nothing for this workgroup: skip the staging
+    for (int q = threadIdx.x; q < nnzc; q += PRED_WIDE_LDS_BLOCK) { l_val[q] = a.col_val[q]; l_k[q] = a.col_k[q]; }
+    for (int q = threadIdx.x; q <= (int)a.D; q += PRED_WIDE_LDS_BLOCK) l_ptr[q] = a.col_ptr[q];
+    __syncthreads();
+    for (i64 q = (i64)blockIdx.x * PRED_WIDE_LDS_BLOCK + threadIdx.x; q < nw; q += (i64)gridDim.x * PRED_WIDE_LDS_BLOCK) {
+        const i64 row = wide_list[q];
+        int n;
+        double xn;
+        if (!predict_row_head(a, row, n, xn)) continue;
+        i64 to;
+        if (n <= 8) to = predict_row_merge_wide<8>(a, row, n, xn, l_ptr, l_k, l_val);
+        else if (n <= 16) to = predict_row_merge_wide<16>(a, row, n, xn, l_ptr, l_k, l_val);
+        else to = predict_row_generic(a, row, n, xn);
+        if (counts && to >= 0) atomicAdd(&counts[to], 1ull);
     }
 }
 
@@ -372,28 +401,34 @@ static int run_predict(sit_ctx *c, double threshold)
     bool counted = false;
     if (c->max_col <= PRED_MAXCOL) {
         HIP_TRY(c, hipMemsetAsync(wcount, 0, 4, c->stream));
-        const size_t lds = (size_t)c->csc_nnz * 12 + (size_t)(c->D + 1) * 4 + (size_t)c->K * 4 + 16;
+        const size_t csc = (size_t)c->csc_nnz * 12 + (size_t)(c->D + 1) * 4 + 16, lds = csc + (size_t)c->K * 4;
         const char *pl = getenv("SITATOR_PREDICT_LDS");                 // "0": keep the centres in global memory (A/B, tests)
         const bool no_lds = pl && pl[0] == '0';
-        // wide rows are few (none at C2): a small grid walks their list
+        if (c->num_cu <= 0) {
+            int v = 0;
+            c->num_cu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0 ? v : 256;
+        }
+        const int ncu = c->num_cu;
+        // wide rows are few (none at C2) or most (C5): a grid-stride walk of their list
         const unsigned gw = (unsigned)std::min<i64>((c->N + PRED_BLOCK - 1) / PRED_BLOCK, 16384);
-        if (lds <= 52 * 1024 && !no_lds) {
-            // three or four workgroups of 512 threads per CU; the labels are counted on the way
-            if (c->num_cu <= 0) {
-                int v = 0;
-                c->num_cu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0 ? v : 256;
-            }
-            const int ncu = c->num_cu;
+        const bool narrow_lds = lds <= 52 * 1024 && !no_lds, wide_lds = csc <= 150 * 1024 && !no_lds;
+        u64 *cnt = narrow_lds ? (u64 *)c->d_counts : nullptr;            // the LDS kernel counts the labels on the way
+        if (narrow_lds) {
+            // three or four workgroups of 512 threads per CU
             const i64 blocks = (c->N + PRED_LDS_BLOCK - 1) / PRED_LDS_BLOCK;
             const unsigned g2 = (unsigned)std::min<i64>(blocks, (i64)ncu * (lds <= 36 * 1024 ? 4 : 3));
             HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
             HIP_TRY(c, hipFuncSetAttribute((const void *)k_predict_rows_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             k_predict_rows_lds<<<dim3(g2), dim3(PRED_LDS_BLOCK), lds, c->stream>>>(a, wlist, wcount, (int)c->csc_nnz, (int)c->K, (u64 *)c->d_counts);
-            if (c->rows_W > 4) k_predict_rows_wide<<<dim3(gw), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, (u64 *)c->d_counts);
             counted = true;
-        } else {
+        } else
             k_predict_rows<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount);
-            if (c->rows_W > 4) k_predict_rows_wide<<<dim3(gw), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, nullptr);
+        if (c->rows_W > 4) {
+            if (wide_lds) {
+                HIP_TRY(c, hipFuncSetAttribute((const void *)k_predict_rows_wide_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)csc));
+                k_predict_rows_wide_lds<<<dim3((unsigned)ncu), dim3(PRED_WIDE_LDS_BLOCK), csc, c->stream>>>(a, wlist, wcount, (int)c->csc_nnz, cnt);
+            } else
+                k_predict_rows_wide<<<dim3(gw), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, cnt);
         }
     } else k_predict_rows_dense<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
     HIP_TRY(c, hipGetLastError());
