@@ -42,6 +42,7 @@
 #define FS_W0 (FS_BMAX / 64)      // bitmap words per centre, level 0 (bit = batch row)
 #define FS_W1 (FS_W0 / 64)        // level 1 (bit = level-0 word is non-zero)
 #define FS_LOG 2048               // support-growth records per walk
+#define FS_BMW 256                // words of a row's bitmap of centres already listed (speculation)
 #define FS_NP 16                  // row entries staged per joining row
 #define FS_LCAP 8192              // joining rows listed at a time by a walking wave
 #define FS_TAIL 32                // rows the commit may apply one at a time
@@ -301,7 +302,7 @@ __device__ __forceinline__ i32 group_mex(const i32 *ovl, int m, int gl)
 // FS_NEW or FS_BREAK, uniform over the group.
 template <int NR, int NS, int G>
 __device__ __forceinline__ int fs_decide(const FS &s, const FSRows &r, i64 row, int K, double threshold, i32 *ovl,
-                                         int gl, int &nov_out, double &xn_out)
+                                         unsigned *seen, int gl, int &nov_out, double &xn_out)
 {
     Row<NR> R;
     row_load(R, r, row);
@@ -309,7 +310,14 @@ __device__ __forceinline__ int fs_decide(const FS &s, const FSRows &r, i64 row, 
     const double xn = row_norm(R, r, row);
     int nov = 0;
     Best best = best_empty();
-    for (int t0 = 0; (t0 >> 3) < n; t0 += G) {                  // eight slots per entry and round
+    const bool listed = K <= FS_BMW * 32;      // the group's bitmap of centres holds them all
+    if (listed) for (int w = gl; w < ((K + 31) >> 5); w += G) seen[w] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    // lane <-> (row entry e, slot of the centre list of its dimension); eight slots per entry and round.  A centre
+    // listed under several of the row's dimensions is taken once: by whoever marks it first in the bitmap (then the
+    // candidates are scored in a second sweep, a lane each), or - more centres than the bitmap holds - by the
+    // entry that its support meets first, which the dot product finds out.
+    for (int t0 = 0; (t0 >> 3) < n; t0 += G) {
         const int t = t0 + gl, e = t >> 3;
         const bool live = e < n;
         i32 d = 0, c0 = 0;
@@ -326,16 +334,21 @@ __device__ __forceinline__ int fs_decide(const FS &s, const FSRows &r, i64 row, 
             i32 c = 0;
             if (live && q < m) {
                 c = q0 == 0 ? c0 : s.dc_list[(i64)d * FS_DC + q];
-                Sup<NS> S;
-                sup_load(S, s.cs_idx + (i64)c * FS_CS, s.cs_val + (i64)c * FS_CS, s.cs_n[c]);
-                const double nrm = s.c_nrm[c];
-                int first;
-                double dot = row_dot(R, r, row, S, first);
-                uniq = first == e;                              // a centre met under an earlier entry is scored there
-                if (uniq) {
-                    dot /= nrm;                                 // :239
-                    dot /= xn;                                  // :240
-                    best = best_merge(best, best_of(dot, c));
+                if (listed) {
+                    const unsigned bit = 1u << (c & 31);
+                    uniq = (atomicOr(&seen[c >> 5], bit) & bit) == 0u;
+                } else {
+                    Sup<NS> S;
+                    sup_load(S, s.cs_idx + (i64)c * FS_CS, s.cs_val + (i64)c * FS_CS, s.cs_n[c]);
+                    const double nrm = s.c_nrm[c];
+                    int first;
+                    double dot = row_dot(R, r, row, S, first);
+                    uniq = first == e;
+                    if (uniq) {
+                        dot /= nrm;                             // :239
+                        dot /= xn;                              // :240
+                        best = best_merge(best, best_of(dot, c));
+                    }
                 }
             }
             const u64 ub = gballot<G>(uniq);
@@ -347,6 +360,20 @@ __device__ __forceinline__ int fs_decide(const FS &s, const FSRows &r, i64 row, 
         }
     }
     __builtin_amdgcn_wave_barrier();
+    if (listed) {
+        const int keep = nov < FS_OC ? nov : FS_OC;
+        for (int p = gl; p < keep; p += G) {
+            const i32 c = ovl[p];
+            Sup<NS> S;
+            sup_load(S, s.cs_idx + (i64)c * FS_CS, s.cs_val + (i64)c * FS_CS, s.cs_n[c]);
+            const double nrm = s.c_nrm[c];
+            int first;
+            double dot = row_dot(R, r, row, S, first);
+            dot /= nrm;                                         // :239
+            dot /= xn;                                          // :240
+            best = best_merge(best, best_of(dot, c));
+        }
+    }
     best = greduce<G>(best);
     nov_out = nov; xn_out = xn;
     if (n == 0) return K == 0 ? FS_NEW : FS_BREAK;              // zero row: NaN argmax semantics, serial path
@@ -358,14 +385,14 @@ __device__ __forceinline__ int fs_decide(const FS &s, const FSRows &r, i64 row, 
 // ---- A: speculate ---------------------------------------------------------------------------------
 template <int NR, int NS, int G>
 __device__ __forceinline__ void fs_speculate(const FS &s, const FSRows &r, FSCtl *ctl, int nb, int K, i64 pos,
-                                             double threshold, i32 *ovl)
+                                             double threshold, i32 *ovl, unsigned *seen)
 {
     const int gl = threadIdx.x & (G - 1);
     const int j = (int)(((i64)blockIdx.x * 256 + threadIdx.x) / G);
     if (j >= nb) return;                                        // uniform over the group
     int nov;
     double xn;
-    const int dec = fs_decide<NR, NS, G>(s, r, pos + j, K, threshold, ovl, gl, nov, xn);
+    const int dec = fs_decide<NR, NS, G>(s, r, pos + j, K, threshold, ovl, seen, gl, nov, xn);
     const int keep = nov < FS_OC ? nov : FS_OC;
     for (int p = gl; p < keep; p += G) OV(s, j, p) = ovl[p];
     if (gl == 0) {
@@ -381,13 +408,14 @@ template <int NR, int NS>
 __global__ __launch_bounds__(256) void k_fs_speculate(FS s, FSRows r, int par, double threshold)
 {
     __shared__ i32 ovl[16 * FS_OC];
+    __shared__ unsigned seen[16 * FS_BMW];
     FSCtl *ctl = s.ctl + par;
     if (ctl->halt) return;
     const int nb = ctl->nb, K = ctl->K;
     const i64 pos = ctl->pos;
     // small batches: a wave per row (latency); large ones: sixteen lanes per row (throughput)
-    if (nb <= 16384) fs_speculate<NR, NS, 64>(s, r, ctl, nb, K, pos, threshold, ovl + (threadIdx.x >> 6) * FS_OC);
-    else fs_speculate<NR, NS, 16>(s, r, ctl, nb, K, pos, threshold, ovl + (threadIdx.x >> 4) * FS_OC);
+    if (nb <= 16384) fs_speculate<NR, NS, 64>(s, r, ctl, nb, K, pos, threshold, ovl + (threadIdx.x >> 6) * FS_OC, seen + (threadIdx.x >> 6) * FS_BMW);
+    else fs_speculate<NR, NS, 16>(s, r, ctl, nb, K, pos, threshold, ovl + (threadIdx.x >> 4) * FS_OC, seen + (threadIdx.x >> 4) * FS_BMW);
 }
 
 // ---- the join lists: bitmaps --------------------------------------------------------------------------------
@@ -883,6 +911,7 @@ __global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, doubl
     __shared__ i32 ri[FS_NP];
     __shared__ double rv[FS_NP];
     __shared__ i32 ovl[FS_OC];
+    __shared__ unsigned seen[FS_BMW];
     FSCtl *ctl = s.ctl + par, *nxt = s.ctl + (par ^ 1);
     const int lane = threadIdx.x;
     if (ctl->halt) {
@@ -939,7 +968,7 @@ __global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, doubl
                 if (Kn >= s.Kcap) break;
                 int nov;
                 double xn;
-                const int dec = fs_decide<NR, NS, 64>(s, r, pos + q, Kn, threshold, ovl, lane, nov, xn);
+                const int dec = fs_decide<NR, NS, 64>(s, r, pos + q, Kn, threshold, ovl, seen, lane, nov, xn);
                 if (dec == FS_BREAK) break;                       // the next step meets it at its own first row
                 if (!fs_apply_row(s, r, ctl, pos + q, q, dec, -1, xn, Kn, ri, rv, lane)) break;
                 applied++;
