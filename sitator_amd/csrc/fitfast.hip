@@ -706,6 +706,8 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
                 __builtin_amdgcn_wave_barrier();
                 const u64 gm = __ballot(grow);
                 const int s1 = gm ? __ffsll((long long)gm) - 1 : Tg;
+                FF_T(t_l1);
+                FF_ACC(2, t_l1 - t_l0);
                 // the chain: per join multiply, add, divide (a / b as RN(a * RN(1 / b)) with one exact-residual
                 // correction: bit-identical to the IEEE quotient) and the version.  The join's constants come out of
                 // its lane's registers; what it adds to my slot is read from LDS one join ahead.
