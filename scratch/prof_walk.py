@@ -10,7 +10,7 @@ host = synth.config_host("C2")
 ctx, *_ = _setup(host, 64, F, seed=31)
 assert ctx.fill()[0] == 0
 lib = _lib.load()
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 12)()
 lib.sit_debug_ff_prof(out, 1)
 t = time.time()
 clf = DotProdClassifier(threshold=0.45, min_samples=1)
@@ -24,3 +24,4 @@ joins, groups, waves = v[5], v[6], v[7]
 print("joins %d groups %d waves-with-joins %d" % (joins, groups, waves))
 for n, c in zip(names, v[:5]):
     print("%-14s %.3g cycles  (%.0f per join, %.0f per group, %.0f per wave)" % (n, c, c / max(joins, 1), c / max(groups, 1), c / max(waves, 1)))
+print("longest walking wave: %d cycles, %d joins, %d groups" % (v[8], v[9], v[10]))

@@ -554,6 +554,7 @@ struct Walker {
 // cycles of the walking waves: [0] listing, [1] group set-up, [2] look-ups, [3] join loops, [4] general joins;
 // counts: [5] joins, [6] groups, [7] waves with joins
 __device__ unsigned long long ff_prof[8];
+__device__ unsigned long long ff_wmax[4];   // longest walking wave: cycles, its joins, its groups, its general joins
 #define FF_T(x) const long long x = clock64()
 #define FF_ACC(i, v) do { if (threadIdx.x == 0) atomicAdd(&ff_prof[i], (unsigned long long)(v)); } while (0)
 #else
@@ -754,6 +755,12 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
         }
         a = b; Pa = Pb;
     }
+#ifdef FF_PROFILE
+    {
+        const unsigned long long dt = (unsigned long long)(clock64() - t_list0);
+        if (threadIdx.x == 0 && dt > ff_wmax[0]) { ff_wmax[0] = dt; ff_wmax[1] = (unsigned long long)T; ff_wmax[2] = (unsigned long long)((T + 63) / 64); }
+    }
+#endif
 }
 
 __global__ __launch_bounds__(64) void k_fs_walk(FS s, FSRows r, int par)
@@ -1015,6 +1022,7 @@ __global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, doubl
 extern "C" void sit_debug_ff_prof(unsigned long long *out, int reset)
 {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ff_prof), sizeof(ff_prof));
+    (void)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(ff_wmax), sizeof(ff_wmax));
     if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(ff_prof), z, sizeof(z)); }
 }
 #endif
