@@ -112,16 +112,17 @@ def test_full_size_two_shards_equal_one_pass(c2_full):
     assert np.array_equal(np.concatenate(labels).reshape(100000, 64), st.traj)
 
 
-def test_c3_full_length_properties_and_sampled_oracle(oracle):
+@pytest.mark.parametrize("cfg,M,F", [("C3", 448, 250000), ("C4", 256, 125000)])
+def test_full_length_properties_and_sampled_oracle(oracle, cfg, M, F):
     """BASELINE configs[2] at its stated size: LLZO-like cell, 448 mobile ions, 250 000 frames = 1.12e8 landmark
-    vectors (9.2 GB of frames, resident in HBM).  Size-independent properties, and landmark vectors / labels of a random
+    vectors (9.2 GB of frames, resident in HBM), and one rank's share of configs[3] (1 000 000 frames over 8 GPUs:
+    125 000 frames x 256 ions, 6.9 GB).  Size-independent properties, and landmark vectors / labels of a random
     sample of frames against the CPU oracle."""
     import psutil
     from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth
     if psutil.virtual_memory().available < 30 * 2 ** 30:
-        pytest.skip("needs ~20 GB of host memory for the 9.2 GB trajectory")
-    host = synth.config_host("C3")
-    M, F = 448, 250000
+        pytest.skip("needs ~20 GB of host memory for the trajectory")
+    host = synth.config_host(cfg)
     gen = synth.TrajectoryGenerator(host, M, seed=3, threads=16)
     ref = gen.reference_positions()
     frames = gen.generate(F)
