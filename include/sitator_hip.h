@@ -268,9 +268,11 @@ int sit_timers(sit_ctx *ctx, double *ms, int n);
  * candidates per bin (loose), [2] longest tight list, [3] mean candidates per bin (tight),
  * [4] delta (sampled static displacement bound, A), [5] frames of the last fill that exceeded
  * delta, [6..8] loose grid, [9..11] tight grid, [12] frames per workgroup of the last fill,
- * [13] verified batches / [14] serially applied rows / [15] re-walks of the last speculative fit,
+ * [13] steps (speculate / walk / verify / commit) / [14] rows applied one at a time (cluster-founding rows and the
+ * rows at a cut) / [15] steps cut short by a wrong speculation, summed over the speculative fits of the context,
  * [16] generation of the fill kernel the last sit_fill launched (1, 2 or 3), [17] survivor slots per wave and
- * [18] waves per workgroup of that launch.                                                              */
+ * [18] waves per workgroup of that launch, [19] capacity bits that ended a speculative fit (0: none) and
+ * [20] the row it stopped at, [24..27] work census of a SITATOR_DEBUG_STOP=9 fill.                         */
 int sit_info(sit_ctx *ctx, double *out, int n);
 int sit_synchronize(sit_ctx *ctx);
 
