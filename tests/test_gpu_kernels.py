@@ -389,6 +389,55 @@ def test_speculative_fit_on_random_sparse_rows(oracle, seed, D, N, maxnnz):
     np.testing.assert_allclose(clf.cluster_centers, exp, rtol=1e-12, atol=1e-300)
 
 
+def _capacity_case(kind):
+    """Rows built to run one capacity of the sparse clustering state over (fitfast.hip: 63 support entries per
+    centre, 64 centres per landmark dimension, 64 candidate centres per row)."""
+    rng = np.random.default_rng(3)
+    if kind == "support":          # every row keeps joining one centre and brings a new dimension
+        D, N = 128, 110
+        X = np.zeros((N, D))
+        X[:, 0] = 1.0
+        for i in range(1, N):
+            X[i, i] = 0.02
+        thr, bit = 0.9, 8
+    elif kind == "dimension":      # a hundred centres that all hold dimension 0
+        D, N = 128, 100
+        X = np.zeros((N, D))
+        X[:, 0] = 1.0
+        for i in range(N):
+            X[i, 1 + i] = 1.0
+        thr, bit = 0.9, 1
+    else:                          # "candidates": a row that overlaps seventy single-dimension centres
+        D, N = 128, 90
+        X = np.zeros((N, D))
+        for i in range(70):
+            X[i, i] = 1.0
+        X[70:, :70] = rng.uniform(0.5, 1.0, size=(N - 70, 70))
+        thr, bit = 0.9, 2
+    tail = np.zeros((40, D))       # rows after the capacity was hit: the serial stream carries on exactly
+    tail[np.arange(40), rng.integers(0, D, size=40)] = 1.0
+    return np.vstack([X, tail]), thr, bit
+
+
+@pytest.mark.parametrize("kind", ["support", "dimension", "candidates"])
+def test_speculative_fit_capacities_hand_over_to_the_serial_stream(oracle, kind):
+    """When a capacity of the sparse state does not fit, the step chain stops with the state exact as of that row
+    and the single-workgroup stream takes over: same centres as the oracle's ordered stream, and the context says
+    which capacity it was."""
+    from sitator_amd import DotProdClassifier
+    from sitator_amd.dotprod_classifier import _as_device_rows
+    X, thr, bit = _capacity_case(kind)
+    lv = _as_device_rows(X)
+    clf = DotProdClassifier(threshold=thr, min_samples=1)
+    clf.fit_centers(lv)
+    info = lv.ctx.info()
+    assert info["fit_capacity_hit"] & bit, info
+    assert 0 <= info["fit_stop_row"] < len(X)
+    exp = oracle.fit_centers(X, thr)
+    assert clf.cluster_centers.shape == exp.shape
+    np.testing.assert_allclose(clf.cluster_centers, exp, rtol=1e-12, atol=1e-300)
+
+
 def test_speculative_fit_grows_its_state_past_the_first_allocation():
     """More than 2048 clusters: the sparse clustering state is exported, reallocated and re-imported mid-stream.
     Checked against the ordered single-workgroup stream (itself checked against the oracle above)."""
