@@ -5,10 +5,11 @@
 // does exactly that with one workgroup.  Here the same result is produced in parallel, a batch of rows at a time,
 // by four kernels per step, enqueued without the host looking at anything in between (all control state lives in a
 // device block, FSCtl; the host reads it back once per chunk of steps):
-//   A  speculate  decide every row of the batch against the centres AS OF THE BATCH START.  A group of lanes per row,
-//                 a lane per (row dimension, centre listed under it): three memory round trips per row.  The row's
-//                 candidates (the centres that share a dimension with it: only those can score != 0) are recorded,
-//                 and the row sets its bit in the joined centre's bitmap (two levels: rows, words).
+//   A  speculate  decide every row of the batch against the centres AS OF THE BATCH START.  A group of lanes per row:
+//                 a lane per (row dimension, centre listed under it) collects the row's candidates (the centres that
+//                 share a dimension with it: only those can score != 0), each once, then a lane per candidate scores
+//                 it - a handful of memory round trips per row.  The candidates are recorded, and the row sets its
+//                 bit in the joined centre's bitmap (two levels: rows, words).
 //   B  walk       a wave per centre applies, IN ROW ORDER (the bitmap is the sorted join list), the running-mean
 //                 updates of the rows speculated to join it -- bit for bit the reference's arithmetic -- and publishes
 //                 every intermediate state as a VERSION keyed by the joining row.  Centres evolve independently given
