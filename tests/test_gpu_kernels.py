@@ -389,6 +389,39 @@ def test_speculative_fit_on_random_sparse_rows(oracle, seed, D, N, maxnnz):
     np.testing.assert_allclose(clf.cluster_centers, exp, rtol=1e-12, atol=1e-300)
 
 
+@pytest.mark.parametrize("seed,D,N,maxnnz,nproto,thr,dwell", [(1, 64, 20000, 13, 400, 0.9, 8), (2, 24, 70000, 4, 5, 0.9, 200),
+                                                               (3, 1500, 20000, 13, 40, 0.6, 1), (4, 200, 70000, 2, 4000, 0.9, 1)])
+def test_speculative_fit_is_bit_identical_to_the_serial_stream(seed, D, N, maxnnz, nproto, thr, dwell):
+    """Rows drawn from prototypes with a dwell time (trajectory-like runs of joins to one centre, or none), wide and
+    narrow, few and thousands of clusters: the step chain and the single-workgroup stream apply the same arithmetic
+    in the same order, so their centres are equal bit for bit (scratch/fuzz_fit.py runs more of these)."""
+    from sitator_amd import DotProdClassifier
+    rng = np.random.default_rng(seed)
+    proto = rng.integers(0, D, size=(nproto, maxnnz))
+    pw = rng.uniform(0.05, 1.0, size=(nproto, maxnnz))
+    X = np.zeros((N, D))
+    i = 0
+    while i < N:
+        p = int(rng.integers(nproto))
+        for _ in range(dwell):
+            if i >= N:
+                break
+            k = int(rng.integers(1, maxnnz + 1))
+            X[i, proto[p, :k]] = pw[p, :k] * rng.uniform(0.9, 1.1, size=k)
+            i += 1
+    got = []
+    for serial in (False, True):
+        if serial:
+            os.environ["SITATOR_FIT"] = "serial"
+        try:
+            clf = DotProdClassifier(threshold=thr, min_samples=1, max_converge_iters=30)
+            clf.fit_centers(X)
+            got.append(clf.cluster_centers)
+        finally:
+            os.environ.pop("SITATOR_FIT", None)
+    assert got[0].shape == got[1].shape and np.array_equal(got[0], got[1])
+
+
 def _capacity_case(kind):
     """Rows built to run one capacity of the sparse clustering state over (fitfast.hip: 63 support entries per
     centre, 64 centres per landmark dimension, 64 candidate centres per row)."""
