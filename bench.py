@@ -10,14 +10,17 @@ path over the resident trajectory: wrap + static-lattice check + landmark vector
 (frame, mobile ion) + cosine assignment to the fitted site centres -> int64 label + float64
 confidence per (frame, ion).  Frames are resident in HBM before the timed region; the site
 centres come from the product's own end-to-end `run()` on the same trajectory (outside the timed
-region; its wall time is reported as `end_to_end_run`).
+region; it is run twice - `end_to_end_run.seconds` is the second, warm run, `cold_seconds` the first one of the
+process).
 
 N > 1: one process per GPU.  Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks come from
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; a bare `python bench.py --gpus N` starts the N ranks itself (fresh child
 processes, before anything touches a GPU).  The ranks talk through the library's own RCCL entry points
 (`sit_comm_*`, sitator_amd/sharding.py `RcclComm`) - the end-to-end run exercises every exchange step of the path
 (first-offender keys, counts, the ordered fit relay, site-centre anchors and sums, occupancy); the timed pass has no
-collective in it (frames shard embarrassingly) and is bracketed by an RCCL barrier on both sides.
+collective in it (frames shard embarrassingly) and is bracketed by a barrier on both sides.  A gloo group (CPU) is the
+control plane: it carries the 128-byte RCCL unique id and the ranks' agreement that every one of them got its
+communicator; if one did not, the (tiny) exchange steps run over gloo and `end_to_end_run.exchange` says so.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the fill kernel that ran: k_fill3 unless the
 tables force an older generation) with the algorithmic bytes of SURVEY.md section 8(d): B = 24*A/M + 16 bytes per
