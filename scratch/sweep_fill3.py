@@ -46,10 +46,13 @@ for stop in (1, 4):
 shapes = [(4, 1, 48, 16), (4, 1, 40, 16), (4, 1, 32, 16), (4, 2, 48, 32), (4, 2, 64, 32), (8, 2, 40, 16), (8, 1, 24, 8), (4, 1, 40, 32), (8, 1, 40, 16)]
 if len(sys.argv) > 3:
     shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[3:]]
-for nw, fpb, rcap, iw in shapes:
+for shape in shapes:
+    nw, fpb, rcap, iw = shape[:4]
     env = dict(SITATOR_FILL_WAVES=nw, SITATOR_FILL_FPB=fpb, SITATOR_FILL_RCAP=rcap, SITATOR_FILL_IW=iw)
+    if len(shape) > 4:
+        env["SITATOR_FILL_TCAP"] = shape[4]
     try:
         t = run(ctx3, **env)
-        print("  nw %2d fpb %d rcap %2d iw %2d: min %.4f med %.4f ms (nw used %d)" % (nw, fpb, rcap, iw, t[0], t[1], t[2]["waves_per_workgroup"]), flush=True)
+        print("  nw %2d fpb %d rcap %2d iw %2d tcap %s: min %.4f med %.4f ms (nw used %d)" % (nw, fpb, rcap, iw, shape[4] if len(shape) > 4 else "-", t[0], t[1], t[2]["waves_per_workgroup"]), flush=True)
     except AssertionError as e:
         print("  nw %d fpb %d rcap %d iw %d: failed %s" % (nw, fpb, rcap, iw, e), flush=True)

@@ -26,7 +26,11 @@
 // LDS per workgroup is ~32 KB at 64 ions and 512 statics (five workgroups = 20 waves per CU).
 // Kept from fill2: tight/loose pruning tables, error keys, slot-major sparse rows, exactness rules.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
+#include <algorithm>
 #include <cstring>
 
 #include "sit_internal.h"
@@ -60,7 +64,7 @@ struct Fill3Head {
     const double2 *exptab;
     u64 *err, *scal;
     i64 F, A, frame0;
-    int S, M, fpb, contig, debug_stop, rcap, iw, force_loose, s0, m0;
+    int S, M, fpb, contig, debug_stop, rcap, iw, force_loose, s0, m0, tcap;
     double delta2, thr2_lo, thr2_hi, static_thr, safe2;
 };
 typedef const Fill3Args __attribute__((address_space(4))) *Fill3ArgsPtr;
@@ -209,13 +213,13 @@ __device__ __forceinline__ int wave_add_scan(int x)
     return x;
 }
 
-#define F3_TCAP 128        // (ion, landmark) tasks of a wave batch
+#define F3_TCAP 128        // (ion, landmark) tasks of a wave batch: the default; bases with long candidate lists take more
 
 // LDS of a wave, in bytes: `rcap` survivor slots (multiple of 8, <= 64), windows of `iw` ions (multiple of 4, <= 64)
-__host__ __device__ inline int f3_wave_bytes(int rcap, int vp, int iw)
+__host__ __device__ inline int f3_wave_bytes(int rcap, int vp, int iw, int tcap)
 {
     return rcap * vp * 8         // sd2: squared distances, then logistic factors, of the survivors
-         + F3_TCAP * 4           // ttab: landmark | critical vertex << 22 | ion << 26 per task
+         + tcap * 4              // ttab: landmark | critical vertex << 22 | ion << 26 per task
          + rcap * 4              // sv_k: the task of every survivor
          + iw * 16               // info: per ion of the window {offset vector, statics of its frame (byte offsets), frame}
          + iw * 4;               // entries written per ion
@@ -238,13 +242,14 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     const int rcap = h.rcap;
     // layout: [per-wave buffers] [exp table] [atoms: per frame statics then mobiles] [frame flags]
     const int IW = h.iw;
-    char *lp = smem + wave * f3_wave_bytes(rcap, VP, IW);
+    const int TCAP = h.tcap;
+    char *lp = smem + wave * f3_wave_bytes(rcap, VP, IW, TCAP);
     double *sd2 = (double *)lp; lp += rcap * VP * 8;
-    unsigned *ttab = (unsigned *)lp; lp += F3_TCAP * 4;
+    unsigned *ttab = (unsigned *)lp; lp += TCAP * 4;
     unsigned *sv_k = (unsigned *)lp; lp += rcap * 4;
     uint4 *info = (uint4 *)lp; lp += IW * 16;
     unsigned *nzc = (unsigned *)lp;
-    double2 *etab = (double2 *)(smem + NW * f3_wave_bytes(rcap, VP, IW));
+    double2 *etab = (double2 *)(smem + NW * f3_wave_bytes(rcap, VP, IW, TCAP));
     double *xyz = (double *)(etab + F3_EXPN);                   // [fpb][S + M][3]; mobiles become centroid - ion
     u64 *fmax = (u64 *)(xyz + 3 * fpb * SM);                    // [fpb]
     const Pbc &P = h.P;
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     if (tid < fpb) fmax[tid] = 0ull;
     double2 etv = make_double2(0.0, 0.0);
     if (tid < F3_EXPN) etv = h.exptab[tid];                    // in flight beside the frame loads; parked below
-    for (int q = lane; q < F3_TCAP; q += 64) ttab[q] = 0u;     // stale entries must stay valid (landmark 0, ion 0)
+    for (int q = lane; q < TCAP; q += 64) ttab[q] = 0u;     // stale entries must stay valid (landmark 0, ion 0)
     if (lane < IW) info[lane] = make_uint4(0u, 0u, 0u, 0u);
     // ---- phase 1a: copy this workgroup's atoms into LDS, eight independent loads per thread in flight ----
     {
@@ -379,9 +384,9 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
         const int inL = wave_add_scan(nL), exL = inL - nL;
         int ion_s = 0;
         while (ion_s < nib) {
-            // batch [ion_s, ion_e): whole ions, at most F3_TCAP tasks
+            // batch [ion_s, ion_e): whole ions, at most TCAP tasks
             const int preL = __shfl(exL, ion_s);
-            const unsigned long long fit = __ballot(lane >= ion_s && lane < nib && inL - preL <= F3_TCAP);
+            const unsigned long long fit = __ballot(lane >= ion_s && lane < nib && inL - preL <= TCAP);
             if (!fit) { if (lane == 0) atomicAdd(&h.scal[3], 1ull); break; }       // cannot happen (host checks)
             const int ion_e = ion_s + __popcll(fit);
             const int nlt = __shfl(inL, ion_e - 1) - preL;
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                     for (int u = 0; u < 2; u++) {
                         if (u == 1 && !two) { bad[1] = ~0ull; tk[1] = 0u; d2[1] = 0.0; break; }
                         const int t = TPP * (cursor + u) + (lane >> LG);
-                        tk[u] = ttab[t < F3_TCAP ? t : 0];
+                        tk[u] = ttab[t < TCAP ? t : 0];
                         const unsigned k = tk[u] & 0x3fffffu;
                         const uint4 iv = info[tk[u] >> 26];
                         i32 v = verts[k * VP + hh];
@@ -608,6 +613,36 @@ bool fill3_eligible(sit_ctx *c)
     return true;
 }
 
+// the instantiation for this cell / landmark width / waves per workgroup / mapping mode
+static hipError_t f3_dispatch(sit_ctx *c, const Fill3Head &h, Fill3ArgsPtr full, unsigned grid, size_t lds, int nw, int vp,
+                              bool diag, bool dynmap)
+{
+#define F3_LAUNCH(CELL, LGV, NWV, DY)                                                                                          \
+    do {                                                                                                                   \
+        hipError_t e = hipFuncSetAttribute((const void *)k_fill3<CELL, LGV, NWV, DY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                     \
+        k_fill3<CELL, LGV, NWV, DY><<<dim3(grid), dim3(NWV * 64), lds, c->stream>>>(h, full);                              \
+    } while (0)
+#define F3_PICK2(CELL, LGV, NWV)                                                                                               \
+    do { if (dynmap) F3_LAUNCH(CELL, LGV, NWV, 1); else F3_LAUNCH(CELL, LGV, NWV, 0); } while (0)
+#define F3_PICK(CELL, LGV)                                                                                                     \
+    do {                                                                                                                   \
+        if (nw == 16) F3_PICK2(CELL, LGV, 16); else if (nw == 8) F3_PICK2(CELL, LGV, 8); else F3_PICK2(CELL, LGV, 4);      \
+    } while (0)
+    if (diag) { if (vp == 8) F3_PICK(1, 3); else F3_PICK(1, 2); }
+    else { if (vp == 8) F3_PICK(0, 3); else F3_PICK(0, 2); }
+#undef F3_PICK
+#undef F3_PICK2
+#undef F3_LAUNCH
+    return hipGetLastError();
+}
+
+// Survivor slots and task-table size of a wave depend on what the data does (C5 keeps six components per ion, C3
+// one): the first fill of a kind times the candidates on the leading frames and the process remembers the choice.
+struct F3Tuned { i64 key[8]; int rcap, tcap; };
+static std::mutex g_f3_mutex;
+static std::vector<F3Tuned> g_f3_tuned;
+
 int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
 {
     const i64 S = c->S, M = c->M;
@@ -672,8 +707,14 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
         const i64 per = ((i64)fpbv * M + nwv - 1) / nwv;
         return (int)(per < 16 ? 16 : (per > 64 ? 64 : (per + 3) / 4 * 4));
     };
+    // tasks of a wave batch: 128, or more where the candidate lists are long (C3: 7 per ion, C5: 9) so that a batch
+    // still holds a window's ions
+    int tcap = f3_env_int("SITATOR_FILL_TCAP", 0);
+    const bool tcap_auto = tcap < 64 || tcap > 1024;
+    if (tcap_auto) tcap = F3_TCAP;
+    tcap = (tcap + 63) / 64 * 64;
     auto lds_bytes = [&](int nwv, int fpbv, int rcapv) {
-        return (size_t)nwv * f3_wave_bytes(rcapv, vp, iw_for(nwv, fpbv)) + F3_EXPN * 16 + (size_t)fpbv * frame_bytes + (size_t)fpbv * 8 + 32;
+        return (size_t)nwv * f3_wave_bytes(rcapv, vp, iw_for(nwv, fpbv), tcap) + F3_EXPN * 16 + (size_t)fpbv * frame_bytes + (size_t)fpbv * 8 + 32;
     };
     if (nw != 4 && nw != 8 && nw != 16) {
         // small frames: 4 waves and several workgroups per CU; a frame that leaves room for one workgroup only: 16
@@ -686,13 +727,22 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
         auto wg_per_cu = [&](int r) { const size_t b = (lds_bytes(nw, fpb, r) + 1535) / 1024 * 1024; size_t k = (160 * 1024) / b; return k > 8 ? (size_t)8 : k; };
         for (int r : {40, 32}) if (wg_per_cu(r) > wg_per_cu(rcap)) rcap = r;
     }
+    if (tcap_auto) {
+        // a batch should hold the ions of a window: (mean candidates per ion + 1) x ions, in steps of 64 up to 512,
+        // as long as that does not cost a workgroup per CU (C3: 1.79 -> 1.58 ms, C5: 3.29 -> 3.16 ms)
+        const double per_ion = (have_tight ? c->tight_mean_candidates : c->mean_candidates) + 1.0;
+        int want = (int)(per_ion * iw_for(nw, fpb));
+        want = want < F3_TCAP ? F3_TCAP : (want > 512 ? 512 : (want + 63) / 64 * 64);
+        auto wgs = [&](int t) { const int keep = tcap; tcap = t; const size_t b = (lds_bytes(nw, fpb, rcap) + 1535) / 1024 * 1024; tcap = keep; return (160 * 1024) / b; };
+        const size_t base = wgs(F3_TCAP);
+        int pick = F3_TCAP;
+        for (int t = F3_TCAP + 64; t <= want; t += 64) if (wgs(t) == base) pick = t;
+        tcap = pick;
+    }
     while (fpb > 1 && lds_bytes(nw, fpb, rcap) > 160 * 1024 - 512) fpb--;
-    const size_t lds = lds_bytes(nw, fpb, rcap);
-    SIT_REQUIRE(c, lds <= 160 * 1024 - 256, "sit_fill: one frame's atoms do not fit in LDS");
+    SIT_REQUIRE(c, lds_bytes(nw, fpb, rcap) <= 160 * 1024 - 256, "sit_fill: one frame's atoms do not fit in LDS");
     iw = iw_for(nw, fpb);
-    h.fpb = fpb; h.rcap = rcap; h.iw = iw;
-    c->last_fpb = fpb; c->last_kernel = 3; c->last_iw = rcap; c->last_nw = nw;
-    const unsigned grid = (unsigned)((c->F + fpb - 1) / fpb);
+    h.fpb = fpb; h.iw = iw;
     if (!c->d_fill_args) {
         if ((rc = dev_alloc(c, &c->d_fill_args, (i64)std::max(sizeof(Fill3Args), (size_t)1024)))) return rc;
         c->fill_args_host.clear();
@@ -707,22 +757,67 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
     if (contig && c->idx_s0 == 0 && c->idx_m0 == S && c->A == S + M) contig = 2;
     { const int forced = f3_env_int("SITATOR_FILL_CONTIG", -1); if (forced >= 0 && forced < contig) contig = forced; }
     h.contig = contig;
-#define F3_LAUNCH(CELL, LGV, NWV, DY)                                                                                          \
-    do {                                                                                                                   \
-        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill3<CELL, LGV, NWV, DY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        k_fill3<CELL, LGV, NWV, DY><<<dim3(grid), dim3(NWV * 64), lds, c->stream>>>(h, full);                              \
-    } while (0)
-#define F3_PICK2(CELL, LGV, NWV)                                                                                               \
-    do { if (dynmap) F3_LAUNCH(CELL, LGV, NWV, 1); else F3_LAUNCH(CELL, LGV, NWV, 0); } while (0)
-#define F3_PICK(CELL, LGV)                                                                                                     \
-    do {                                                                                                                   \
-        if (nw == 16) F3_PICK2(CELL, LGV, 16); else if (nw == 8) F3_PICK2(CELL, LGV, 8); else F3_PICK2(CELL, LGV, 4);      \
-    } while (0)
-    if (diag) { if (vp == 8) F3_PICK(1, 3); else F3_PICK(1, 2); }
-    else { if (vp == 8) F3_PICK(0, 3); else F3_PICK(0, 2); }
-#undef F3_PICK
-#undef F3_PICK2
-#undef F3_LAUNCH
-    HIP_TRY(c, hipGetLastError());
+
+    // ---- survivor slots / task-table size: measured once per kind of fill ----
+    if (rcap_auto && tcap_auto && h.debug_stop == 0 && f3_env_int("SITATOR_FILL_AUTOTUNE", 1) && c->F * M >= (1 << 18)) {
+        const i64 key[8] = {S, M, c->D, vp, have_tight ? c->W_tight : c->W, (i64)nw * 64 + fpb, dynmap ? 1 : 0, (i64)(c->tight_mean_candidates * 1024)};
+        bool found = false;
+        {
+            std::lock_guard<std::mutex> lock(g_f3_mutex);
+            for (const F3Tuned &t : g_f3_tuned) if (memcmp(t.key, key, sizeof(key)) == 0) { rcap = t.rcap; tcap = t.tcap; found = true; break; }
+        }
+        if (!found) {
+            const double per_ion = (have_tight ? c->tight_mean_candidates : c->mean_candidates) + 1.0;
+            int want = (int)(per_ion * iw);
+            want = want < F3_TCAP ? F3_TCAP : (want > 512 ? 512 : (want + 63) / 64 * 64);
+            const int min_rcap = 64 / vp > 32 ? 64 / vp : 32;
+            const int NC = 5;
+            const int cand[NC][2] = {{rcap, tcap}, {rcap, want}, {64, want}, {min_rcap, want}, {min_rcap, want > 256 ? 256 : want}};
+            hipEvent_t e0, e1;
+            HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
+            Fill3Head ht = h;
+            ht.F = std::min<i64>(c->F, (i64)2048 * fpb);                      // the leading frames: ~1.6 rounds of workgroups
+            const unsigned gt = (unsigned)((ht.F + fpb - 1) / fpb);
+            float best = 1e30f;
+            int br = rcap, bt = tcap;
+            const int keep_tcap = tcap;
+            for (int q = 0; q < NC; q++) {
+                bool dup = false;
+                for (int q2 = 0; q2 < q; q2++) dup = dup || (cand[q2][0] == cand[q][0] && cand[q2][1] == cand[q][1]);
+                if (dup) continue;
+                tcap = cand[q][1];
+                const size_t ldq = lds_bytes(nw, fpb, cand[q][0]);
+                if (ldq > 160 * 1024 - 512) continue;
+                ht.rcap = cand[q][0]; ht.tcap = cand[q][1];
+                float tq = 1e30f;
+                for (int rep = 0; rep < 3; rep++) {                            // the first launch of a shape warms it up
+                    HIP_TRY(c, hipEventRecord(e0, c->stream));
+                    HIP_TRY(c, f3_dispatch(c, ht, full, gt, ldq, nw, vp, diag, dynmap));
+                    HIP_TRY(c, hipEventRecord(e1, c->stream));
+                    HIP_TRY(c, hipEventSynchronize(e1));
+                    float ms = 0;
+                    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+                    if (rep > 0 && ms < tq) tq = ms;
+                }
+                if (tq < best * (q == 0 ? 1.0f : 0.97f)) { best = tq; br = cand[q][0]; bt = cand[q][1]; }   // the default wins ties
+            }
+            tcap = keep_tcap;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            rcap = br; tcap = bt;
+            F3Tuned t; memcpy(t.key, key, sizeof(key)); t.rcap = rcap; t.tcap = tcap;
+            { std::lock_guard<std::mutex> lock(g_f3_mutex); g_f3_tuned.push_back(t); }
+            // what the trial launches reported does not count
+            HIP_TRY(c, hipMemsetAsync(c->d_err, 0xFF, sizeof(u64), c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream));
+        }
+    }
+    const size_t lds = lds_bytes(nw, fpb, rcap);
+    SIT_REQUIRE(c, lds <= 160 * 1024 - 256, "sit_fill: one frame's atoms do not fit in LDS");
+    h.rcap = rcap; h.tcap = tcap;
+    if (f3_env_int("SITATOR_DEBUG_SHAPE", 0))
+        fprintf(stderr, "k_fill3 shape: nw %d fpb %d rcap %d iw %d tcap %d, %zu bytes of LDS per workgroup\n", nw, fpb, rcap, iw, tcap, lds);
+    c->last_fpb = fpb; c->last_kernel = 3; c->last_iw = rcap; c->last_nw = nw;
+    const unsigned grid = (unsigned)((c->F + fpb - 1) / fpb);
+    HIP_TRY(c, f3_dispatch(c, h, full, grid, lds, nw, vp, diag, dynmap));
     return SIT_OK;
 }
