@@ -811,6 +811,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
             HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream));
         }
     }
+    if (tcap < (int)c->W) tcap = ((int)c->W + 63) / 64 * 64;   // the longest candidate list must fit a batch
     const size_t lds = lds_bytes(nw, fpb, rcap);
     SIT_REQUIRE(c, lds <= 160 * 1024 - 256, "sit_fill: one frame's atoms do not fit in LDS");
     h.rcap = rcap; h.tcap = tcap;

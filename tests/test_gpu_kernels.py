@@ -96,19 +96,19 @@ def test_third_generation_sparse_rows_are_ascending(oracle, cfg, M, F, rcap):
     np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
 
 
-@pytest.mark.parametrize("waves,fpb,rcap,iw,contig", [("4", "1", "48", "16", "2"), ("8", "2", "8", "5", "1"),
-                                                      ("16", "3", "64", "64", "0"), ("4", "4", "16", "33", "2")])
-def test_third_generation_launch_shapes_agree(waves, fpb, rcap, iw, contig):
+@pytest.mark.parametrize("waves,fpb,rcap,iw,contig,tcap", [("4", "1", "48", "16", "2", "128"), ("8", "2", "8", "5", "1", "64"),
+                                                           ("16", "3", "64", "64", "0", "512"), ("4", "4", "16", "33", "2", "256")])
+def test_third_generation_launch_shapes_agree(waves, fpb, rcap, iw, contig, tcap):
     """Waves and frames per workgroup, the ions per wave window, the survivor slots per wave (a full region forces
-    extra rounds) and the way the frames are copied into LDS only change how the work is cut up: rows are identical
-    bit for bit."""
+    extra rounds), the tasks per wave batch and the way the frames are copied into LDS only change how the work is
+    cut up: rows are identical bit for bit (the fill measures and picks survivor slots and batch size itself)."""
     from sitator_amd import synth
     host = synth.config_host("C2")
     ctx, *_ = _setup(host, 64, 90, seed=23, kernel="3")
     assert ctx.fill()[0] == 0
     base = ctx.rows_dense()
     env = {"SITATOR_FILL_WAVES": waves, "SITATOR_FILL_FPB": fpb, "SITATOR_FILL_RCAP": rcap, "SITATOR_FILL_IW": iw,
-           "SITATOR_FILL_CONTIG": contig}
+           "SITATOR_FILL_CONTIG": contig, "SITATOR_FILL_TCAP": tcap}
     os.environ.update(env)
     try:
         assert ctx.fill()[0] == 0
