@@ -1248,7 +1248,14 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
             const i64 before = st.pos;
             st = *f->h_ctl;
             if (!st.halt && st.pos <= before) { c->msg = "fit: the step chain made no progress"; return SIT_ERR_CAPACITY; }
+            // steps enqueued past the end of the stream are no-ops but cost their launches: near the end the chunk
+            // follows the rows per step seen so far
             chunk = FS_CHUNK;
+            if (!st.halt && st.steps > 0) {
+                const double per_step = (double)st.pos / st.steps;
+                const double est = (double)(st.nrows - st.pos) / (per_step > 1.0 ? per_step : 1.0) * 1.25 + 4.0;
+                if (est < chunk) chunk = est < 4.0 ? 4 : (int)est;
+            }
         }
         c->ff_batches += st.steps; c->ff_rewalks += st.bad_steps; c->ff_serial_rows += st.single_rows;
         if (tp && st.trace_n > 0) {
