@@ -108,17 +108,36 @@ __device__ __forceinline__ double div_rb(double a, double b, double rb)
 
 // exp(x) for x <= ~10 (helpers.pyx:205: x = steepness * (t - midpoint) <= log(1/1e-4 - 1) by the cut-off):
 // x = (128 k + j) ln2/128 + r, exp = 2^k * T[j] * (1 + expm1(r)), T as hi + lo.
-__device__ __forceinline__ double exp_tab(double x, const double2 *tab)
+// The constants of exp_tab / vertex_factor, held in VECTOR registers: the kernel is short of scalar registers (every
+// constant the compiler parks there pushes another value into a spill lane and costs VALU instructions to move),
+// and has vector registers to spare at five waves per SIMD (96 in allocation granules of 8: the kernel uses 92; three
+// more constants took it to 98 -> 104 -> four waves, and C2 from 1.16 to 1.25 ms).
+struct ExpK {
+    double log2e_128, magic, ln2_128_hi, ln2_128_lo, c5, c4, c3, mid, steep, rz;
+};
+__device__ __forceinline__ double in_vgpr(double x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ ExpK expk_make(double mid, double steep, double rz)
+{
+    ExpK k;
+    k.log2e_128 = in_vgpr(0x1.71547652b82fep+7);
+    k.magic = in_vgpr(6755399441055744.0);             // 1.5 * 2^52: the integer lands in the low mantissa bits
+    k.ln2_128_hi = in_vgpr(0x1.62e42fefp-8);
+    k.ln2_128_lo = in_vgpr(0x1.473de6af278edp-41);
+    k.c5 = in_vgpr(1.0 / 120); k.c4 = in_vgpr(1.0 / 24); k.c3 = in_vgpr(1.0 / 6);
+    k.mid = in_vgpr(mid); k.steep = in_vgpr(steep); k.rz = in_vgpr(rz);
+    return k;
+}
+
+__device__ __forceinline__ double exp_tab(double x, const double2 *tab, const ExpK &k)
 {
     x = x < -700.0 ? -700.0 : x;                       // exp(-700) ~ 1e-304: 1 + e == 1 all the same, no denormals
-    const double MAGIC = 6755399441055744.0;           // 1.5 * 2^52: the integer lands in the low mantissa bits
-    const double u = __builtin_fma(x, 0x1.71547652b82fep+7, MAGIC);
-    const double n = u - MAGIC;
+    const double u = __builtin_fma(x, k.log2e_128, k.magic);
+    const double n = u - k.magic;
     const int ni = (int)(unsigned)__double_as_longlong(u);
-    double r = __builtin_fma(-n, 0x1.62e42fefp-8, x);
-    r = __builtin_fma(-n, 0x1.473de6af278edp-41, r);
-    double q = __builtin_fma(r, 1.0 / 120, 1.0 / 24);
-    q = __builtin_fma(r, q, 1.0 / 6);
+    double r = __builtin_fma(-n, k.ln2_128_hi, x);
+    r = __builtin_fma(-n, k.ln2_128_lo, r);
+    double q = __builtin_fma(r, k.c5, k.c4);
+    q = __builtin_fma(r, q, k.c3);
     q = __builtin_fma(r, q, 0.5);
     q = __builtin_fma(r, q, 1.0);
     const double p = r * q;
@@ -128,15 +147,14 @@ __device__ __forceinline__ double exp_tab(double x, const double2 *tab)
 }
 
 // one logistic factor of helpers.pyx:186-205 from the squared distance; 0.0 encodes "beyond the cut-off"
-__device__ __forceinline__ double vertex_factor(double d2, double vcd, double rvcd, double rz, double steep, double mid,
-                                                const double2 *tab)
+__device__ __forceinline__ double vertex_factor(double d2, double vcd, double rvcd, const ExpK &k, const double2 *tab)
 {
     d2 = d2 < 1e-300 ? 1e-300 : d2;                    // an ion exactly on a static atom: t - midpoint is the same
     const double dist = sqrt_nr(d2);
     const double tt = div_rb(dist, vcd, rvcd);
-    const double e = exp_tab(steep * (tt - mid), tab);
+    const double e = exp_tab(k.steep * (tt - k.mid), tab, k);
     const double f = rcp_nr(1.0 + e);
-    return tt > rz ? 0.0 : f;
+    return tt > k.rz ? 0.0 : f;
 }
 
 __device__ __forceinline__ double root_chain(double acc, int nv);
@@ -229,7 +247,7 @@ __host__ __device__ inline int f3_wave_bytes(int rcap, int vp, int iw, int tcap)
 // (static ids go through the frame's lattice map; the static-lattice check was made by k_lattice_map).
 // h.contig: 2 = the workgroup's atoms are one run of doubles in memory (statics then mobiles, nothing else),
 // 1 = static_idx / mobile_idx are two consecutive ranges, 0 = arbitrary index lists.
-template <int CELL, int LG, int NW, int DYN>
+template <int CELL, int LG, int NW, int DYN, int DBG>
 __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr full)
 {
     constexpr int VP = 1 << LG;
@@ -240,6 +258,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     const int fpb = h.fpb;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rcap = h.rcap;
+    const int dbg = DBG ? h.debug_stop : 0;                     // the ablation stops and the census live in the DBG = 1 build
     // layout: [per-wave buffers] [exp table] [atoms: per frame statics then mobiles] [frame flags]
     const int IW = h.iw;
     const int TCAP = h.tcap;
@@ -337,14 +356,14 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
         if (h.force_loose) tight = false;
         if (!tight) atomicAdd(&h.scal[2], 1ull);
     }
-    if (h.debug_stop == 1) return;
+    if (dbg == 1) return;
 
     // phase-2 constants: scalar loads from the device copy of the arguments, issued after the barrier
     const Fill3Args __attribute__((address_space(4))) &g = *full;
     const i32 *verts = g.verts;
     const double *hi2p = g.hi2p;
     const double2 *vr = g.vr;
-    const double mid = g.midpoint, steep = g.steepness, rz = g.rz;
+    const ExpK ek = expk_make(g.midpoint, g.steepness, g.rz);
     // per-lane constants of the (task, vertex) passes
     const int hh = lane & (VP - 1), gl0 = lane & ~(VP - 1);     // my vertex, first lane of my task
     const unsigned long long grpmask = (VP == 8 ? 0xffull : 0xfull) << gl0, below = (1ull << gl0) - 1ull;
@@ -400,12 +419,12 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                     for (int u = 0; u < 4; u++) if (c0 + u < nL) ttab[exL - preL + c0 + u] = e[u] | ((unsigned)lane << 26);
                 }
             }
-            if (h.debug_stop == 9 && lane == 0) { atomicAdd(&h.scal[5], (u64)nlt); atomicAdd(&h.scal[7], 1ull); }
+            if (dbg == 9 && lane == 0) { atomicAdd(&h.scal[5], (u64)nlt); atomicAdd(&h.scal[7], 1ull); }
             __builtin_amdgcn_wave_barrier();
             // ---- D0: one lane per task tests the task's CRITICAL vertex (the one with the least room in this ion's
             //      bin, candidates.hip); the tasks that pass are compacted in place ----
             int t_end = 0;
-            const int nlt0 = h.debug_stop == 2 ? 0 : nlt;        // ablation: stop after the task table
+            const int nlt0 = dbg == 2 ? 0 : nlt;        // ablation: stop after the task table
             for (int t0 = 0; t0 < nlt0; t0 += 64) {
                 const int t = t0 + lane;
                 const bool act = t < nlt0;
@@ -427,8 +446,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 if (keep) ttab[t_end + __popcll(km & ltmask)] = tk;
                 t_end += __popcll(km);
             }
-            if (h.debug_stop == 9 && lane == 0) atomicAdd(&h.scal[4], (u64)t_end);
-            if (h.debug_stop == 3) t_end = 0;                     // ablation: stop after the critical-vertex test
+            if (dbg == 9 && lane == 0) atomicAdd(&h.scal[4], (u64)t_end);
+            if (dbg == 3) t_end = 0;                     // ablation: stop after the critical-vertex test
             __builtin_amdgcn_wave_barrier();
             const int pend = (t_end + TPP - 1) / TPP;           // passes of TPP tasks over [0, t_end)
             int cursor = 0;
@@ -476,8 +495,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                     }
                     cursor += two ? 2 : 1;
                 }
-                if (h.debug_stop == 9 && lane == 0) atomicAdd(&h.scal[6], (u64)cnt);
-                if (h.debug_stop == 4) cnt = 0;
+                if (dbg == 9 && lane == 0) atomicAdd(&h.scal[6], (u64)cnt);
+                if (dbg == 4) cnt = 0;
                 __builtin_amdgcn_wave_barrier();
                 // ---- E: one logistic factor per (survivor, vertex) (helpers.pyx:196-205), in place; two items per
                 //      lane and iteration, loads first.  Padded vertices (1 / vcd stored as 0) give the factor 1 ----
@@ -496,11 +515,11 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const int i = i0 + 64 * u + lane;
-                        const double f = vertex_factor(d2[u], c[u].x, c[u].y, rz, steep, mid, etab);
+                        const double f = vertex_factor(d2[u], c[u].x, c[u].y, ek, etab);
                         if (i < items) sd2[i] = c[u].y != 0.0 ? f : 1.0;
                     }
                 }
-                if (h.debug_stop == 5) cnt = 0;                   // ablation: stop after the logistic factors
+                if (dbg == 5) cnt = 0;                   // ablation: stop after the logistic factors
                 __builtin_amdgcn_wave_barrier();
                 // ---- T: ci *= temp in vertex order (helpers.pyx:208) and the n-th root (:212), one lane per
                 //      survivor; the row entry of a component is the number of earlier non-zero components of its
@@ -541,7 +560,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < nib) {
-            const int nnz = h.debug_stop >= 2 && h.debug_stop <= 5 ? 1 : (int)nzc[lane];
+            const int nnz = dbg >= 2 && dbg <= 5 ? 1 : (int)nzc[lane];
             const i64 row = (f0 + fl) * M + j;
             g.row_nnz[row] = nnz < g.W ? nnz : g.W;
             if (nnz == 0) {                                               // helpers.pyx:116-120
@@ -617,14 +636,16 @@ bool fill3_eligible(sit_ctx *c)
 static hipError_t f3_dispatch(sit_ctx *c, const Fill3Head &h, Fill3ArgsPtr full, unsigned grid, size_t lds, int nw, int vp,
                               bool diag, bool dynmap)
 {
-#define F3_LAUNCH(CELL, LGV, NWV, DY)                                                                                          \
+#define F3_LAUNCH(CELL, LGV, NWV, DY, DB)                                                                                      \
     do {                                                                                                                   \
-        hipError_t e = hipFuncSetAttribute((const void *)k_fill3<CELL, LGV, NWV, DY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipError_t e = hipFuncSetAttribute((const void *)k_fill3<CELL, LGV, NWV, DY, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                     \
-        k_fill3<CELL, LGV, NWV, DY><<<dim3(grid), dim3(NWV * 64), lds, c->stream>>>(h, full);                              \
+        k_fill3<CELL, LGV, NWV, DY, DB><<<dim3(grid), dim3(NWV * 64), lds, c->stream>>>(h, full);                          \
     } while (0)
+#define F3_PICK3(CELL, LGV, NWV, DY)                                                                                           \
+    do { if (h.debug_stop) F3_LAUNCH(CELL, LGV, NWV, DY, 1); else F3_LAUNCH(CELL, LGV, NWV, DY, 0); } while (0)
 #define F3_PICK2(CELL, LGV, NWV)                                                                                               \
-    do { if (dynmap) F3_LAUNCH(CELL, LGV, NWV, 1); else F3_LAUNCH(CELL, LGV, NWV, 0); } while (0)
+    do { if (dynmap) F3_PICK3(CELL, LGV, NWV, 1); else F3_PICK3(CELL, LGV, NWV, 0); } while (0)
 #define F3_PICK(CELL, LGV)                                                                                                     \
     do {                                                                                                                   \
         if (nw == 16) F3_PICK2(CELL, LGV, 16); else if (nw == 8) F3_PICK2(CELL, LGV, 8); else F3_PICK2(CELL, LGV, 4);      \
@@ -633,6 +654,7 @@ static hipError_t f3_dispatch(sit_ctx *c, const Fill3Head &h, Fill3ArgsPtr full,
     else { if (vp == 8) F3_PICK(0, 3); else F3_PICK(0, 2); }
 #undef F3_PICK
 #undef F3_PICK2
+#undef F3_PICK3
 #undef F3_LAUNCH
     return hipGetLastError();
 }
