@@ -38,8 +38,8 @@
 #define F3_EXPN 128
 
 struct Fill3Args {
-    const i32 *verts;                 // [D,Vp], -1 padded
-    const double *hi2p;               // [D,Vp] squared screening bound, +inf on padding
+    const uint4 *vh;                  // [D,Vp] {24 * static id (byte offset of the vertex in a frame), static id, squared
+                                      //         screening bound as two words (+inf on padding)}
     const double2 *vr;                // [D,Vp] {vcd, 1/vcd}
     const unsigned char *nvtab;       // [D]
     const i32 *t_off, *t_list;        // tight table
@@ -360,8 +360,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
 
     // phase-2 constants: scalar loads from the device copy of the arguments, issued after the barrier
     const Fill3Args __attribute__((address_space(4))) &g = *full;
-    const i32 *verts = g.verts;
-    const double *hi2p = g.hi2p;
+    const uint4 *vh = g.vh;
     const double2 *vr = g.vr;
     const ExpK ek = expk_make(g.midpoint, g.steepness, g.rz);
     // per-lane constants of the (task, vertex) passes
@@ -431,11 +430,11 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 const unsigned tk = ttab[act ? t : 0];
                 const unsigned k = tk & 0x3fffffu, cv = (tk >> 22) & 7u;
                 const uint4 iv = info[tk >> 26];
-                i32 v = verts[k * VP + cv];
-                const double hk = hi2p[k * VP + cv];
-                v = v < 0 ? 0 : v;
-                if (DYN) v = g.lattice_map[(f0 + (i64)iv.z) * S + v];
-                const double *sp = (const double *)((const char *)xyz + (iv.y + 24u * (unsigned)v));
+                const uint4 rec = vh[k * VP + cv];
+                const double hk = __hiloint2double((int)rec.w, (int)rec.z);
+                unsigned voff = rec.x;
+                if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)iv.z) * S + (i64)rec.y];
+                const double *sp = (const double *)((const char *)xyz + (iv.y + voff));
                 const double *op = (const double *)((const char *)xyz + iv.x);
                 double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];
                 wrapc3<CELL>(P, qx, qy, qz);
@@ -469,11 +468,11 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                         tk[u] = ttab[t < TCAP ? t : 0];
                         const unsigned k = tk[u] & 0x3fffffu;
                         const uint4 iv = info[tk[u] >> 26];
-                        i32 v = verts[k * VP + hh];
-                        const double hk = hi2p[k * VP + hh];
-                        v = v < 0 ? 0 : v;
-                        if (DYN) v = g.lattice_map[(f0 + (i64)iv.z) * S + v];
-                        const double *sp = (const double *)((const char *)xyz + (iv.y + 24u * (unsigned)v));
+                        const uint4 rec = vh[k * VP + hh];
+                        const double hk = __hiloint2double((int)rec.w, (int)rec.z);
+                        unsigned voff = rec.x;
+                        if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)iv.z) * S + (i64)rec.y];
+                        const double *sp = (const double *)((const char *)xyz + (iv.y + voff));
                         const double *op = (const double *)((const char *)xyz + iv.x);
                         double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];
                         wrapc3<CELL>(P, qx, qy, qz);
@@ -601,7 +600,15 @@ static int fill3_basis_tables(sit_ctx *c)
         }
         nv[(size_t)k] = (unsigned char)cnt;
     }
+    std::vector<unsigned> vh((size_t)(4 * n));
+    for (i64 e = 0; e < n; e++) {
+        const unsigned vi = v[(size_t)e] < 0 ? 0u : (unsigned)v[(size_t)e];
+        unsigned long long bits;
+        memcpy(&bits, &hi2[(size_t)e], 8);
+        vh[4 * e] = 24u * vi; vh[4 * e + 1] = vi; vh[4 * e + 2] = (unsigned)(bits & 0xffffffffull); vh[4 * e + 3] = (unsigned)(bits >> 32);
+    }
     int rc;
+    if ((rc = dev_upload(c, &c->d_vh, vh.data(), 4 * n))) return rc;
     if ((rc = dev_upload(c, &c->d_hi2p, hi2.data(), n))) return rc;
     if ((rc = dev_upload(c, &c->d_vr, vr.data(), 2 * n))) return rc;
     if ((rc = dev_upload(c, &c->d_nv, nv.data(), c->D))) return rc;
@@ -674,7 +681,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
     const bool have_tight = c->tight_delta >= 0;
     Fill3Args a;
     memset(&a, 0, sizeof(a));
-    a.verts = c->d_verts; a.hi2p = c->d_hi2p; a.vr = (const double2 *)c->d_vr; a.nvtab = c->d_nv;
+    a.vh = (const uint4 *)c->d_vh; a.vr = (const double2 *)c->d_vr; a.nvtab = c->d_nv;
     a.l_off = c->d_bin_off; a.l_list = c->d_bin_list; a.l_crit = c->d_bin_crit;
     a.t_off = have_tight ? c->d_tbin_off : c->d_bin_off; a.t_list = have_tight ? c->d_tbin_list : c->d_bin_list;
     a.t_crit = have_tight ? c->d_tbin_crit : c->d_bin_crit;

@@ -66,6 +66,7 @@ struct sit_ctx {
     double *d_frame_dmax = nullptr;   // [F] per-frame displacement maximum (dynamic mapping)
     // third-generation fill (fill3.hip): inf-padded bounds, {vcd, 1/vcd} pairs, vertex counts, exp table
     double *d_hi2p = nullptr;         // [D,Vp] as d_hi2 but +inf on padded vertices
+    unsigned *d_vh = nullptr;         // [D,Vp,4] {24 * static id, static id, d_hi2p as two words}: one load per (landmark, vertex)
     double *d_vr = nullptr;           // [D,Vp,2] {vcd, correctly rounded 1/vcd}
     unsigned char *d_nv = nullptr;    // [D] vertices per landmark
     double *d_exptab = nullptr;       // [128,2] {hi, lo} of 2^(j/128)
