@@ -130,7 +130,7 @@ __device__ __forceinline__ ExpK expk_make(double mid, double steep, double rz)
 
 __device__ __forceinline__ double exp_tab(double x, const double2 *tab, const ExpK &k)
 {
-    x = x < -700.0 ? -700.0 : x;                       // exp(-700) ~ 1e-304: 1 + e == 1 all the same, no denormals
+    x = __builtin_fmax(x, -700.0);                     // exp(-700) ~ 1e-304: 1 + e == 1 all the same, no denormals
     const double u = __builtin_fma(x, k.log2e_128, k.magic);
     const double n = u - k.magic;
     const int ni = (int)(unsigned)__double_as_longlong(u);
@@ -149,7 +149,7 @@ __device__ __forceinline__ double exp_tab(double x, const double2 *tab, const Ex
 // one logistic factor of helpers.pyx:186-205 from the squared distance; 0.0 encodes "beyond the cut-off"
 __device__ __forceinline__ double vertex_factor(double d2, double vcd, double rvcd, const ExpK &k, const double2 *tab)
 {
-    d2 = d2 < 1e-300 ? 1e-300 : d2;                    // an ion exactly on a static atom: t - midpoint is the same
+    d2 = __builtin_fmax(d2, 1e-300);                   // an ion exactly on a static atom: t - midpoint is the same
     const double dist = sqrt_nr(d2);
     const double tt = div_rb(dist, vcd, rvcd);
     const double e = exp_tab(k.steep * (tt - k.mid), tab, k);
