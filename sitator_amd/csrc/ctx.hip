@@ -30,8 +30,9 @@ extern "C" int sit_create(const double *cell, const double *cell_inv, int device
     HIP_TRY(c, hipStreamCreate(&c->stream));
     for (int i = 0; i < T_N; i++) { HIP_TRY(c, hipEventCreate(&c->tev0[i])); HIP_TRY(c, hipEventCreate(&c->tev1[i])); }
     HIP_TRY(c, hipHostMalloc(&c->h_pinned, 256));
-    HIP_TRY(c, hipMalloc((void **)&c->d_err, sizeof(u64)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_scal, sizeof(u64) * 16));
+    // the error key and the counters sit side by side: one read-back per call
+    HIP_TRY(c, hipMalloc((void **)&c->d_err, sizeof(u64) * 17));
+    c->d_scal = c->d_err + 1;
     HIP_TRY(c, hipMalloc((void **)&c->d_fit_K, sizeof(i64)));
     return SIT_OK;
 }
@@ -46,7 +47,7 @@ extern "C" void sit_destroy(sit_ctx *c)
                     c->d_lattice_map, c->d_tbin_off, c->d_tbin_list, c->d_fill_args, c->d_frame_dmax, c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs,
                     c->d_counts, c->d_col_ptr, c->d_col_k, c->d_col_val, c->d_cen_dense, c->d_fit_centers,
                     c->d_hi2p, c->d_vh, c->d_vr, c->d_nv, c->d_exptab, c->d_bin_crit, c->d_tbin_crit,
-                    c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scal, c->d_scratch};
+                    c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     fitfast_free(c);
     for (int i = 0; i < T_N; i++) { if (c->tev0[i]) (void)hipEventDestroy(c->tev0[i]); if (c->tev1[i]) (void)hipEventDestroy(c->tev1[i]); }

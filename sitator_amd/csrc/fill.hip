@@ -372,8 +372,7 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         c->assign_valid = false;
         if (assign && (rc = sit_predict_internal(c, p->predict_threshold))) return rc;
         u64 *hb = (u64 *)c->h_pinned;          // [0] error key, [1..4] scalars
-        HIP_TRY(c, hipMemcpyAsync(hb, c->d_err, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(hb + 1, c->d_scal, 64, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(hb, c->d_err, 72, hipMemcpyDeviceToHost, c->stream));      // d_scal follows d_err
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const u64 hkey = hb[0], hs[4] = {hb[1], hb[2], hb[3], hb[4]};
         for (int q = 0; q < 4; q++) c->census[q] = (double)hb[5 + q];
