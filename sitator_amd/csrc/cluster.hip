@@ -418,14 +418,14 @@ static int run_predict(sit_ctx *c, double threshold)
             const i64 blocks = (c->N + PRED_LDS_BLOCK - 1) / PRED_LDS_BLOCK;
             const unsigned g2 = (unsigned)std::min<i64>(blocks, (i64)ncu * (lds <= 36 * 1024 ? 4 : 3));
             HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
-            HIP_TRY(c, hipFuncSetAttribute((const void *)k_predict_rows_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(c, lds_limit((const void *)k_predict_rows_lds, lds, c->device));
             k_predict_rows_lds<<<dim3(g2), dim3(PRED_LDS_BLOCK), lds, c->stream>>>(a, wlist, wcount, (int)c->csc_nnz, (int)c->K, (u64 *)c->d_counts);
             counted = true;
         } else
             k_predict_rows<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount);
         if (c->rows_W > 4) {
             if (wide_lds) {
-                HIP_TRY(c, hipFuncSetAttribute((const void *)k_predict_rows_wide_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)csc));
+                HIP_TRY(c, lds_limit((const void *)k_predict_rows_wide_lds, csc, c->device));
                 k_predict_rows_wide_lds<<<dim3((unsigned)ncu), dim3(PRED_WIDE_LDS_BLOCK), csc, c->stream>>>(a, wlist, wcount, (int)c->csc_nnz, cnt);
             } else
                 k_predict_rows_wide<<<dim3(gw), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, cnt);

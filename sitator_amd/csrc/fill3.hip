@@ -645,7 +645,7 @@ static hipError_t f3_dispatch(sit_ctx *c, const Fill3Head &h, Fill3ArgsPtr full,
 {
 #define F3_LAUNCH(CELL, LGV, NWV, DY, DB)                                                                                      \
     do {                                                                                                                   \
-        hipError_t e = hipFuncSetAttribute((const void *)k_fill3<CELL, LGV, NWV, DY, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipError_t e = lds_limit((const void *)k_fill3<CELL, LGV, NWV, DY, DB>, lds, c->device);                           \
         if (e != hipSuccess) return e;                                                                                     \
         k_fill3<CELL, LGV, NWV, DY, DB><<<dim3(grid), dim3(NWV * 64), lds, c->stream>>>(h, full);                          \
     } while (0)

@@ -146,6 +146,25 @@ struct sit_ctx {
         }                                                                               \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when the kernel needs more than it was last granted on this
+// device (the call is a few microseconds of host time, three of them sat in every step of the hot path)
+static inline hipError_t lds_limit(const void *kernel, size_t bytes, int device)
+{
+    struct Seen { const void *k; int dev; size_t bytes; };
+    static thread_local Seen seen[64];
+    static thread_local int nseen = 0;
+    for (int i = 0; i < nseen; i++)
+        if (seen[i].k == kernel && seen[i].dev == device) {
+            if (seen[i].bytes >= bytes) return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            if (e == hipSuccess) seen[i].bytes = bytes;
+            return e;
+        }
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && nseen < 64) { seen[nseen].k = kernel; seen[nseen].dev = device; seen[nseen].bytes = bytes; nseen++; }
+    return e;
+}
+
 template <typename T>
 static inline int dev_alloc(sit_ctx *c, T **p, i64 n)
 {
