@@ -18,4 +18,4 @@ la, dt = once(); print("first run %.3f s" % dt, {k: round(v, 3) for k, v in la.w
 la, dt = once(); print("second run %.3f s" % dt, {k: round(v, 3) for k, v in la.wall_timings.items()})
 pr = cProfile.Profile(); pr.enable(); la, dt = once(); pr.disable()
 print("profiled run %.3f s" % dt, {k: round(v, 3) for k, v in la.wall_timings.items()})
-pstats.Stats(pr).sort_stats("tottime").print_stats(25)
+pstats.Stats(pr).sort_stats("tottime").print_stats(18); pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
