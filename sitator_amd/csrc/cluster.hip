@@ -598,7 +598,11 @@ __global__ __launch_bounds__(FIT_T) void k_fit_stream(FitArgs a)
             }
         }
         for (int e = t; e < n; e += FIT_T) xd[ei[e]] = 0.0;
-        __threadfence_block();
+        // The centres live in global memory and the next row's scores are read by OTHER waves than the ones that just
+        // wrote them.  A workgroup-scope fence is not enough on gfx950: about one fit in a hundred then read a stale
+        // L1 line (scratch/dbg_serial_repeat.py: 7 of 50 runs of one C5 case, 0 of 50 with the device-scope fence;
+        // the soak's oracle arbitration showed it was always this kernel, never the step chain).
+        __threadfence();
         __syncthreads();
     }
     if (t == 0) {
