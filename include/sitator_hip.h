@@ -119,6 +119,17 @@ typedef struct sit_fill_params {
  * On a domain error returns its status and fills *err.                                    */
 int sit_fill(sit_ctx *ctx, const sit_fill_params *p, int64_t *n_all_zero, sit_error *err);
 
+/* sit_set_frames + sit_fill (rows stored) + sit_fit_reset + sit_fit_push_stored_rows(fit_threshold) in one call, with
+ * the upload overlapped: the trajectory goes to the GPU in chunks on a copy stream while the chunks that have arrived
+ * are filled and their rows streamed through fit_centers (LandmarkAnalysis.py:211-232 followed by the first pass of
+ * util/DotProdClassifier.pyx:199-288; the fit is an ordered stream over the rows, so it can start on the first
+ * frames).  Same rows, same clustering state, same first-offender error as the separate calls.  *fitted = 1 when the
+ * first pass of the fit has been made (read it with sit_fit_get_state); 0 when the call fell back to upload + fill
+ * only (dynamic lattice mapping, a short trajectory, SITATOR_FIT=serial).                                          */
+int sit_upload_fill_fit(sit_ctx *ctx, const double *frames, int64_t n_frames, int64_t n_atoms, const int64_t *static_idx,
+                        int64_t n_static, const int64_t *mobile_idx, int64_t n_mobile, int64_t frame0,
+                        const sit_fill_params *p, double fit_threshold, int64_t *n_all_zero, sit_error *err, int *fitted);
+
 /* Seen-flags of the static atoms of one frame under dynamic mapping (helpers.pyx:87-92). */
 int sit_static_seen(sit_ctx *ctx, int64_t local_frame, uint8_t *seen);
 

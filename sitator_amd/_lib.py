@@ -48,6 +48,8 @@ SIGNATURES = {
     "sit_set_frames_device": (C.c_int, [_vp, _vp, i64, i64, _ip, i64, _ip, i64, i64]),
     "sit_frames_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "sit_fill": (C.c_int, [_vp, C.POINTER(FillParams), _ip, C.POINTER(SitError)]),
+    "sit_upload_fill_fit": (C.c_int, [_vp, _dp, i64, i64, _ip, i64, _ip, i64, i64, C.POINTER(FillParams), C.c_double, _ip,
+                                      C.POINTER(SitError), C.POINTER(C.c_int)]),
     "sit_static_seen": (C.c_int, [_vp, i64, _u8p]),
     "sit_row_width": (C.c_int, [_vp, _ip]),
     "sit_get_rows_dense": (C.c_int, [_vp, i64, i64, _dp]),
@@ -239,6 +241,26 @@ class HipContext(object):
         self.frame0 = int(frame0)
         self._check(self.lib.sit_set_frames(self._h, _d(frames), self.F, self.A, _i(static_idx), len(static_idx),
                                             _i(mobile_idx), self.M, self.frame0))
+
+    def upload_fill_fit(self, frames, static_idx, mobile_idx, frame0, dynamic_lattice_mapping, relaxed_lattice_checks,
+                        check_for_zeros, fit_threshold):
+        """``set_frames`` + ``fill`` + the first pass of ``fit_centers`` with the upload overlapped
+        (``sit_upload_fill_fit``).  Returns ``(rc, n_all_zero, err, fitted)``."""
+        frames = _f64(frames)
+        static_idx = _i64(static_idx)
+        mobile_idx = _i64(mobile_idx)
+        self.F, self.A = frames.shape[0], frames.shape[1]
+        self.M = len(mobile_idx)
+        self.N = self.F * self.M
+        self.frame0 = int(frame0)
+        p = FillParams(int(dynamic_lattice_mapping), int(relaxed_lattice_checks), int(check_for_zeros), 1, 0, 1, 0.0)
+        nz = i64(0)
+        err = SitError()
+        fitted = C.c_int(0)
+        rc = self.lib.sit_upload_fill_fit(self._h, _d(frames), self.F, self.A, _i(static_idx), len(static_idx),
+                                          _i(mobile_idx), self.M, self.frame0, C.byref(p), float(fit_threshold),
+                                          C.byref(nz), C.byref(err), C.byref(fitted))
+        return rc, nz.value, err, bool(fitted.value)
 
     def row_width(self):
         w = i64(0)

@@ -753,6 +753,12 @@ static int fit_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *
     return SIT_OK;
 }
 
+int fit_stream_rows(sit_ctx *c, i64 row_lo, i64 nrows, double threshold)
+{
+    if (nrows <= 0) return SIT_OK;
+    return fit_stream(c, c->d_row_nnz + row_lo, c->d_row_idx + row_lo, c->d_row_val + row_lo, nullptr, c->N, (int)c->rows_W, nrows, threshold);
+}
+
 extern "C" int sit_fit_push_stored_rows(sit_ctx *c, double threshold)
 {
     if (!c) return SIT_ERR_INVALID;

@@ -50,6 +50,7 @@ extern "C" void sit_destroy(sit_ctx *c)
                     c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     fitfast_free(c);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (int i = 0; i < T_N; i++) { if (c->tev0[i]) (void)hipEventDestroy(c->tev0[i]); if (c->tev1[i]) (void)hipEventDestroy(c->tev1[i]); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -273,7 +274,7 @@ extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const 
 
 // ---- trajectory -------------------------------------------------------------------------------
 
-static int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S, const i64 *mobile_idx,
+int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S, const i64 *mobile_idx,
                           i64 M, i64 frame0)
 {
     SIT_REQUIRE(c, c->S > 0, "sit_set_frames: call sit_set_basis first");

@@ -9,6 +9,16 @@
 // Rows go to HBM slot-major (idx[e*N+row]) so that the stores of a wave coalesce.
 #include <cmath>
 
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
 #include "sit_internal.h"
 
 struct FillArgs {
@@ -384,6 +394,180 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         return SIT_OK;
     }
     return SIT_ERR_CAPACITY;
+}
+
+// Host -> device copy of part of a pageable buffer through a ring of pinned staging buffers: copy threads fill 4 MB
+// slots, each slot leaves by DMA on `stream` as soon as it is staged and is reused once its DMA has finished.  (A plain
+// hipMemcpyAsync of pageable memory is as fast, 55 GB/s, but it blocks the runtime for other threads' launches while it
+// runs: this one only enqueues.)  Returns when the whole range has arrived.
+#define RING_SLOTS 8
+#define RING_CHUNK ((size_t)4 << 20)
+static std::mutex g_ring_mutex;
+static char *g_ring = nullptr;
+
+static int upload_staged(sit_ctx *c, hipStream_t stream, hipEvent_t *slot_ev, void *dst, const void *src, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_ring_mutex);
+    if (!g_ring && hipHostMalloc((void **)&g_ring, RING_SLOTS * RING_CHUNK) != hipSuccess) { g_ring = nullptr; return SIT_ERR_HIP; }
+    const size_t nchunks = (bytes + RING_CHUNK - 1) / RING_CHUNK;
+    const int nthreads = (int)std::min<size_t>(4, nchunks);
+    std::vector<std::atomic<int>> staged(nchunks);
+    std::atomic<long long> released(RING_SLOTS), next(0);
+    for (auto &f : staged) f.store(0);
+    char *ring = g_ring;
+    auto worker = [&]() {
+        for (;;) {
+            const long long i = next.fetch_add(1);
+            if (i >= (long long)nchunks) return;
+            while (released.load(std::memory_order_acquire) <= i) std::this_thread::sleep_for(std::chrono::microseconds(10));
+            const size_t off = (size_t)i * RING_CHUNK, n = std::min(RING_CHUNK, bytes - off);
+            memcpy(ring + (size_t)(i % RING_SLOTS) * RING_CHUNK, (const char *)src + off, n);
+            staged[(size_t)i].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthreads; t++) pool.emplace_back(worker);
+    int rc = SIT_OK;
+    for (size_t i = 0; i < nchunks; i++) {
+        while (!staged[i].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(10));
+        const size_t off = i * RING_CHUNK, n = std::min(RING_CHUNK, bytes - off);
+        const int slot = (int)(i % RING_SLOTS);
+        if (rc == SIT_OK && (hipMemcpyAsync((char *)dst + off, ring + (size_t)slot * RING_CHUNK, n, hipMemcpyHostToDevice, stream) != hipSuccess ||
+                             hipEventRecord(slot_ev[slot], stream) != hipSuccess)) rc = SIT_ERR_HIP;
+        if (i + 1 >= RING_SLOTS / 2) {          // the slot of the oldest chunk in flight is handed back once its DMA is done
+            const size_t done = i + 1 - RING_SLOTS / 2;
+            if (rc == SIT_OK && hipEventSynchronize(slot_ev[done % RING_SLOTS]) != hipSuccess) rc = SIT_ERR_HIP;
+            released.store((long long)(done + 1 + RING_SLOTS), std::memory_order_release);
+        }
+    }
+    released.store((long long)nchunks + RING_SLOTS, std::memory_order_release);
+    for (auto &t : pool) t.join();
+    if (rc == SIT_OK && hipStreamSynchronize(stream) != hipSuccess) rc = SIT_ERR_HIP;
+    return rc;
+}
+
+// sit_set_frames + sit_fill (rows stored) + sit_fit_reset + sit_fit_push_stored_rows in one call, with the upload
+// overlapped: a helper thread sends the trajectory to the GPU in chunks on a copy stream while this thread fills the
+// chunks that have arrived and streams their rows through the fit (fit_centers is an ordered stream over the rows, so
+// it can start on the first frames while the last ones are still on the PCIe link; the fit is the longer of the two).
+// Same results as the three calls: the fill is exact whichever pruning table a frame takes (here the tight table is
+// sized on the first chunk's static displacements), the fit sees the same rows in the same order, the first offender
+// of an error is the smallest key over all chunks.  *fitted = 0: conditions for the pipeline not met (dynamic lattice
+// mapping, an older fill kernel, a short trajectory): frames uploaded and rows filled only.
+extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 A, const i64 *static_idx, i64 S,
+                                   const i64 *mobile_idx, i64 M, i64 frame0, const sit_fill_params *p, double fit_threshold,
+                                   i64 *n_all_zero, sit_error *err, int *fitted)
+{
+    if (!c || !frames || !p || !fitted) return SIT_ERR_INVALID;
+    *fitted = 0;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 chunk_frames_min = 4096;
+    const bool plain = p->dynamic_lattice_mapping || p->assign || c->fill_kernel != 3 || F < 2 * chunk_frames_min || !c->fit_use_fast;
+    int rc;
+    if (plain) {
+        if ((rc = sit_set_frames(c, frames, F, A, static_idx, S, mobile_idx, M, frame0))) return rc;
+        return sit_fill(c, p, n_all_zero, err);
+    }
+    if ((rc = set_frame_meta(c, F, A, static_idx, S, mobile_idx, M, frame0))) return rc;
+    if (!(c->W <= 128 && fill3_eligible(c))) {
+        if ((rc = sit_set_frames(c, frames, F, A, static_idx, S, mobile_idx, M, frame0))) return rc;
+        return sit_fill(c, p, n_all_zero, err);
+    }
+    if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
+    const i64 bytes = F * A * 24;
+    if (!c->frames_owned || c->frames_cap_bytes < bytes) {
+        if (c->frames_owned && c->d_frames) (void)hipFree(c->d_frames);
+        c->d_frames = nullptr; c->frames_owned = true; c->frames_cap_bytes = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_frames, (size_t)bytes));
+        c->frames_cap_bytes = bytes;
+    }
+    // every allocation first: hipMalloc / hipFree stall the other thread's copies
+    const i64 N = c->N, W = c->W;
+    if (c->rows_W != W || c->rows_N != N || !c->d_row_nnz) {
+        c->rows_valid = false;
+        if ((rc = dev_alloc(c, &c->d_row_nnz, N))) return rc;
+        if ((rc = dev_alloc(c, &c->d_row_idx, N * W))) return rc;
+        if ((rc = dev_alloc(c, &c->d_row_val, N * W))) return rc;
+        if (hipMemsetAsync(c->d_row_idx, 0, (size_t)(N * W) * 4, c->stream) != hipSuccess ||
+            hipMemsetAsync(c->d_row_val, 0, (size_t)(N * W) * 8, c->stream) != hipSuccess) { c->msg = "row buffers"; return SIT_ERR_HIP; }
+        c->rows_W = W; c->rows_N = N;
+    }
+    if (hipMemsetAsync(c->d_err, 0xFF, sizeof(u64), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream) != hipSuccess) { c->msg = "counters"; return SIT_ERR_HIP; }
+    if ((rc = sit_fit_reset(c))) return rc;
+    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    // chunks of whole frames: 8 to 16 of them, at least 4096 frames each
+    int nch = (int)(F / chunk_frames_min);
+    nch = nch > 16 ? 16 : (nch < 2 ? 2 : nch);
+    const i64 cf = (F + nch - 1) / nch;
+    std::vector<hipEvent_t> ev((size_t)nch, nullptr);
+    for (int i = 0; i < nch; i++) HIP_TRY(c, hipEventCreateWithFlags(&ev[(size_t)i], hipEventDisableTiming));
+    hipEvent_t slot_ev[RING_SLOTS] = {};
+    for (int i = 0; i < RING_SLOTS; i++) HIP_TRY(c, hipEventCreateWithFlags(&slot_ev[i], hipEventDisableTiming));
+    std::atomic<int> issued(0), failed(0);
+    const bool dbgpipe = getenv("SITATOR_DEBUG_PIPE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    std::thread up([&]() {
+        if (hipSetDevice(c->device) != hipSuccess) failed.store(1);
+        for (int i = 0; i < nch; i++) {
+            if (dbgpipe) fprintf(stderr, "  upload of chunk %d starts at %.1f ms\n", i, since());
+            const i64 lo = i * cf, hi = std::min<i64>(F, lo + cf);
+            if (!failed.load() && hi > lo &&
+                (upload_staged(c, c->copy_stream, slot_ev, (char *)c->d_frames + lo * A * 24, (const char *)frames + lo * A * 24,
+                               (size_t)((hi - lo) * A * 24)) != SIT_OK ||
+                 hipEventRecord(ev[(size_t)i], c->copy_stream) != hipSuccess)) failed.store(1);
+            issued.store(i + 1, std::memory_order_release);
+        }
+    });
+    auto finish = [&](int code) {
+        up.join();
+        (void)hipStreamSynchronize(c->copy_stream);
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : slot_ev) if (e) (void)hipEventDestroy(e);
+        return code;
+    };
+    auto wait_chunk = [&](int i) -> int {
+        while (issued.load(std::memory_order_acquire) <= i) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if (failed.load()) { c->msg = "upload of a trajectory chunk failed"; return SIT_ERR_HIP; }
+        if (hipStreamWaitEvent(c->stream, ev[(size_t)i], 0) != hipSuccess) { c->msg = "hipStreamWaitEvent failed"; return SIT_ERR_HIP; }
+        return SIT_OK;
+    };
+    StageTimer timer(c, T_FILL);
+    for (int i = 0; i < nch; i++) {
+        const i64 lo = i * cf, hi = std::min<i64>(F, lo + cf);
+        if (hi <= lo) break;
+        if (dbgpipe) fprintf(stderr, "  main waits for chunk %d at %.1f ms\n", i, since());
+        if ((rc = wait_chunk(i))) return finish(rc);
+        if (dbgpipe) fprintf(stderr, "  main has chunk %d at %.1f ms\n", i, since());
+        if (i == 0) {
+            // the tight pruning table from the static displacements of the first chunk (a frame beyond it takes the
+            // loose table: exact either way)
+            c->F = hi;
+            rc = ensure_tight_table(c);
+            c->F = F;
+            if (rc) return finish(rc);
+        }
+        if ((rc = fill3_launch(c, p, true, lo, hi))) return finish(rc);
+        if ((rc = fit_stream_rows(c, lo * M, (hi - lo) * M, fit_threshold))) return finish(rc);
+    }
+    timer.stop();
+    c->rows_valid = true;
+    c->assign_valid = false;
+    u64 *hb = (u64 *)c->h_pinned;
+    if (hipMemcpyAsync(hb, c->d_err, 72, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        c->msg = "read-back of the fill's error word failed";
+        return finish(SIT_ERR_HIP);
+    }
+    finish(SIT_OK);
+    const u64 hkey = hb[0], hs[4] = {hb[1], hb[2], hb[3], hb[4]};
+    if (n_all_zero) *n_all_zero = (i64)hs[0];
+    c->fallback_frames = (i64)hs[2];
+    const int kind = decode_error(c, hkey, err);
+    if (kind != SIT_OK) return kind;
+    if (hs[3]) { c->msg = "landmark row wider than the pruning bound (internal error)"; return SIT_ERR_CAPACITY; }
+    *fitted = 1;
+    return SIT_OK;
 }
 
 extern "C" int sit_static_seen(sit_ctx *c, i64 local_frame, uint8_t *seen)

@@ -63,7 +63,7 @@ struct Fill3Head {
     const double *frame_dmax;
     const double2 *exptab;
     u64 *err, *scal;
-    i64 F, A, frame0;
+    i64 F, A, frame0, fbeg;           // the launch covers frames [fbeg, F)
     int S, M, fpb, contig, debug_stop, rcap, iw, force_loose, s0, m0, tcap;
     double delta2, thr2_lo, thr2_hi, static_thr, safe2;
 };
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     double *xyz = (double *)(etab + F3_EXPN);                   // [fpb][S + M][3]; mobiles become centroid - ion
     u64 *fmax = (u64 *)(xyz + 3 * fpb * SM);                    // [fpb]
     const Pbc &P = h.P;
-    const i64 f0 = (i64)blockIdx.x * fpb;
+    const i64 f0 = h.fbeg + (i64)blockIdx.x * fpb;
     const int nf = (int)((h.F - f0) < fpb ? (h.F - f0) : fpb);
     const u64 errw = (u64)(S + 1 + M);
 
@@ -672,8 +672,9 @@ struct F3Tuned { i64 key[8]; int rcap, tcap; };
 static std::mutex g_f3_mutex;
 static std::vector<F3Tuned> g_f3_tuned;
 
-int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
+int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64 f_hi)
 {
+    if (f_hi < 0) f_hi = c->F;
     const i64 S = c->S, M = c->M;
     SIT_REQUIRE(c, c->D * c->Vp < (1LL << 31) && c->F * S < (1LL << 40) && c->A < (1LL << 25), "sit_fill: sizes too large");
     int rc = fill3_basis_tables(c);
@@ -700,7 +701,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
     h.ref_static = c->d_ref_static;
     h.frame_dmax = p->dynamic_lattice_mapping ? c->d_frame_dmax : nullptr;
     h.exptab = (const double2 *)c->d_exptab;
-    h.err = c->d_err; h.scal = c->d_scal; h.F = c->F; h.A = c->A; h.frame0 = c->frame0;
+    h.err = c->d_err; h.scal = c->d_scal; h.F = f_hi; h.fbeg = f_lo; h.A = c->A; h.frame0 = c->frame0;
     h.S = (int)S; h.M = (int)M;
     const bool dynmap = a.lattice_map != nullptr;
     h.debug_stop = f3_env_int("SITATOR_DEBUG_STOP", 0);
@@ -788,7 +789,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
     h.contig = contig;
 
     // ---- survivor slots / task-table size: measured once per kind of fill ----
-    if (rcap_auto && tcap_auto && h.debug_stop == 0 && f3_env_int("SITATOR_FILL_AUTOTUNE", 1) && c->F * M >= (1 << 18)) {
+    if (rcap_auto && tcap_auto && h.debug_stop == 0 && f3_env_int("SITATOR_FILL_AUTOTUNE", 1) && (f_hi - f_lo) * M >= (1 << 18)) {
         const i64 key[8] = {S, M, c->D, vp, have_tight ? c->W_tight : c->W, (i64)nw * 64 + fpb, dynmap ? 1 : 0, (i64)(c->tight_mean_candidates * 1024)};
         bool found = false;
         {
@@ -805,8 +806,8 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
             hipEvent_t e0, e1;
             HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
             Fill3Head ht = h;
-            ht.F = std::min<i64>(c->F, (i64)2048 * fpb);                      // the leading frames: ~1.6 rounds of workgroups
-            const unsigned gt = (unsigned)((ht.F + fpb - 1) / fpb);
+            ht.F = std::min<i64>(f_hi, f_lo + (i64)2048 * fpb);               // the leading frames: ~1.6 rounds of workgroups
+            const unsigned gt = (unsigned)((ht.F - f_lo + fpb - 1) / fpb);
             float best = 1e30f;
             int br = rcap, bt = tcap;
             const int keep_tcap = tcap;
@@ -847,7 +848,8 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store)
     if (f3_env_int("SITATOR_DEBUG_SHAPE", 0))
         fprintf(stderr, "k_fill3 shape: nw %d fpb %d rcap %d iw %d tcap %d, %zu bytes of LDS per workgroup\n", nw, fpb, rcap, iw, tcap, lds);
     c->last_fpb = fpb; c->last_kernel = 3; c->last_iw = rcap; c->last_nw = nw;
-    const unsigned grid = (unsigned)((c->F + fpb - 1) / fpb);
+    const unsigned grid = (unsigned)((f_hi - f_lo + fpb - 1) / fpb);
+    if (f_hi <= f_lo) return SIT_OK;
     HIP_TRY(c, f3_dispatch(c, h, full, grid, lds, nw, vp, diag, dynmap));
     return SIT_OK;
 }

@@ -30,6 +30,7 @@ struct sit_ctx {
     int device = 0;
     int num_cu = 0;                                            // compute units of the device (queried once)
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;                         // uploads of sit_upload_fill_fit (fill.hip)
     hipEvent_t tev0[T_N] = {nullptr}, tev1[T_N] = {nullptr};   // per-stage event pairs
     bool tpending[T_N] = {false};                              // recorded, not yet read
     void *h_pinned = nullptr;                                  // small pinned read-back buffer (256 bytes)
@@ -321,4 +322,7 @@ int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32
 int fill2_sample_dmax(sit_ctx *c, std::vector<double> &out);
 int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, double threshold);
 bool fill3_eligible(sit_ctx *c);
-int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store);
+int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo = 0, i64 f_hi = -1);   // frames [f_lo, f_hi)
+int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S, const i64 *mobile_idx, i64 M, i64 frame0);   // ctx.hip
+// rows [row_lo, row_lo + nrows) of the stored landmark rows through the fit (cluster.hip)
+int fit_stream_rows(sit_ctx *c, i64 row_lo, i64 nrows, double threshold);

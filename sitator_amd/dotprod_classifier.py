@@ -93,7 +93,14 @@ class DotProdClassifier(object):
         ctx, comm = X.ctx, X.comm
         centers = np.zeros((0, ctx.D))
         counts = np.zeros(0, dtype=np.int64)
-        for r in range(comm.size):
+        prefit = getattr(X, "prefit_threshold", None)
+        if prefit is not None and prefit == self._threshold and comm.size == 1:
+            # the rows went through the fit while they were being made (sit_upload_fill_fit): the state is there
+            X.prefit_threshold = None
+            centers, counts = ctx.fit_get_state()
+        else:
+            prefit = None
+        for r in range(comm.size if prefit is None else 0):
             if comm.rank == r:
                 if r == 0:
                     ctx.fit_reset()

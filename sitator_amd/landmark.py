@@ -13,6 +13,7 @@ Extra, reference-preserving keywords: ``comm`` (frame sharding across GPUs, see 
 and ``device``.
 """
 import importlib
+import os
 import logging
 import time
 
@@ -72,6 +73,8 @@ class LandmarkAnalysis(object):
         self.force_no_memmap = force_no_memmap
         self._comm = comm if comm is not None else Comm()
         self._device = device
+        # upload, fill and first fit pass as one pipelined call where that applies (SITATOR_PIPELINE=0: the separate calls)
+        self._pipeline = os.environ.get("SITATOR_PIPELINE", "1") != "0"
         self._landmark_vectors = None
         self._landmark_dimension = None
         self._ctx = None
@@ -143,11 +146,25 @@ class LandmarkAnalysis(object):
             frame0 = int(np.sum(counts[:comm.rank]))
         static_idx = np.where(sn.static_mask)[0]
         mobile_idx = np.where(sn.mobile_mask)[0]
-        ctx.set_frames(frames, static_idx, mobile_idx, frame0=frame0)
-        lap("upload")
-        logger.info("  - computing landmark vectors -")
-        rc, n_zero, err = ctx.fill(self.dynamic_lattice_mapping, self.relaxed_lattice_checks,
-                                   self.check_for_zero_landmarks)
+        prefit = None
+        if (comm.size == 1 and self._cluster_algo == "dotprod" and not self.dynamic_lattice_mapping and self._pipeline
+                and hasattr(ctx, "upload_fill_fit")):
+            # one process, the ordered dotprod clustering: upload, fill and the first pass of fit_centers as one
+            # pipelined call (the fit starts on the first frames while the last ones are still being uploaded)
+            from .cluster import dotprod as _dp
+            thr = dict(_dp.DEFAULT_PARAMS, **self._clustering_params)["clustering_threshold"]
+            logger.info("  - computing landmark vectors -")
+            rc, n_zero, err, fitted = ctx.upload_fill_fit(frames, static_idx, mobile_idx, frame0, False,
+                                                          self.relaxed_lattice_checks, self.check_for_zero_landmarks, thr)
+            if fitted:
+                prefit = thr
+            lap("upload")
+        else:
+            ctx.set_frames(frames, static_idx, mobile_idx, frame0=frame0)
+            lap("upload")
+            logger.info("  - computing landmark vectors -")
+            rc, n_zero, err = ctx.fill(self.dynamic_lattice_mapping, self.relaxed_lattice_checks,
+                                       self.check_for_zero_landmarks)
         self._raise_fill_error(ctx, comm, rc, err)
         self.n_all_zero_lvecs = int(comm.allreduce_sum(np.array([n_zero], dtype=np.int64))[0]) \
             if comm.size > 1 else n_zero
@@ -155,6 +172,7 @@ class LandmarkAnalysis(object):
             logger.warning("     Had %i all-zero landmark vectors; no error because `check_for_zero_landmarks = False`."
                            % self.n_all_zero_lvecs)
         self._landmark_vectors = LandmarkVectors(ctx, comm)
+        self._landmark_vectors.prefit_threshold = prefit    # the first pass of fit_centers is in the context already
 
         lap("fill")
         # Step 3: cluster (plugin located by name, :234-242)

@@ -213,3 +213,67 @@ def test_c3_shaped_cut_against_oracle(oracle):
 def test_triclinic_mcl_against_oracle(oracle):
     from sitator_amd import synth
     _oracle_vs_gpu(oracle, synth.config_host("C1b"), 4, 1500, seed=505, algo="mcl")
+
+
+def _run_c2(frames, gen, host, pipeline, **kw):
+    import os
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure
+    sn = SiteNetwork(Structure(gen.reference_positions(), host.cell), gen.static_mask, gen.mobile_mask)
+    sn.centers = host.centers
+    sn.vertices = host.vertices
+    os.environ["SITATOR_PIPELINE"] = "1" if pipeline else "0"
+    try:
+        la = LandmarkAnalysis(verbose=False, **kw)
+        st = la.run(sn, frames)
+    finally:
+        os.environ.pop("SITATOR_PIPELINE", None)
+    return la, st
+
+
+@pytest.mark.gpu
+def test_pipelined_upload_fill_fit_equals_the_separate_calls():
+    """LandmarkAnalysis.run with the upload overlapped (sit_upload_fill_fit: chunks of the trajectory are filled and
+    streamed through fit_centers while the later ones are still on their way) against the plain sequence of calls:
+    same labels, confidences, site centres, landmark vectors, zero-vector count."""
+    from sitator_amd import synth
+    host = synth.config_host("C2")
+    gen = synth.TrajectoryGenerator(host, 64, seed=77, p_hop=1 / 200.0)
+    frames = gen.generate(12288)
+    la_p, st_p = _run_c2(frames, gen, host, True, check_for_zero_landmarks=False)
+    la_s, st_s = _run_c2(frames, gen, host, False, check_for_zero_landmarks=False)
+    assert "upload" in la_p.wall_timings and la_p.wall_timings.get("fill", 0.0) < 1e-3, "the pipelined call was not taken"
+    assert np.array_equal(st_p.traj, st_s.traj)
+    assert np.array_equal(st_p.confidences, st_s.confidences)
+    assert np.array_equal(st_p.site_network.centers, st_s.site_network.centers)
+    assert np.array_equal(np.asarray(la_p.cluster_centers_), np.asarray(la_s.cluster_centers_))
+    assert la_p.n_all_zero_lvecs == la_s.n_all_zero_lvecs
+    lo = 64 * 9000
+    assert np.array_equal(la_p._ctx.rows_dense(lo, 640), la_s._ctx.rows_dense(lo, 640))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["static", "zero"])
+def test_pipelined_call_reports_the_first_offender_of_a_late_chunk(kind):
+    """An error in a late chunk of the pipelined call is the error the separate calls raise: same type, frame and
+    atom (the smallest key over all chunks, as sit_fill finds it over all frames)."""
+    from sitator_amd import synth, errors
+    host = synth.config_host("C2")
+    gen = synth.TrajectoryGenerator(host, 64, seed=78)
+    frames = gen.generate(12288)
+    sidx, midx = np.where(gen.static_mask)[0], np.where(gen.mobile_mask)[0]
+    if kind == "static":
+        frames[11000, sidx[5]] += (1.7, 0.0, 0.0)           # beyond static_movement_threshold
+        frames[11900, sidx[9]] += (0.0, 1.9, 0.0)
+        exc = errors.StaticLatticeError
+    else:
+        frames[10500, midx[3]] = host.static_pos[0] + 0.01  # an ion sitting on a host atom: no landmark in reach
+        exc = errors.ZeroLandmarkError
+    got = []
+    for pipeline in (True, False):
+        with pytest.raises(exc) as ei:
+            _run_c2(frames, gen, host, pipeline)
+        got.append(ei.value)
+    if kind == "static":
+        assert got[0].frame == got[1].frame == 11000 and list(got[0].lattice_atoms) == list(got[1].lattice_atoms)
+    else:
+        assert (got[0].frame, got[0].mobile_index) == (got[1].frame, got[1].mobile_index)
