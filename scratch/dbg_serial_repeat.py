@@ -1,5 +1,6 @@
-"""The serial single-workgroup fit flakes (about 1 % of the soak's cases, always the serial side): how often on the
-two cases that showed it, and does a stronger fence (SITATOR_FIT_FENCE=1 -> device-scope fence in k_fit_stream) help?"""
+"""The serial single-workgroup fit flaked (about 1 % of the soak's cases, always the serial side): how often on the
+two cases that showed it?  (Cause: a missing barrier in the founding branch of k_fit_stream, DESIGN.md section 3;
+0 of 50 on both cases since.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -38,6 +38,7 @@ SIGNATURES = {
     "sit_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "sit_create": (C.c_int, [_dp, _dp, C.c_int, C.POINTER(_vp)]),
     "sit_destroy": (None, [_vp]),
+    "sit_release_cached_memory": (None, []),
     "sit_last_message": (C.c_char_p, [_vp]),
     "sit_wrap_points": (C.c_int, [_vp, _dp, i64]),
     "sit_distances": (C.c_int, [_vp, _dp, _dp, i64, _dp]),
@@ -125,6 +126,11 @@ def device_count():
     n = C.c_int(0)
     load().sit_device_count(C.byref(n))
     return n.value
+
+
+def release_cached_memory():
+    """Returns the idle large device buffers the library keeps between contexts (sit_release_cached_memory)."""
+    load().sit_release_cached_memory()
 
 
 def _d(a):
@@ -230,6 +236,12 @@ class HipContext(object):
         self._check(self.lib.sit_set_basis(self._h, _d(ref_static), self.S, _i(verts), _d(vert_dists),
                                            self.D, self.V, float(midpoint), float(steepness),
                                            float(static_threshold)))
+
+    def frames_device_ptr(self):
+        """Device address of the resident trajectory (sit_frames_device_ptr)."""
+        p = C.c_void_p()
+        self._check(self.lib.sit_frames_device_ptr(self._h, C.byref(p)))
+        return p.value
 
     def set_frames(self, frames, static_idx, mobile_idx, frame0=0):
         frames = _f64(frames)

@@ -255,15 +255,15 @@ int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32
     HIP_TRY(c, hipMemcpyAsync(hs, stats, 12, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const i64 total = (i64)hs[1] + ((i64)hs[2] << 31);
-    if (total > 2000000000LL) { (void)hipFree(cursor); c->msg = "candidate table too large"; return SIT_ERR_CAPACITY; }
-    if ((rc = dev_alloc(c, d_list, total > 0 ? total : 1))) { (void)hipFree(cursor); return rc; }
-    if ((rc = dev_alloc(c, d_crit, total > 0 ? total : 1))) { (void)hipFree(cursor); return rc; }
+    if (total > 2000000000LL) { sit_dfree(c, cursor); c->msg = "candidate table too large"; return SIT_ERR_CAPACITY; }
+    if ((rc = dev_alloc(c, d_list, total > 0 ? total : 1))) { sit_dfree(c, cursor); return rc; }
+    if ((rc = dev_alloc(c, d_crit, total > 0 ? total : 1))) { sit_dfree(c, cursor); return rc; }
     a.list = *d_list;
     k_cand_pass<true><<<dim3((unsigned)c->D), dim3(256), 0, c->stream>>>(a);
     k_cand_sort<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, c->stream>>>(*d_off, *d_list, *d_crit, nb, c->D < (1LL << 24) ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(cursor);
+    sit_dfree(c, cursor);
     *W = hs[0] > 0 ? hs[0] : 1;
     *mean = (double)total / (double)nb;
     return SIT_OK;

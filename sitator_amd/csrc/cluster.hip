@@ -575,6 +575,11 @@ __global__ __launch_bounds__(FIT_T) void k_fit_stream(FitArgs a)
             for (i64 d = t; d < a.D; d += FIT_T) ck[d] = xd[d];
             if (t == 0) { a.nrm[K] = vn; a.cnt[K] = w; }
             K++;
+            // the row's entries are cleared below by the threads that loaded them, which are not the threads that
+            // copy them here: without this barrier a founding row now and then lost a component to the clearing
+            // (scratch/dbg_flake31.py: 5 of 150 serial fits of one case, none of 250 with it; the join branch has its own
+            // barrier).  This was the flaky fit test of round 1.
+            __syncthreads();
         } else {                                                          // :283-288
             double *ck = a.cen + to * a.D;
             const i64 nold = a.cnt[to];
@@ -599,10 +604,8 @@ __global__ __launch_bounds__(FIT_T) void k_fit_stream(FitArgs a)
         }
         for (int e = t; e < n; e += FIT_T) xd[ei[e]] = 0.0;
         // The centres live in global memory and the next row's scores are read by OTHER waves than the ones that just
-        // wrote them.  A workgroup-scope fence is not enough on gfx950: about one fit in a hundred then read a stale
-        // L1 line (scratch/dbg_serial_repeat.py: 7 of 50 runs of one C5 case, 0 of 50 with the device-scope fence;
-        // the soak's oracle arbitration showed it was always this kernel, never the step chain).
-        __threadfence();
+        // wrote them: workgroup-scope fence, then the barrier.
+        __threadfence_block();
         __syncthreads();
     }
     if (t == 0) {
@@ -797,7 +800,7 @@ extern "C" int sit_fit_push_dense_rows(sit_ctx *c, const double *rows, const i64
     StageTimer t(c, T_FIT);
     rc = fit_stream(c, dn, di, dv, dw, nrows, (int)D, nrows, threshold);
     t.stop();
-    (void)hipFree(dn); (void)hipFree(di); (void)hipFree(dv); if (dw) (void)hipFree(dw);
+    sit_dfree(c, dn); sit_dfree(c, di); sit_dfree(c, dv); if (dw) sit_dfree(c, dw);
     return rc;
 }
 

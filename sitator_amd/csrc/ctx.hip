@@ -3,7 +3,105 @@
 #include <cstring>
 #include <cstdlib>
 
+#include <mutex>
+#include <vector>
+
 #include "sit_internal.h"
+
+// ---- the process-wide pool of large device buffers (see sit_internal.h) ---------------------------------------------
+namespace {
+struct PoolEnt { void *p; size_t bytes; int device; bool idle; unsigned long long stamp; };
+std::mutex g_pool_mu;
+std::vector<PoolEnt> g_pool;
+unsigned long long g_pool_clock = 0;
+
+size_t pool_env_mb(const char *name, size_t dflt)
+{
+    const char *v = getenv(name);
+    if (!v || !*v) return dflt;
+    const long long x = atoll(v);
+    return x < 0 ? dflt : (size_t)x;
+}
+size_t pool_min_bytes() { static const size_t v = pool_env_mb("SITATOR_POOL_MIN_MB", 64) << 20; return v; }
+size_t pool_cap_bytes() { static const size_t v = pool_env_mb("SITATOR_POOL_GB", 64) << 30; return v; }
+
+// idle buffers beyond the cap go back to the driver, least recently used first (call with the lock held)
+void pool_trim(size_t cap)
+{
+    while (true) {
+        size_t idle = 0;
+        int oldest = -1;
+        for (int i = 0; i < (int)g_pool.size(); i++)
+            if (g_pool[(size_t)i].idle) {
+                idle += g_pool[(size_t)i].bytes;
+                if (oldest < 0 || g_pool[(size_t)i].stamp < g_pool[(size_t)oldest].stamp) oldest = i;
+            }
+        if (idle <= cap || oldest < 0) return;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipSetDevice(g_pool[(size_t)oldest].device);
+        (void)hipFree(g_pool[(size_t)oldest].p);
+        (void)hipSetDevice(dev);
+        g_pool.erase(g_pool.begin() + oldest);
+    }
+}
+}  // namespace
+
+hipError_t sit_dmalloc(sit_ctx *c, void **p, size_t bytes)
+{
+    *p = nullptr;
+    if (bytes == 0) bytes = 8;
+    const bool pooled = bytes >= pool_min_bytes() && pool_cap_bytes() > 0;
+    if (pooled) {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_pool.size(); i++) {
+            const PoolEnt &e = g_pool[(size_t)i];
+            if (!e.idle || e.device != c->device || e.bytes < bytes || e.bytes > bytes + bytes / 4 + (1 << 20)) continue;
+            if (best < 0 || e.bytes < g_pool[(size_t)best].bytes) best = i;
+        }
+        if (best >= 0) { g_pool[(size_t)best].idle = false; *p = g_pool[(size_t)best].p; return hipSuccess; }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        // out of memory with idle buffers held back: return them and try once more
+        (void)hipGetLastError();
+        { std::lock_guard<std::mutex> lock(g_pool_mu); pool_trim(0); }
+        e = hipMalloc(p, bytes);
+        if (e != hipSuccess) return e;
+    }
+    if (pooled) {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size();) { if (g_pool[i].p == *p) g_pool.erase(g_pool.begin() + (long)i); else i++; }
+        g_pool.push_back({*p, bytes, c->device, false, 0ull});
+    }
+    return hipSuccess;
+}
+
+void sit_dfree(sit_ctx *c, void *p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        for (PoolEnt &e : g_pool)
+            if (e.p == p && !e.idle) {
+                // whoever takes the buffer next may be another context on another stream: this one's work on it must
+                // have ended (hipFree would have waited for the whole device)
+                if (c && c->stream) (void)hipStreamSynchronize(c->stream);
+                if (c && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+                e.idle = true; e.stamp = ++g_pool_clock;
+                pool_trim(pool_cap_bytes());
+                return;
+            }
+    }
+    (void)hipFree(p);
+}
+
+extern "C" void sit_release_cached_memory(void)
+{
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    pool_trim(0);
+}
 
 extern "C" int sit_device_count(int *count)
 {
@@ -48,7 +146,7 @@ extern "C" void sit_destroy(sit_ctx *c)
                     c->d_counts, c->d_col_ptr, c->d_col_k, c->d_col_val, c->d_cen_dense, c->d_fit_centers,
                     c->d_hi2p, c->d_vh, c->d_vr, c->d_nv, c->d_exptab, c->d_bin_crit, c->d_tbin_crit,
                     c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scratch};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) sit_dfree(c, p);
     fitfast_free(c);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (int i = 0; i < T_N; i++) { if (c->tev0[i]) (void)hipEventDestroy(c->tev0[i]); if (c->tev1[i]) (void)hipEventDestroy(c->tev1[i]); }
@@ -266,7 +364,7 @@ extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const 
             if (i != j && (c->pbc.cm[3 * i + j] != 0.0 || c->pbc.ci[3 * i + j] != 0.0)) c->cell_diagonal = false;
     const char *fk = getenv("SITATOR_FILL_KERNEL");
     c->fill_kernel = (fk && fk[0] == '1') ? 1 : ((fk && fk[0] == '2') ? 2 : 3);
-    for (void **q : {(void **)&c->d_hi2p, (void **)&c->d_vh, (void **)&c->d_vr, (void **)&c->d_nv}) if (*q) { (void)hipFree(*q); *q = nullptr; }
+    for (void **q : {(void **)&c->d_hi2p, (void **)&c->d_vh, (void **)&c->d_vr, (void **)&c->d_nv}) if (*q) { sit_dfree(c, *q); *q = nullptr; }
     c->tight_valid = false;
     c->rows_valid = false; c->assign_valid = false; c->map_valid = false;
     return SIT_OK;
@@ -311,9 +409,9 @@ extern "C" int sit_set_frames(sit_ctx *c, const double *frames, i64 F, i64 A, co
     if (rc) return rc;
     const i64 bytes = F * A * 24;
     if (!c->frames_owned || c->frames_cap_bytes < bytes) {
-        if (c->frames_owned && c->d_frames) (void)hipFree(c->d_frames);
+        if (c->frames_owned && c->d_frames) sit_dfree(c, c->d_frames);
         c->d_frames = nullptr; c->frames_owned = true; c->frames_cap_bytes = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_frames, (size_t)(bytes > 0 ? bytes : 8)));
+        HIP_TRY(c, sit_dmalloc(c, (void **)&c->d_frames, (size_t)(bytes > 0 ? bytes : 8)));
         c->frames_cap_bytes = bytes;
     }
     if (frames && bytes > 0) {
@@ -331,7 +429,7 @@ extern "C" int sit_set_frames_device(sit_ctx *c, const void *frames_dev, i64 F, 
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = set_frame_meta(c, F, A, static_idx, S, mobile_idx, M, frame0);
     if (rc) return rc;
-    if (c->frames_owned && c->d_frames) (void)hipFree(c->d_frames);
+    if (c->frames_owned && c->d_frames) sit_dfree(c, c->d_frames);
     c->d_frames = (double *)frames_dev;
     c->frames_owned = false; c->frames_cap_bytes = 0;
     return SIT_OK;

@@ -474,13 +474,17 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
         return sit_fill(c, p, n_all_zero, err);
     }
     if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
+    const bool dbgpipe = getenv("SITATOR_DEBUG_PIPE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     const i64 bytes = F * A * 24;
     if (!c->frames_owned || c->frames_cap_bytes < bytes) {
-        if (c->frames_owned && c->d_frames) (void)hipFree(c->d_frames);
+        if (c->frames_owned && c->d_frames) sit_dfree(c, c->d_frames);
         c->d_frames = nullptr; c->frames_owned = true; c->frames_cap_bytes = 0;
-        HIP_TRY(c, hipMalloc((void **)&c->d_frames, (size_t)bytes));
+        HIP_TRY(c, sit_dmalloc(c, (void **)&c->d_frames, (size_t)bytes));
         c->frames_cap_bytes = bytes;
     }
+    if (dbgpipe) fprintf(stderr, "  frame buffer at %.1f ms\n", since());
     // every allocation first: hipMalloc / hipFree stall the other thread's copies
     const i64 N = c->N, W = c->W;
     if (c->rows_W != W || c->rows_N != N || !c->d_row_nnz) {
@@ -494,7 +498,9 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
     }
     if (hipMemsetAsync(c->d_err, 0xFF, sizeof(u64), c->stream) != hipSuccess ||
         hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream) != hipSuccess) { c->msg = "counters"; return SIT_ERR_HIP; }
+    if (dbgpipe) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "  row buffers at %.1f ms\n", since()); }
     if ((rc = sit_fit_reset(c))) return rc;
+    if ((rc = fill3_prepare(c))) return rc;
     if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     // chunks of whole frames: 8 to 16 of them, at least 4096 frames each
     int nch = (int)(F / chunk_frames_min);
@@ -505,9 +511,8 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
     hipEvent_t slot_ev[RING_SLOTS] = {};
     for (int i = 0; i < RING_SLOTS; i++) HIP_TRY(c, hipEventCreateWithFlags(&slot_ev[i], hipEventDisableTiming));
     std::atomic<int> issued(0), failed(0);
-    const bool dbgpipe = getenv("SITATOR_DEBUG_PIPE") != nullptr;
-    const auto t_start = std::chrono::steady_clock::now();
-    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    const bool merge = !(getenv("SITATOR_PIPE_MERGE") && getenv("SITATOR_PIPE_MERGE")[0] == '0');
+    if (dbgpipe) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "  buffers and tables ready at %.1f ms\n", since()); }
     std::thread up([&]() {
         if (hipSetDevice(c->device) != hipSuccess) failed.store(1);
         for (int i = 0; i < nch; i++) {
@@ -534,12 +539,17 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
         return SIT_OK;
     };
     StageTimer timer(c, T_FILL);
-    for (int i = 0; i < nch; i++) {
-        const i64 lo = i * cf, hi = std::min<i64>(F, lo + cf);
-        if (hi <= lo) break;
+    for (int i = 0; i < nch;) {
+        if (i * cf >= F) break;
         if (dbgpipe) fprintf(stderr, "  main waits for chunk %d at %.1f ms\n", i, since());
         if ((rc = wait_chunk(i))) return finish(rc);
-        if (dbgpipe) fprintf(stderr, "  main has chunk %d at %.1f ms\n", i, since());
+        // chunks that have landed meanwhile go in the same fill launch and the same fit call (chunk 0 stays alone:
+        // the tight table is sized on it and the sooner the fit starts founding its clusters the better)
+        int j = i;
+        while (merge && i > 0 && j + 1 < nch && (j + 1) * cf < F && issued.load(std::memory_order_acquire) > j + 1 &&
+               hipEventQuery(ev[(size_t)(j + 1)]) == hipSuccess) j++;
+        const i64 lo = i * cf, hi = std::min<i64>(F, (j + 1) * cf);
+        if (dbgpipe) fprintf(stderr, "  main has chunks %d..%d at %.1f ms\n", i, j, since());
         if (i == 0) {
             // the tight pruning table from the static displacements of the first chunk (a frame beyond it takes the
             // loose table: exact either way)
@@ -547,11 +557,15 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
             rc = ensure_tight_table(c);
             c->F = F;
             if (rc) return finish(rc);
+            if (dbgpipe) fprintf(stderr, "  tight table at %.1f ms\n", since());
         }
         if ((rc = fill3_launch(c, p, true, lo, hi))) return finish(rc);
+        if (dbgpipe) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "  chunks %d..%d filled at %.1f ms\n", i, j, since()); }
         if ((rc = fit_stream_rows(c, lo * M, (hi - lo) * M, fit_threshold))) return finish(rc);
+        i = j + 1;
     }
     timer.stop();
+    if (dbgpipe) fprintf(stderr, "  last fit done at %.1f ms\n", since());
     c->rows_valid = true;
     c->assign_valid = false;
     u64 *hb = (u64 *)c->h_pinned;

@@ -672,6 +672,18 @@ struct F3Tuned { i64 key[8]; int rcap, tcap; };
 static std::mutex g_f3_mutex;
 static std::vector<F3Tuned> g_f3_tuned;
 
+// Everything fill3_launch allocates, ahead of time (the pipelined call: an allocation stalls copies in flight)
+int fill3_prepare(sit_ctx *c)
+{
+    int rc = fill3_basis_tables(c);
+    if (rc) return rc;
+    if (!c->d_fill_args) {
+        if ((rc = dev_alloc(c, &c->d_fill_args, (i64)std::max(sizeof(Fill3Args), (size_t)1024)))) return rc;
+        c->fill_args_host.clear();
+    }
+    return SIT_OK;
+}
+
 int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64 f_hi)
 {
     if (f_hi < 0) f_hi = c->F;

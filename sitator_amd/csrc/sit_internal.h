@@ -166,12 +166,19 @@ static inline hipError_t lds_limit(const void *kernel, size_t bytes, int device)
     return e;
 }
 
+// Device memory of a context (ctx.hip).  Buffers of SITATOR_POOL_MIN_MB (64) and more are not returned to the driver
+// when a context lets go of them but kept, up to SITATOR_POOL_GB (64) in all, for the next context of the process:
+// on this driver a multi-GB hipFree followed by a hipMalloc of the same pages stalls for about a second per 27 GB.
+// Contents are whatever the last user left: every caller initialises what it reads.
+hipError_t sit_dmalloc(sit_ctx *c, void **p, size_t bytes);
+void sit_dfree(sit_ctx *c, void *p);
+
 template <typename T>
 static inline int dev_alloc(sit_ctx *c, T **p, i64 n)
 {
-    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (*p) { sit_dfree(c, *p); *p = nullptr; }
     if (n <= 0) n = 1;
-    HIP_TRY(c, hipMalloc((void **)p, sizeof(T) * (size_t)n));
+    HIP_TRY(c, sit_dmalloc(c, (void **)p, sizeof(T) * (size_t)n));
     return SIT_OK;
 }
 
@@ -323,6 +330,7 @@ int fill2_sample_dmax(sit_ctx *c, std::vector<double> &out);
 int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, double threshold);
 bool fill3_eligible(sit_ctx *c);
 int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo = 0, i64 f_hi = -1);   // frames [f_lo, f_hi)
+int fill3_prepare(sit_ctx *c);     // the allocations of fill3_launch, ahead of time
 int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S, const i64 *mobile_idx, i64 M, i64 frame0);   // ctx.hip
 // rows [row_lo, row_lo + nrows) of the stored landmark rows through the fit (cluster.hip)
 int fit_stream_rows(sit_ctx *c, i64 row_lo, i64 nrows, double threshold);

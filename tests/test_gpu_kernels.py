@@ -579,3 +579,33 @@ def test_mcl_reductions_are_exact_and_reproducible(oracle):
         m = lab == k
         np.testing.assert_allclose(w1[k], conf[m].sum(), rtol=1e-13)
         np.testing.assert_allclose(s1[k], (conf[m][:, None] * X[m]).sum(axis=0), rtol=1e-12, atol=1e-300)
+
+
+@pytest.mark.gpu
+def test_large_buffers_are_recycled_between_contexts_with_identical_results():
+    """Device buffers of 64 MB and more go to the library's pool when a context closes and to the next context that
+    asks (ctx.hip): the second context must not see what the first left in them."""
+    from sitator_amd import synth, _lib
+    host = synth.config_host("C2")
+    F = 6000                                     # 576 atoms x 24 B x 6000 frames = 83 MB of trajectory
+    ctx, *_ = _setup(host, 64, F, seed=91)
+    assert ctx.fill(check_for_zeros=False)[0] == 0
+    a = ctx.rows_dense(0, 64 * 300).copy()
+    ptr_a = ctx.frames_device_ptr()
+    ctx.close()
+    # a different trajectory of the same size: takes the pooled buffer, must give its own rows
+    ctx2, *_ = _setup(host, 64, F, seed=92)
+    assert ctx2.fill(check_for_zeros=False)[0] == 0
+    b = ctx2.rows_dense(0, 64 * 300).copy()
+    ptr_b = ctx2.frames_device_ptr()
+    ctx2.close()
+    ctx3, *_ = _setup(host, 64, F, seed=91)
+    assert ctx3.fill(check_for_zeros=False)[0] == 0
+    a2 = ctx3.rows_dense(0, 64 * 300).copy()
+    ctx3.close()
+    assert ptr_a == ptr_b, "the trajectory buffer was not recycled"
+    assert np.array_equal(a, a2) and not np.array_equal(a, b)
+    _lib.release_cached_memory()
+    ctx4, *_ = _setup(host, 64, F, seed=91)
+    assert ctx4.fill(check_for_zeros=False)[0] == 0
+    assert np.array_equal(ctx4.rows_dense(0, 64 * 300), a)
