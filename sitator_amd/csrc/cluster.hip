@@ -445,8 +445,17 @@ extern "C" int sit_get_assignments(sit_ctx *c, i64 *labels, double *confs, i64 *
     if (!c) return SIT_ERR_INVALID;
     SIT_REQUIRE(c, c->assign_valid, "no assignments on the device");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (labels && c->N) HIP_TRY(c, hipMemcpyAsync(labels, c->d_labels, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
-    if (confs && c->N) HIP_TRY(c, hipMemcpyAsync(confs, c->d_confs, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    static const size_t staged_min = [] { const char *v = getenv("SITATOR_STAGED_D2H_MB"); const long long n = v ? atoll(v) : -1; return (size_t)(n >= 0 ? n : 64) << 20; }();
+    const bool staged = (size_t)c->N * 8 >= staged_min;               // large read-backs go through the copy threads
+    int rc;
+    if (labels && c->N) {
+        if (staged) { if ((rc = download_staged(c, c->stream, labels, c->d_labels, (size_t)c->N * 8))) return rc; }
+        else HIP_TRY(c, hipMemcpyAsync(labels, c->d_labels, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    if (confs && c->N) {
+        if (staged) { if ((rc = download_staged(c, c->stream, confs, c->d_confs, (size_t)c->N * 8))) return rc; }
+        else HIP_TRY(c, hipMemcpyAsync(confs, c->d_confs, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    }
     if (counts) HIP_TRY(c, hipMemcpyAsync(counts, c->d_counts, (size_t)c->K * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SIT_OK;

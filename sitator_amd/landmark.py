@@ -194,7 +194,7 @@ class LandmarkAnalysis(object):
             rep_lvecs = np.asarray(rep_lvecs)
             assert rep_lvecs.shape == (len(cluster_counts), self._landmark_dimension)
         self.cluster_centers_ = rep_lvecs          # site centres in landmark space (extra attribute)
-        if len(lmk_lbls):
+        if len(lmk_lbls) and logger.isEnabledFor(logging.INFO):           # a pass over all labels: only when asked for
             logger.info("    Failed to assign %i%% of mobile particle positions to sites."
                         % (100.0 * np.sum(lmk_lbls < 0) / float(len(lmk_lbls))))
         lmk_lbls = lmk_lbls.reshape(n_frames, sn.n_mobile)
@@ -212,7 +212,8 @@ class LandmarkAnalysis(object):
             out_sn.vertices = [set.union(*[set(sn.vertices[l]) for l in lclust]) for lclust in landmark_clusters]
 
         lap("site_centers")
-        out_st = SiteTrajectory(out_sn, lmk_lbls, lmk_confs, _ctx=ctx, _comm=comm)
+        # the label array was made for this call and nothing else refers to it: adopted, not copied (0.9 GB at C3)
+        out_st = SiteTrajectory(out_sn, lmk_lbls, lmk_confs, _ctx=ctx, _comm=comm, _adopt=True)
         self.n_multiple_assignments, self.avg_mobile_per_site = out_st.check_multiple_occupancy(
             max_mobile_per_site=self.max_mobile_per_site)
         # the context is shared with this object (predict() through landmark_vectors rewrites its labels): from here

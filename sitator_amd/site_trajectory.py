@@ -15,7 +15,7 @@ class SiteTrajectory(object):
 
     SITE_UNKNOWN = -1
 
-    def __init__(self, site_network, particle_assignments, confidences=None, _ctx=None, _comm=None):
+    def __init__(self, site_network, particle_assignments, confidences=None, _ctx=None, _comm=None, _adopt=False):
         particle_assignments = np.asarray(particle_assignments)
         if particle_assignments.ndim != 2:
             raise ValueError("particle_assignments must be 2D")
@@ -24,7 +24,8 @@ class SiteTrajectory(object):
         if confidences is not None and confidences.shape != particle_assignments.shape:
             raise ValueError("confidences has wrong shape %s; should be %s" % (confidences.shape, particle_assignments.shape))
         self._sn = site_network
-        self._traj = particle_assignments.copy()
+        # SiteTrajectory.py:31 copies; _adopt: the caller hands over an array nobody else holds
+        self._traj = particle_assignments if _adopt else particle_assignments.copy()
         self._confs = confidences
         self._real_traj = None
         # device context whose resident assignments equal self._traj (set by LandmarkAnalysis)
