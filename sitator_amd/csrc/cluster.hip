@@ -719,6 +719,7 @@ static int fit_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *
     i64 begin = 0;
     if (fitfast_valid(c)) {
         if ((rc = fitfast_stream(c, nnz, idx, val, weights, stride, width, nrows, threshold, &begin))) return rc;
+        if (getenv("SITATOR_DEBUG_PIPE")) fprintf(stderr, "    fit: step chain took %lld of %lld rows, state %s\n", (long long)begin, (long long)nrows, fitfast_valid(c) ? "valid" : "handed over");
         if (begin >= nrows && fitfast_valid(c)) return SIT_OK;
         // a capacity of the sparse state was exceeded: hand the exact state over to the serial dense kernel
         std::vector<double> cen; std::vector<i64> cnt; i64 Kd = 0;

@@ -1277,6 +1277,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         keep.K = K; keep.halt = 1;
         HIP_TRY(c, hipMemcpyAsync(f->st.ctl, &keep, sizeof(keep), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (getenv("SITATOR_DEBUG_PIPE")) fprintf(stderr, "    fit: chain ended with halt %d why %d at row %lld of %lld, K %d, steps %d\n", st.halt, st.why, (long long)base, (long long)nrows, K, st.steps);
         if (st.halt == 1) break;
         if (st.halt == 3) { f->valid = false; c->ff_why = st.why; c->ff_stop_row = base; break; }
         // halt == 2: the centre arrays must grow: export, reallocate, import
@@ -1287,6 +1288,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         f->ready = false;
         if ((rc = ff_from_dense(c, f, cen.data(), cnt.data(), Kd, &fits))) return rc;
         if (!fits) { f->valid = false; break; }
+        f->valid = true;                      // ff_alloc marked the new arena as empty: it now holds the state again
         if (base >= nrows) break;
     }
     *consumed = base;

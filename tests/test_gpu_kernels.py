@@ -496,6 +496,46 @@ def test_speculative_fit_grows_its_state_past_the_first_allocation():
     np.testing.assert_allclose(clf.cluster_centers, ser.cluster_centers, rtol=1e-12, atol=1e-300)
 
 
+def test_speculative_fit_keeps_the_step_chain_after_growing_its_state():
+    """Rows streamed in several calls (as the pipelined upload does): the call in which the sparse state outgrows its
+    first allocation (2048 centres) re-imports it, and the NEXT call must still take the step chain - it once found
+    the state flagged as handed over and went on row by row (105 s for one C4 trajectory).  No capacity is involved:
+    2200 two-landmark prototypes on disjoint landmark pairs."""
+    from sitator_amd.dotprod_classifier import _as_device_rows
+    rng = np.random.default_rng(11)
+    P, N = 2200, 9000
+    D = 2 * P
+    X = np.zeros((N, D))
+    which = rng.integers(0, P, size=N)
+    X[np.arange(N), 2 * which] = rng.uniform(0.5, 1.0, size=N)
+    X[np.arange(N), 2 * which + 1] = rng.uniform(0.5, 1.0, size=N)
+    ctx = _as_device_rows(X[:8]).ctx
+    ctx.fit_reset()
+    batches = []
+    for lo in range(0, N, 3000):
+        ctx.fit_push_dense_rows(X[lo:lo + 3000], np.ones(3000, dtype=np.int64), 0.7)
+        batches.append(ctx.info()["fit_batches"])
+    info = ctx.info()
+    cen, cnt = ctx.fit_get_state()
+    assert len(cen) == len(np.unique(which)) > 2100
+    assert info["fit_capacity_hit"] == 0 and batches[2] > batches[1] > batches[0] > 0, (info, batches)
+    assert int(cnt.sum()) == N
+    # the ordered single-workgroup stream (checked against the oracle in the tests above) on the same calls
+    import os
+    os.environ["SITATOR_FIT"] = "serial"
+    try:
+        ser = _as_device_rows(X[:8]).ctx
+    finally:
+        os.environ.pop("SITATOR_FIT", None)
+    ser.fit_reset()
+    for lo in range(0, N, 3000):
+        ser.fit_push_dense_rows(X[lo:lo + 3000], np.ones(3000, dtype=np.int64), 0.7)
+    exp, exp_cnt = ser.fit_get_state()
+    assert ser.info()["fit_batches"] == 0
+    assert cen.shape == exp.shape and np.array_equal(cnt, exp_cnt)
+    np.testing.assert_allclose(cen, exp, rtol=1e-12, atol=1e-300)
+
+
 @pytest.mark.parametrize("cfg,M,F", [("C2", 64, 120), ("C5", 160, 30), ("C1b", 4, 300)])
 def test_eight_wave_workgroups_give_the_same_rows(cfg, M, F):
     """The fill kernel's 8-waves-per-workgroup build (chosen automatically for big frames) against the 4-wave one:
