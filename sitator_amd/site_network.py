@@ -1,7 +1,7 @@
 """Minimal ``SiteNetwork`` data contract consumed and produced by ``LandmarkAnalysis.run``
 (reference: ``sitator/SiteNetwork.py:48-125,167-223``).  Only what the landmark path touches:
-structure/masks/counts, ``static_structure``, ``centers``, ``vertices``, ``copy()``.
-Site/edge attribute storage and plotting are out of scope.
+structure/masks/counts, ``static_structure``, ``centers``, ``vertices``, ``site_types``, the named per-site /
+per-edge arrays the next-tier operators attach, ``copy()``.  Plotting is out of scope.
 """
 import re
 
@@ -39,164 +39,163 @@ def _static_subset(structure, drop):
     return sub
 
 
+def _read_only(array):
+    """A view of ``array`` that refuses writes (what the reference's getters hand out)."""
+    if array is None:
+        return None
+    out = array.view()
+    out.flags.writeable = False
+    return out
+
+
 class SiteNetwork(object):
-    """Sites (``centers``, optional ``vertices``) of mobile atoms in a static host lattice."""
+    """Sites (``centers``, optional ``vertices``) of mobile atoms in a static host lattice.
+
+    Data contract of ``sitator/SiteNetwork.py``: masks and counts (``:70-96``), ``centers`` / ``vertices`` /
+    ``site_types`` (``:167-256``), named per-site and per-edge arrays readable as ``sn.<name>`` (``:262-391``).
+    Everything derived from a set of centres lives in ONE record (``_sites``) that a new ``centers`` replaces, and the
+    named arrays in one table keyed by name with their kind - the messages of the reference's errors are kept, they
+    are part of the drop-in behaviour."""
+
+    ATTR_NAME_REGEX = re.compile("^[a-zA-Z][a-zA-Z0-9_]*$")
+    _SITE, _EDGE = "site", "edge"
 
     def __init__(self, structure, static_mask, mobile_mask):
-        static_mask = np.asarray(static_mask, dtype=bool)
-        mobile_mask = np.asarray(mobile_mask, dtype=bool)
-        assert static_mask.ndim == mobile_mask.ndim == 1, "The masks must be one-dimensional"
-        assert len(structure) == len(static_mask) == len(mobile_mask), \
+        masks = [np.asarray(m, dtype=bool) for m in (static_mask, mobile_mask)]
+        assert masks[0].ndim == 1 and masks[1].ndim == 1, "The masks must be one-dimensional"
+        assert len(structure) == len(masks[0]) == len(masks[1]), \
             "The masks must have the same length as the # of atoms in the structure."
-        assert not np.any(static_mask & mobile_mask), "static_mask and mobile_mask cannot overlap."
+        assert not (masks[0] & masks[1]).any(), "static_mask and mobile_mask cannot overlap."
         self.structure = structure
-        self.static_mask = static_mask
-        self.mobile_mask = mobile_mask
-        self.n_static = int(np.sum(static_mask))
-        self.n_mobile = int(np.sum(mobile_mask))
-        self.static_structure = _static_subset(structure, (~static_mask) | mobile_mask)
+        self.static_mask, self.mobile_mask = masks
+        self.n_static, self.n_mobile = (int(np.count_nonzero(m)) for m in masks)
+        self.static_structure = _static_subset(structure, ~masks[0] | masks[1])
         assert len(self.static_structure) == self.n_static
-        self._centers = None
-        self._vertices = None
-        self._types = None
-        self._site_attrs = {}
-        self._edge_attrs = {}
+        self._sites = self._no_sites()
 
-    # -- site / edge attributes (reference SiteNetwork.py:262-306, :330-391): per-site arrays and
-    #    (n_sites, n_sites) per-edge matrices that analysis steps attach, readable as `sn.<name>`
-    ATTR_NAME_REGEX = re.compile("^[a-zA-Z][a-zA-Z0-9_]*$")
+    @staticmethod
+    def _no_sites(centers=None):
+        return {"centers": centers, "vertices": None, "types": None, "named": {}}
+
+    # -- named per-site / per-edge arrays -------------------------------------------------------------------------
+    def _names_of(self, kind):
+        return [name for name, (k, _) in self._sites["named"].items() if k == kind]
 
     @property
     def site_attributes(self):
-        return list(self._site_attrs.keys())
+        return self._names_of(self._SITE)
 
     @property
     def edge_attributes(self):
-        return list(self._edge_attrs.keys())
+        return self._names_of(self._EDGE)
 
     def has_attribute(self, attr):
-        return (attr in self._site_attrs) or (attr in self._edge_attrs)
+        return attr in self._sites["named"]
 
     def remove_attribute(self, attr):
-        if attr in self._site_attrs:
-            del self._site_attrs[attr]
-        elif attr in self._edge_attrs:
-            del self._edge_attrs[attr]
-        else:
+        if self._sites["named"].pop(attr, None) is None:
             raise AttributeError("This SiteNetwork has no site or edge attribute `%s`" % attr)
 
     def clear_attributes(self):
-        self._site_attrs = {}
-        self._edge_attrs = {}
+        self._sites["named"] = {}
 
-    def _check_name(self, name):
-        if not self.ATTR_NAME_REGEX.match(name):
+    def _store(self, kind, name, array):
+        if self.ATTR_NAME_REGEX.match(name) is None:
             raise ValueError("Attribute name `%s` invalid; must begin with a letter and contain only letters, numbers, and underscores." % name)
-        if name in self.__dict__ or hasattr(type(self), name) or self.has_attribute(name):
+        taken = name in self.__dict__ or hasattr(type(self), name) or self.has_attribute(name)
+        if taken:
             raise KeyError("Attribute with name `%s` already exists" % name)
+        array = np.asarray(array)
+        n = self.n_sites
+        if kind == self._SITE and array.shape[0] != n:
+            raise ValueError("Attribute array has only %i entries; need one for all %i sites." % (len(array), n))
+        if kind == self._EDGE and array.shape != (n, n):
+            raise ValueError("Attribute matrix has shape %s; need first two dimensions to be %s" % (array.shape, (n, n)))
+        self._sites["named"][name] = (kind, array)
 
     def add_site_attribute(self, name, attr, computed=True):
-        self._check_name(name)
-        attr = np.asarray(attr)
-        if attr.shape[0] != self.n_sites:
-            raise ValueError("Attribute array has only %i entries; need one for all %i sites." % (len(attr), self.n_sites))
-        self._site_attrs[name] = attr
+        self._store(self._SITE, name, attr)
 
     def add_edge_attribute(self, name, attr, computed=True):
-        self._check_name(name)
-        attr = np.asarray(attr)
-        if attr.shape != (self.n_sites, self.n_sites):
-            raise ValueError("Attribute matrix has shape %s; need first two dimensions to be %s" % (attr.shape, (self.n_sites, self.n_sites)))
-        self._edge_attrs[name] = attr
+        self._store(self._EDGE, name, attr)
 
     def __getattr__(self, attrkey):
-        v = self.__dict__
-        if "_site_attrs" in v and attrkey in v["_site_attrs"]:
-            return v["_site_attrs"][attrkey]
-        if "_edge_attrs" in v and attrkey in v["_edge_attrs"]:
-            return v["_edge_attrs"][attrkey]
-        raise AttributeError("This SiteNetwork has no site or edge attribute `%s`" % attrkey)
+        # only reached for names that are not ordinary attributes: the named arrays
+        entry = self.__dict__.get("_sites", {"named": {}})["named"].get(attrkey)
+        if entry is None:
+            raise AttributeError("This SiteNetwork has no site or edge attribute `%s`" % attrkey)
+        return entry[1]
 
-    def __len__(self):
-        return self.n_sites
-
+    # -- sites ----------------------------------------------------------------------------------------------------------
     @property
     def n_sites(self):
-        return 0 if self._centers is None else len(self._centers)
+        c = self._sites["centers"]
+        return len(c) if c is not None else 0
+
+    __len__ = lambda self: self.n_sites
 
     @property
     def n_total(self):
-        return len(self.static_mask)
+        return self.static_mask.shape[0]
 
     @property
     def centers(self):
-        view = self._centers.view()
-        view.flags.writeable = False
-        return view
+        return _read_only(self._sites["centers"])
 
     @centers.setter
     def centers(self, value):
-        value = np.asarray(value)
-        if value.ndim != 2 or value.shape[1] != 3:
+        points = np.asarray(value)
+        if points.ndim != 2 or points.shape[1] != 3:
             raise ValueError("`centers` must be a list of points")
-        self._vertices = None          # new centres invalidate everything derived from the old
-        self._types = None
-        self._site_attrs = {}
-        self._edge_attrs = {}
-        self._centers = value
+        self._sites = self._no_sites(points)       # vertices, types and named arrays belonged to the old sites
 
     @property
     def vertices(self):
-        return self._vertices
+        return self._sites["vertices"]
 
     @vertices.setter
     def vertices(self, value):
-        if len(value) != len(self._centers):
-            raise ValueError("Wrong # of vertices %i; expected %i" % (len(value), len(self._centers)))
-        self._vertices = value
+        if len(value) != self.n_sites:
+            raise ValueError("Wrong # of vertices %i; expected %i" % (len(value), self.n_sites))
+        self._sites["vertices"] = value
 
     @property
     def number_of_vertices(self):
-        return None if self._vertices is None else [len(v) for v in self._vertices]
+        v = self._sites["vertices"]
+        return [len(x) for x in v] if v is not None else None
 
-    # -- site types (reference SiteNetwork.py:233-256)
     @property
     def site_types(self):
-        if self._types is None:
-            return None
-        view = self._types.view()
-        view.flags.writeable = False
-        return view
+        return _read_only(self._sites["types"])
 
     @site_types.setter
     def site_types(self, value):
-        value = np.asarray(value)
-        if not value.shape == (len(self._centers),):
-            raise ValueError("Wrong # of types %s; expected %i" % (value.shape, len(self._centers)))
-        self._types = value
-
-    @property
-    def n_types(self):
-        return len(np.unique(self.site_types))
+        kinds = np.asarray(value)
+        if kinds.shape != (self.n_sites,):
+            raise ValueError("Wrong # of types %s; expected %i" % (kinds.shape, self.n_sites))
+        self._sites["types"] = kinds
 
     @property
     def types(self):
         return np.unique(self.site_types)
 
     @property
+    def n_types(self):
+        return len(self.types)
+
+    @property
     def site_ids(self):
         return np.arange(self.n_sites)
 
     def copy(self):
-        new = SiteNetwork(self.structure, self.static_mask, self.mobile_mask)
-        if self._centers is not None:
-            new.centers = self._centers.copy()
-        if self._vertices is not None:
-            new.vertices = [list(v) for v in self._vertices]
-        if self._types is not None:
-            new.site_types = self._types.copy()
-        for k, v in self._site_attrs.items():
-            new.add_site_attribute(k, v.copy())
-        for k, v in self._edge_attrs.items():
-            new.add_edge_attribute(k, v.copy())
-        return new
+        twin = SiteNetwork(self.structure, self.static_mask, self.mobile_mask)
+        rec = self._sites
+        if rec["centers"] is not None:
+            twin.centers = rec["centers"].copy()
+            if rec["vertices"] is not None:
+                twin.vertices = [list(v) for v in rec["vertices"]]
+            if rec["types"] is not None:
+                twin.site_types = rec["types"].copy()
+            for name, (kind, array) in rec["named"].items():
+                twin._store(kind, name, array.copy())
+        return twin
