@@ -101,6 +101,7 @@ def main():
     from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth, _lib, sharding
 
     comm = None
+    stuck_in_rccl = False           # a thread of this process never came back from RCCL: leave with os._exit at the end
     exchange = "none (single process)"
     if world > 1:
         # control plane: a gloo group (CPU, TCP) carries the RCCL unique id and the agreement on whether every rank
@@ -120,15 +121,35 @@ def main():
                 except Exception as e:      # noqa: BLE001
                     why = "%s: %s" % (type(e).__name__, e)
             dist.broadcast(uid, src=0)          # every rank takes part whatever happened on rank 0
-            try:
-                if not bool(uid.any()):
-                    raise RuntimeError("no unique id from rank 0")
-                if local >= ndev:
-                    raise RuntimeError("LOCAL_RANK %d but only %d GPU(s) visible" % (local, ndev))
-                comm = sharding.RcclComm(local, rank, world, uid.numpy().tobytes())
-            except Exception as e:      # noqa: BLE001 - reported, and the run goes on over gloo
-                why = why or "%s: %s" % (type(e).__name__, e)
-                comm = None
+            # ncclCommInitRank is itself a collective: a rank that cannot take part must say so BEFORE the others
+            # enter it (they would wait for it for ever), so the ranks first agree that every one of them is ready
+            if not why and not bool(uid.any()):
+                why = "no unique id from rank 0"
+            if not why and local >= ndev:
+                why = "LOCAL_RANK %d but only %d GPU(s) visible" % (local, ndev)
+            ready = torch.tensor([0 if why else 1])
+            dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+            if int(ready.item()) == 1:
+                # ... and the call itself runs under a watchdog: a rank stuck in it reports that and carries on
+                import threading
+                box = {}
+
+                def _init():
+                    try:
+                        box["comm"] = sharding.RcclComm(local, rank, world, uid.numpy().tobytes())
+                    except Exception as e:      # noqa: BLE001 - reported, and the run goes on over gloo
+                        box["why"] = "%s: %s" % (type(e).__name__, e)
+
+                th = threading.Thread(target=_init, daemon=True)
+                th.start()
+                limit = float(os.environ.get("SITATOR_RCCL_INIT_TIMEOUT", "120"))
+                th.join(limit)
+                if th.is_alive():
+                    why = "ncclCommInitRank did not return within %.0f s" % limit
+                    stuck_in_rccl = True
+                else:
+                    comm = box.get("comm")
+                    why = box.get("why", "")
             ok = torch.tensor([1 if comm is not None else 0])
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 1:
@@ -141,6 +162,7 @@ def main():
                 dist.all_gather_object(reasons, why)
                 exchange = "gloo (no RCCL communicator: %s)" % "; ".join(sorted({r for r in reasons if r}))[:300]
                 comm = sharding.TorchComm(device="cpu")
+                local = local % max(ndev, 1)        # fewer GPUs than ranks: the ranks share what there is
                 print("[rank %d/%d] %s" % (rank, world, exchange), file=sys.stderr, flush=True)
         else:
             comm = sharding.TorchComm(device="cpu")
@@ -296,6 +318,9 @@ def main():
         comm.barrier()
         if hasattr(comm, "close"):
             comm.close()
+    if stuck_in_rccl:               # interpreter shutdown would wait on the thread that RCCL still holds
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def lib_sha():
