@@ -627,6 +627,7 @@ def test_large_buffers_are_recycled_between_contexts_with_identical_results():
     asks (ctx.hip): the second context must not see what the first left in them."""
     from sitator_amd import synth, _lib
     host = synth.config_host("C2")
+    _lib.release_cached_memory()                 # whatever earlier tests left idle: this test looks at addresses
     F = 6000                                     # 576 atoms x 24 B x 6000 frames = 83 MB of trajectory
     ctx, *_ = _setup(host, 64, F, seed=91)
     assert ctx.fill(check_for_zeros=False)[0] == 0
