@@ -602,6 +602,7 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
         int j = i;
         while (merge && i > 0 && j + 1 < nch && (j + 1) * cf < F && issued.load(std::memory_order_acquire) > j + 1 &&
                hipEventQuery(ev[(size_t)(j + 1)]) == hipSuccess) j++;
+        if (failed.load()) { c->msg = "upload of a trajectory chunk failed"; return finish(SIT_ERR_HIP); }   // an event never recorded reads as complete
         const i64 lo = i * cf, hi = std::min<i64>(F, (j + 1) * cf);
         if (dbgpipe) fprintf(stderr, "  main has chunks %d..%d at %.1f ms\n", i, j, since());
         if (i == 0) {

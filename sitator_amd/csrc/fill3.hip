@@ -802,7 +802,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
 
     // ---- survivor slots / task-table size: measured once per kind of fill ----
     if (rcap_auto && tcap_auto && h.debug_stop == 0 && f3_env_int("SITATOR_FILL_AUTOTUNE", 1) && (f_hi - f_lo) * M >= (1 << 18)) {
-        const i64 key[8] = {S, M, c->D, vp, have_tight ? c->W_tight : c->W, (i64)nw * 64 + fpb, dynmap ? 1 : 0, (i64)(c->tight_mean_candidates * 1024)};
+        const i64 key[8] = {S, M, c->D, vp, have_tight ? c->W_tight : c->W, (i64)nw * 64 + fpb, dynmap ? 1 : 0, (i64)(c->tight_mean_candidates * 4.0 + 0.5)};   // candidates per ion in quarters: trajectories of one system share a key
         bool found = false;
         {
             std::lock_guard<std::mutex> lock(g_f3_mutex);
