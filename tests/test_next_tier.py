@@ -209,3 +209,49 @@ def test_predict_reports_zero_rows_like_the_reference():
     assert np.array_equal(np.nonzero(lab == -1)[0], [7, 19, 33])
     with pytest.raises(ValueError, match="Data 7 is all zeros!"):
         clf.predict(X, threshold=0.0, ignore_zeros=False)
+
+
+def test_site_network_data_contract_survives_copy_and_pickle():
+    """The SiteNetwork surface the path and the next-tier operators use (sitator/SiteNetwork.py:167-391): read-only
+    views, named per-site / per-edge arrays readable as attributes, the reference's error types, everything derived
+    from a set of centres dropped when new centres come in; identical after copy(), deepcopy and a pickle round trip."""
+    import copy
+    import pickle
+    from sitator_amd import SiteNetwork, Structure
+    rng = np.random.default_rng(5)
+    static = np.array([1, 1, 1, 1, 0, 0], dtype=bool)
+    sn = SiteNetwork(Structure(rng.random((6, 3)), np.eye(3) * 5), static, ~static)
+    assert (sn.n_static, sn.n_mobile, sn.n_total, len(sn), sn.n_sites) == (4, 2, 6, 0, 0)
+    sn.centers = rng.random((3, 3))
+    sn.vertices = [[0, 1], [1, 2], [2, 3]]
+    sn.site_types = np.array([1, 2, 1])
+    sn.add_site_attribute("occupancy", np.arange(3.0))
+    sn.add_edge_attribute("p_ij", np.eye(3))
+    with pytest.raises(ValueError):
+        sn.centers.__setitem__((0, 0), 1.0)                      # read-only view
+    for twin in (sn.copy(), copy.deepcopy(sn), pickle.loads(pickle.dumps(sn))):
+        assert np.array_equal(twin.centers, sn.centers) and twin.vertices == sn.vertices
+        assert np.array_equal(twin.site_types, [1, 2, 1]) and twin.n_types == 2
+        assert twin.site_attributes == ["occupancy"] and twin.edge_attributes == ["p_ij"]
+        assert np.array_equal(twin.occupancy, sn.occupancy) and np.array_equal(twin.p_ij, sn.p_ij)
+        assert twin.number_of_vertices == [2, 2, 2]
+    with pytest.raises(AttributeError):
+        sn.no_such_attribute
+    with pytest.raises(KeyError):
+        sn.add_site_attribute("occupancy", np.arange(3.0))       # taken
+    with pytest.raises(KeyError):
+        sn.add_site_attribute("centers", np.arange(3.0))         # would shadow a property
+    with pytest.raises(ValueError):
+        sn.add_site_attribute("1bad", np.arange(3.0))
+    with pytest.raises(ValueError):
+        sn.add_site_attribute("short", np.arange(2.0))
+    with pytest.raises(ValueError):
+        sn.add_edge_attribute("square", np.zeros((3, 2)))
+    with pytest.raises(ValueError):
+        sn.vertices = [[0]]
+    sn.remove_attribute("occupancy")
+    assert not sn.has_attribute("occupancy") and sn.has_attribute("p_ij")
+    with pytest.raises(AttributeError):
+        sn.remove_attribute("occupancy")
+    sn.centers = rng.random((2, 3))
+    assert sn.vertices is None and sn.site_types is None and sn.site_attributes == [] and sn.edge_attributes == []
