@@ -400,7 +400,6 @@ static int run_predict(sit_ctx *c, double threshold)
     StageTimer t(c, T_PREDICT);
     bool counted = false;
     if (c->max_col <= PRED_MAXCOL) {
-        HIP_TRY(c, hipMemsetAsync(wcount, 0, 4, c->stream));
         const size_t csc = (size_t)c->csc_nnz * 12 + (size_t)(c->D + 1) * 4 + 16, lds = csc + (size_t)c->K * 4;
         const char *pl = getenv("SITATOR_PREDICT_LDS");                 // "0": keep the centres in global memory (A/B, tests)
         const bool no_lds = pl && pl[0] == '0';
@@ -413,11 +412,11 @@ static int run_predict(sit_ctx *c, double threshold)
         const unsigned gw = (unsigned)std::min<i64>((c->N + PRED_BLOCK - 1) / PRED_BLOCK, 16384);
         const bool narrow_lds = lds <= 52 * 1024 && !no_lds, wide_lds = csc <= 150 * 1024 && !no_lds;
         u64 *cnt = narrow_lds ? (u64 *)c->d_counts : nullptr;            // the LDS kernel counts the labels on the way
+        if ((rc = reset_predict_words(c, narrow_lds, wcount))) return rc;
         if (narrow_lds) {
             // three or four workgroups of 512 threads per CU
             const i64 blocks = (c->N + PRED_LDS_BLOCK - 1) / PRED_LDS_BLOCK;
             const unsigned g2 = (unsigned)std::min<i64>(blocks, (i64)ncu * (lds <= 36 * 1024 ? 4 : 3));
-            HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
             HIP_TRY(c, lds_limit((const void *)k_predict_rows_lds, lds, c->device));
             k_predict_rows_lds<<<dim3(g2), dim3(PRED_LDS_BLOCK), lds, c->stream>>>(a, wlist, wcount, (int)c->csc_nnz, (int)c->K, (u64 *)c->d_counts);
             counted = true;

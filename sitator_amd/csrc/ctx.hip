@@ -97,6 +97,37 @@ void sit_dfree(sit_ctx *c, void *p)
     (void)hipFree(p);
 }
 
+// The per-call resets as ONE launch each (a hipMemsetAsync of an unaligned few bytes is two fill kernels, and every
+// launch costs ~6 us of an otherwise 1.4 ms step): error key = all ones, the sixteen counters behind it = 0 ...
+__global__ void k_reset_fill_words(u64 *err_block)
+{
+    const int t = threadIdx.x;
+    if (t == 0) err_block[0] = ~0ull;
+    else if (t <= 16) err_block[t] = 0ull;
+}
+// ... and for the assignment pass: the label counts and the length of the wide-row list
+__global__ void k_reset_predict_words(u64 *counts, i64 K, unsigned *wcount)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < K) counts[i] = 0ull;
+    if (i == 0 && wcount) *wcount = 0u;
+}
+
+int reset_fill_words(sit_ctx *c)
+{
+    k_reset_fill_words<<<dim3(1), dim3(64), 0, c->stream>>>(c->d_err);
+    HIP_TRY(c, hipGetLastError());
+    return SIT_OK;
+}
+
+int reset_predict_words(sit_ctx *c, bool counts, unsigned *wcount)
+{
+    const i64 K = counts ? c->K : 0;
+    k_reset_predict_words<<<dim3((unsigned)((K + 255) / 256 > 0 ? (K + 255) / 256 : 1)), dim3(256), 0, c->stream>>>((u64 *)c->d_counts, K, wcount);
+    HIP_TRY(c, hipGetLastError());
+    return SIT_OK;
+}
+
 extern "C" void sit_release_cached_memory(void)
 {
     std::lock_guard<std::mutex> lock(g_pool_mu);

@@ -361,8 +361,7 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
             c->assign_N = N;
         }
         if (v2 && c->F > 0 && (rc = ensure_tight_table(c))) return rc;
-        HIP_TRY(c, hipMemsetAsync(c->d_err, 0xFF, sizeof(u64), c->stream));
-        HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream));
+        if ((rc = reset_fill_words(c))) return rc;
         if (c->F == 0) {
             if (n_all_zero) *n_all_zero = 0;
             c->rows_valid = store; c->assign_valid = assign;
