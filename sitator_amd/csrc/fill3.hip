@@ -284,7 +284,20 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     // ---- phase 1a: copy this workgroup's atoms into LDS, eight independent loads per thread in flight ----
     {
         const double *fbase = h.frames + f0 * h.A * 3;
-        if (h.contig == 2) {
+        if (h.contig == 3) {
+            // the same run as 16-byte pieces (the frame group starts on a 16-byte boundary and holds an even number
+            // of doubles): half the loads, address computations and LDS stores
+            const int n2 = (nf * SM * 3) >> 1;
+            const double2 *src2 = (const double2 *)fbase;
+            double2 *dst2 = (double2 *)xyz;
+            for (int e0 = tid; e0 < n2; e0 += 4 * NT) {
+                double2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int e = e0 + u * NT; v[u] = e < n2 ? src2[e] : make_double2(0.0, 0.0); }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int e = e0 + u * NT; if (e < n2) dst2[e] = v[u]; }
+            }
+        } else if (h.contig == 2) {
             const int n = nf * SM * 3;
             for (int e0 = tid; e0 < n; e0 += 8 * NT) {
                 double v[8];
@@ -798,6 +811,13 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     int contig = c->idx_contig ? 1 : 0;
     if (contig && c->idx_s0 == 0 && c->idx_m0 == S && c->A == S + M) contig = 2;
     { const int forced = f3_env_int("SITATOR_FILL_CONTIG", -1); if (forced >= 0 && forced < contig) contig = forced; }
+    // 16-byte copies when every frame group of the launch starts on a 16-byte boundary and is an even number of doubles
+    {
+        const bool even_frame = ((S + M) * 3) % 2 == 0;
+        const bool even_groups = fpb % 2 == 0 && f_lo % 2 == 0 && (f_hi - f_lo) % fpb == 0;
+        if (contig == 2 && f3_env_int("SITATOR_FILL_WIDE_COPY", 1) && ((uintptr_t)c->d_frames % 16) == 0 && (even_frame || even_groups))
+            contig = 3;
+    }
     h.contig = contig;
 
     // ---- survivor slots / task-table size: measured once per kind of fill ----
@@ -818,7 +838,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
             hipEvent_t e0, e1;
             HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
             Fill3Head ht = h;
-            ht.F = std::min<i64>(f_hi, f_lo + (i64)2048 * fpb);               // the leading frames: ~1.6 rounds of workgroups
+            ht.F = std::min<i64>(f_hi, f_lo + (i64)4096 * fpb);               // the leading frames: ~3 rounds of workgroups
             const unsigned gt = (unsigned)((ht.F - f_lo + fpb - 1) / fpb);
             float best = 1e30f;
             int br = rcap, bt = tcap;
@@ -832,7 +852,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
                 if (ldq > 160 * 1024 - 512) continue;
                 ht.rcap = cand[q][0]; ht.tcap = cand[q][1];
                 float tq = 1e30f;
-                for (int rep = 0; rep < 3; rep++) {                            // the first launch of a shape warms it up
+                for (int rep = 0; rep < 5; rep++) {                            // the first launch of a shape warms it up; best of four
                     HIP_TRY(c, hipEventRecord(e0, c->stream));
                     HIP_TRY(c, f3_dispatch(c, ht, full, gt, ldq, nw, vp, diag, dynmap));
                     HIP_TRY(c, hipEventRecord(e1, c->stream));
@@ -841,7 +861,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
                     HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
                     if (rep > 0 && ms < tq) tq = ms;
                 }
-                if (tq < best * (q == 0 ? 1.0f : 0.97f)) { best = tq; br = cand[q][0]; bt = cand[q][1]; }   // the default wins ties
+                if (tq < best * (q == 0 ? 1.0f : 0.96f)) { best = tq; br = cand[q][0]; bt = cand[q][1]; }   // the default wins ties (a 60 us trial has jitter)
             }
             tcap = keep_tcap;
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
