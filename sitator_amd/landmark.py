@@ -203,7 +203,7 @@ class LandmarkAnalysis(object):
         n_sites = len(cluster_counts)
         if n_sites < (sn.n_mobile / self.max_mobile_per_site):
             raise errors.InsufficientSitesError(verb="Landmark analysis", n_sites=n_sites, n_mobile=sn.n_mobile)
-        logger.info("    Identified %i sites with assignment counts %s" % (n_sites, cluster_counts))
+        logger.info("    Identified %i sites with assignment counts %s", n_sites, cluster_counts)     # formatted only if shown
 
         # Output network: site centres (:276-299)
         out_sn = sn.copy()
