@@ -7,7 +7,10 @@ from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth
 
 nseeds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 bad = 0
-for cfg, F in (("C1b", 20000), ("C2", 9000), ("C5", 8300), ("C3", 8200), ("C4", 8200), ("C2", 33000)):
+cases = (("C1b", 20000), ("C2", 9000), ("C5", 8300), ("C3", 8200), ("C4", 8200), ("C2", 33000))
+if os.environ.get("SOAK_ONLY"):
+    cases = tuple(c for c in cases if "%s:%d" % c == os.environ["SOAK_ONLY"])
+for cfg, F in cases:
     host = synth.config_host(cfg)
     for seed in range(nseeds):
         gen = synth.TrajectoryGenerator(host, synth.CONFIG_MOBILE[cfg], seed=1000 + 17 * seed, p_hop=1 / (20.0 + 60 * seed))
@@ -15,7 +18,7 @@ for cfg, F in (("C1b", 20000), ("C2", 9000), ("C5", 8300), ("C3", 8200), ("C4", 
         sn = SiteNetwork(Structure(gen.reference_positions(), host.cell), gen.static_mask, gen.mobile_mask)
         sn.centers = host.centers; sn.vertices = host.vertices
         res = {}
-        for mode in ("1", "0"):
+        for mode in (("0", "1") if os.environ.get("SOAK_ORDER") == "01" else ("1", "0")):   # the first run of a new trajectory pays for it
             os.environ["SITATOR_PIPELINE"] = mode
             la = LandmarkAnalysis(verbose=False, check_for_zero_landmarks=False, max_mobile_per_site=64)
             t0 = time.time(); st = la.run(sn, frames); dt = time.time() - t0
