@@ -266,5 +266,6 @@ int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32
     sit_dfree(c, cursor);
     *W = hs[0] > 0 ? hs[0] : 1;
     *mean = (double)total / (double)nb;
+    c->table_gen++;
     return SIT_OK;
 }

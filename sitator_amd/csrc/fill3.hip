@@ -1,30 +1,32 @@
 // Landmark-vector fill, third generation (the one `sit_fill` launches by default for landmarks of up to 8 vertices).
 //
-// Same result as fill2.hip / fill.hip (landmark/helpers.pyx:12-212 in the reference's operation order, FP64, no
-// contraction of the reference's expressions); what changes is where the instructions and the waiting go.  The second
-// generation was VALU-issue-bound at ~100 wave-instructions per ion, less than half of them arithmetic of the
-// reference, and every wave kept private task lists:
-//   * a workgroup parks one frame (of a 64-ion system) in LDS; each wave then owns a window of its ions (a lane each:
-//     bin, candidate list, offset vector) and writes a flat table of (ion, landmark) tasks.  A first pass tests
-//     every task's CRITICAL vertex with one lane (the vertex with the least room in the ion's bin, from the table
-//     builder) and compacts the table in place; the remaining tasks take (task, vertex) LANES - eight lanes per
-//     task, one squared distance each, compared against (rz * vcd)^2 - so a pass has no per-lane loops;
-//   * the tasks whose eight lanes all pass are compacted with two ballots into the wave's region of survivors
-//     (their squared distances, 64 bytes each); the logistic factors are then evaluated one lane per (survivor,
-//     vertex) IN PLACE, multiplied in vertex order by one lane per survivor, and that lane writes the row entry
-//     directly (its position in the row is a population count over the wave's non-zero mask);
-//   * nothing in this is shared between waves but the read-only frame: no workgroup barrier after phase 1;
-//   * sqrt, the two divisions and exp went through the general-purpose library sequences (range scaling, special
-//     cases, a degree-11 polynomial).  The operands here have known ranges, so: sqrt = the library's own
-//     Newton sequence without the range scaling (bit-identical for normal operands), dist/vcd = multiplication
-//     by the correctly rounded reciprocal + one FMA correction (Markstein; bit-identical to IEEE division in 4e8
-//     random trials), 1/(1+e) = the library's sequence without scaling, exp = 128-entry hi/lo table + degree-5
-//     polynomial (max error 0.512 ulp, agrees with glibc in 99.75 % of arguments - closer to the reference's libm
-//     than the device library's exp);
-//   * the frames are copied into LDS as straight runs of doubles (eight loads per thread in flight) and wrapped in
-//     place; the static-lattice check first tries the plain displacement, which bounds the periodic one.
-// LDS per workgroup is ~32 KB at 64 ions and 512 statics (five workgroups = 20 waves per CU).
-// Kept from fill2: tight/loose pruning tables, error keys, slot-major sparse rows, exactness rules.
+// Same result as fill2.hip (landmark/helpers.pyx:12-212: the same distances in the reference's operation order, FP64,
+// no contraction of the reference's expressions, the same zero pattern); what changes is where the instructions go.
+// On gfx950 every vector instruction of this kernel costs 4-5 cycles of a SIMD whatever it computes (an FP64 multiply
+// 5.0, a 32-bit shift-add 4.3, a compare 4.3; only plain 32-bit add / and / mov are cheaper, `scratch/issue_cost.hip`)
+// and scalar instructions are nearly free, so the design rule is: few vector instructions, full lanes, masks and loop
+// control on the scalar unit.
+//   * a workgroup parks one frame (of a 64-ion system) in LDS, wrapped in place; the thread that wraps a mobile ion
+//     also looks up the ion's bin (64 busy lanes; an owner stage per wave window had 16);
+//   * each wave then owns a window of the ions.  The candidate landmarks of the window form one flat task index
+//     space (a prefix sum over the window's list lengths); a lane per TASK finds its ion with a maximum scan over
+//     start markers, loads its list entry - the byte offset of the landmark's CRITICAL vertex record (the vertex with
+//     the least room in the ion's bin, from the table builder) - and tests that vertex; what passes is compacted into
+//     the wave's task table with a ballot;
+//   * the remaining tasks take (task, vertex) LANES: eight lanes per task, one squared distance each, compared with
+//     the EXACT squared-distance threshold of (landmark, vertex): the largest double d2 for which the reference's
+//     RN(RN(sqrt(d2)) / vcd) > cutoff is false, found on the host by bisection over the doubles (sqrt and the division
+//     are monotone, so the comparison d2 > T2 is the reference's decision bit for bit).  Which tasks keep all their
+//     lanes is worked out on the scalar unit from the ballot (shift-or folds, inverse ballot as the execution mask);
+//   * survivors go to the wave's region (their squared distances, 64 bytes each); the logistic factors are evaluated
+//     one lane per (survivor, vertex) IN PLACE - the zero pattern is settled, so sqrt / division / exp / reciprocal
+//     only need to be accurate: Newton sequences without their final correctly-rounding step, a 128-entry exp table
+//     (values within ~1e-14 relative of the reference, the bar is 1e-6) - multiplied in vertex order by one lane per
+//     survivor, and that lane writes the row entry directly (its position in the row is a population count over the
+//     wave's non-zero mask);
+//   * nothing in phase 2 is shared between waves but the read-only frame: no workgroup barrier after phase 1.
+// LDS per workgroup is ~30 KB at 64 ions and 512 statics (five workgroups = 20 waves per CU).
+// Kept from fill2: tight/loose pruning tables, error keys, slot-major sparse rows.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -37,22 +39,25 @@
 
 #define F3_EXPN 128
 
+// read with scalar loads from a device copy (the kernel is short of scalar registers: arguments parked there are
+// loaded where they are used)
 struct Fill3Args {
-    const uint4 *vh;                  // [D,Vp] {24 * static id (byte offset of the vertex in a frame), static id, squared
-                                      //         screening bound as two words (+inf on padding)}
-    const double2 *vr;                // [D,Vp] {vcd, 1/vcd}
+    const uint4 *vh;                  // [D,Vp] {24 * static id (byte offset of the vertex in a frame), static id, exact
+                                      //         squared-distance threshold as two words (+inf on padding)}
+    const double *vr;                 // [D,Vp] 1 / vcd (-inf on padding: the factor of a padded vertex is exactly 1)
     const unsigned char *nvtab;       // [D]
-    const i32 *t_off, *t_list;        // tight table
-    const i32 *l_off, *l_list;        // loose table (static_movement_threshold)
-    const unsigned char *t_crit, *l_crit;   // critical vertex of every list entry
+    const unsigned *pack;             // list entries of the primary table, then of the fallback table:
+                                      // landmark << (LG + 4) | critical vertex << 4 = byte offset of that record in vh
+    const i32 *p_off, *f_off;         // bin offsets of the primary (tight) and the fallback (loose) table
     const i32 *lattice_map;           // [F,S] or null
     i32 *row_nnz, *row_idx;
     double *row_val;
     i64 N;
     int D, W;
-    int tG0, tG1, tG2, lG0, lG1, lG2;
+    int pG0, pG1, pG2, fG0, fG1, fG2;
+    unsigned f_base;                  // first fallback entry in pack
     int check_zeros;
-    double midpoint, steepness, rz;
+    double midpoint, steepness;
 };
 
 struct Fill3Head {
@@ -61,62 +66,75 @@ struct Fill3Head {
     const i32 *static_idx, *mobile_idx;
     const double *ref_static;
     const double *frame_dmax;
-    const double2 *exptab;
+    const double *exptab;
     u64 *err, *scal;
     i64 F, A, frame0, fbeg;           // the launch covers frames [fbeg, F)
-    int S, M, fpb, contig, debug_stop, rcap, iw, force_loose, s0, m0, tcap;
+    int S, M, fpb, contig, debug_stop, rcap, iw, has_fallback, s0, m0, tt, mcap;
     double delta2, thr2_lo, thr2_hi, static_thr, safe2;
 };
 typedef const Fill3Args __attribute__((address_space(4))) *Fill3ArgsPtr;
 
-// ---- arithmetic with known operand ranges -------------------------------------------------------------------------
+// LDS of a workgroup, in bytes from the start of the dynamic allocation
+struct F3Layout {
+    int fmax, ioninfo, etab, wave0;                      // after xyz[fpb][S + M][3] at offset 0
+    int o_ionrec, o_ttab, o_sv, o_nzc, o_mark, wbytes;   // inside a wave's region (sd2 at its offset 0)
+    int total;
+};
+// rcap survivor slots (multiple of 8, <= 64), windows of iw ions (multiple of 4, <= 64), a task table of tt entries
+// (multiple of 64), mcap marker bytes (multiple of 64, >= the candidates of a window)
+__host__ __device__ inline F3Layout f3_layout(int fpb, int SM, int M, int nw, int vp, int rcap, int iw, int tt, int mcap, int fpb1)
+{
+    F3Layout L;
+    int o = fpb * SM * 24;
+    L.fmax = o; o += fpb * 8;
+    o = (o + 15) & ~15;
+    L.ioninfo = o; o += fpb * M * 16;                    // {first entry, entries, fallback bin, -} per ion
+    L.etab = o; o += F3_EXPN * 8;
+    L.wave0 = o;
+    int w = rcap * vp * 8;                               // sd2: squared distances, then logistic factors, of the survivors
+    L.o_ionrec = w; w += iw * (fpb1 ? 4 : 16);           // per ion of the window: first entry - first task (and LDS offsets)
+    w = (w + 7) & ~7;
+    L.o_ttab = w; w += tt * 4;                           // landmark << (LG + 4) | ion of the window
+    L.o_sv = w; w += (rcap + 16) * 4;                    // the task of every survivor (a partly filled pass reads on)
+    L.o_nzc = w; w += iw * 4;                            // entries written per ion
+    L.o_mark = w; w += mcap;                             // the ion that starts at a candidate task (0 elsewhere)
+    L.wbytes = (w + 15) & ~15;
+    L.total = L.wave0 + nw * L.wbytes;
+    return L;
+}
 
-// sqrt for x in [1e-300, 1e300]: the device library's sequence (v_rsq_f64 seed, two coupled Newton steps, final
-// correction with the exact residual) without its range scaling; correctly rounded in the library's sense.
+// ---- arithmetic -----------------------------------------------------------------------------------------------------
+
+// sqrt for x in [1e-300, 1e300]: v_rsq_f64 seed (2^-23), two coupled Newton steps (error ~2^-89 before rounding); the
+// device library's final correctly-rounding step is left out (the value feeds a product that needs 1e-6)
 __device__ __forceinline__ double sqrt_nr(double x)
 {
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     const double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g);
-    double d = __builtin_fma(-g, g, x);
     h = __builtin_fma(h, r, h);
-    g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
+    const double d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
 }
 
-// 1 / b for b in [1, 1e300): the library's division sequence for a numerator of 1 without operand scaling
+// 1 / b for b in [1, 1e300): v_rcp_f64 seed and two Newton steps
 __device__ __forceinline__ double rcp_nr(double b)
 {
     double y = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, y, 1.0);
     y = __builtin_fma(y, e, y);
     e = __builtin_fma(-b, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    const double r = __builtin_fma(-b, y, 1.0);
-    return __builtin_fma(r, y, y);
+    return __builtin_fma(y, e, y);
 }
 
-// a / b given rb = RN(1 / b): q = RN(a * rb), exact residual, one correction (Markstein)
-__device__ __forceinline__ double div_rb(double a, double b, double rb)
-{
-    const double q = a * rb;
-    const double e = __builtin_fma(-q, b, a);
-    return __builtin_fma(e, rb, q);
-}
-
-// exp(x) for x <= ~10 (helpers.pyx:205: x = steepness * (t - midpoint) <= log(1/1e-4 - 1) by the cut-off):
-// x = (128 k + j) ln2/128 + r, exp = 2^k * T[j] * (1 + expm1(r)), T as hi + lo.
 // The constants of exp_tab / vertex_factor, held in VECTOR registers: the kernel is short of scalar registers (every
-// constant the compiler parks there pushes another value into a spill lane and costs VALU instructions to move),
-// and has vector registers to spare at five waves per SIMD (96 in allocation granules of 8: the kernel uses 92; three
-// more constants took it to 98 -> 104 -> four waves, and C2 from 1.16 to 1.25 ms).
+// constant the compiler parks there pushes another value into a spill lane and costs VALU instructions to move).
 struct ExpK {
-    double log2e_128, magic, ln2_128_hi, ln2_128_lo, c5, c4, c3, mid, steep, rz;
+    double log2e_128, magic, ln2_128_hi, ln2_128_lo, c5, c4, c3, mid, steep;
 };
 __device__ __forceinline__ double in_vgpr(double x) { asm volatile("" : "+v"(x)); return x; }
-__device__ __forceinline__ ExpK expk_make(double mid, double steep, double rz)
+__device__ __forceinline__ ExpK expk_make(double mid, double steep)
 {
     ExpK k;
     k.log2e_128 = in_vgpr(0x1.71547652b82fep+7);
@@ -124,11 +142,13 @@ __device__ __forceinline__ ExpK expk_make(double mid, double steep, double rz)
     k.ln2_128_hi = in_vgpr(0x1.62e42fefp-8);
     k.ln2_128_lo = in_vgpr(0x1.473de6af278edp-41);
     k.c5 = in_vgpr(1.0 / 120); k.c4 = in_vgpr(1.0 / 24); k.c3 = in_vgpr(1.0 / 6);
-    k.mid = in_vgpr(mid); k.steep = in_vgpr(steep); k.rz = in_vgpr(rz);
+    k.mid = in_vgpr(mid); k.steep = in_vgpr(steep);
     return k;
 }
 
-__device__ __forceinline__ double exp_tab(double x, const double2 *tab, const ExpK &k)
+// exp(x) for x <= ~10 (helpers.pyx:205: x = steepness * (t - midpoint) <= log(1/1e-4 - 1) by the cut-off):
+// x = (128 k + j) ln2/128 + r, exp = 2^k * T[j] * (1 + expm1(r))
+__device__ __forceinline__ double exp_tab(double x, const double *tab, const ExpK &k)
 {
     x = __builtin_fmax(x, -700.0);                     // exp(-700) ~ 1e-304: 1 + e == 1 all the same, no denormals
     const double u = __builtin_fma(x, k.log2e_128, k.magic);
@@ -141,23 +161,20 @@ __device__ __forceinline__ double exp_tab(double x, const double2 *tab, const Ex
     q = __builtin_fma(r, q, 0.5);
     q = __builtin_fma(r, q, 1.0);
     const double p = r * q;
-    const double2 t = tab[ni & (F3_EXPN - 1)];
-    const double res = t.x + __builtin_fma(t.x, p, t.y);
-    return __builtin_ldexp(res, ni >> 7);
+    const double t = tab[ni & (F3_EXPN - 1)];
+    return __builtin_ldexp(__builtin_fma(t, p, t), ni >> 7);
 }
 
-// one logistic factor of helpers.pyx:186-205 from the squared distance; 0.0 encodes "beyond the cut-off"
-__device__ __forceinline__ double vertex_factor(double d2, double vcd, double rvcd, const ExpK &k, const double2 *tab)
+// one logistic factor of helpers.pyx:186-205 from the squared distance of a vertex that is inside the cut-off
+// (rvcd = -inf on a padded vertex: t = -inf, e = exp(-700), the factor exactly 1)
+__device__ __forceinline__ double vertex_factor(double d2, double rvcd, const ExpK &k, const double *tab)
 {
     d2 = __builtin_fmax(d2, 1e-300);                   // an ion exactly on a static atom: t - midpoint is the same
-    const double dist = sqrt_nr(d2);
-    const double tt = div_rb(dist, vcd, rvcd);
+    const double tt = sqrt_nr(d2) * rvcd;
     const double e = exp_tab(k.steep * (tt - k.mid), tab, k);
-    const double f = rcp_nr(1.0 + e);
-    return tt > k.rz ? 0.0 : f;
+    return rcp_nr(1.0 + e);
 }
 
-__device__ __forceinline__ double root_chain(double acc, int nv);
 __device__ __attribute__((noinline)) double pow_generic3(double acc, int nv) { return pow(acc, 1.0 / nv); }
 // pow(acc, 1.0 / nv) of helpers.pyx:212 for acc in (0, 1]
 __device__ __forceinline__ double root_chain(double acc, int nv)
@@ -184,6 +201,34 @@ __device__ __forceinline__ int wave_max_scan(int x)
     y = F3_DPP(0x143, 0xc); x = x > y ? x : y;        // row_bcast:31 into rows 2 and 3
 #undef F3_DPP
     return x;
+}
+
+// inclusive sum scan over the 64 lanes
+__device__ __forceinline__ int wave_add_scan(int x)
+{
+#define F3_DPP(ctrl, rmask) __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false)
+    x += F3_DPP(0x111, 0xf);
+    x += F3_DPP(0x112, 0xf);
+    x += F3_DPP(0x114, 0xf);
+    x += F3_DPP(0x118, 0xf);
+    x += F3_DPP(0x142, 0xa);
+    x += F3_DPP(0x143, 0xc);
+#undef F3_DPP
+    return x;
+}
+
+// set bits of a wave-uniform mask below this lane, plus a uniform base
+__device__ __forceinline__ int mask_rank(unsigned long long m, int base)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base));
+}
+
+// the lanes of a wave-uniform mask as the branch condition (no vector instruction)
+#define F3_LANES(m) __builtin_amdgcn_inverse_ballot_w64(m)
+
+__device__ __forceinline__ unsigned long long first_lanes(int n)      // lanes [0, n), n >= 0
+{
+    return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
 }
 
 template <int CELL>
@@ -217,70 +262,50 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
     return (b0 * G1 + b1) * G2 + b2;
 }
 
-// inclusive sum scan over the 64 lanes
-__device__ __forceinline__ int wave_add_scan(int x)
-{
-#define F3_DPP(ctrl, rmask) __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false)
-    x += F3_DPP(0x111, 0xf);
-    x += F3_DPP(0x112, 0xf);
-    x += F3_DPP(0x114, 0xf);
-    x += F3_DPP(0x118, 0xf);
-    x += F3_DPP(0x142, 0xa);
-    x += F3_DPP(0x143, 0xc);
-#undef F3_DPP
-    return x;
-}
-
-#define F3_TCAP 128        // (ion, landmark) tasks of a wave batch: the default; bases with long candidate lists take more
-
-// LDS of a wave, in bytes: `rcap` survivor slots (multiple of 8, <= 64), windows of `iw` ions (multiple of 4, <= 64)
-__host__ __device__ inline int f3_wave_bytes(int rcap, int vp, int iw, int tcap)
-{
-    return rcap * vp * 8         // sd2: squared distances, then logistic factors, of the survivors
-         + tcap * 4              // ttab: landmark | critical vertex << 22 | ion << 26 per task
-         + rcap * 4              // sv_k: the task of every survivor
-         + iw * 16               // info: per ion of the window {offset vector, statics of its frame (byte offsets), frame}
-         + iw * 4;               // entries written per ion
-}
-
 // LG: log2 of the padded vertices per landmark (2 or 3).  NW: waves per workgroup.  DYN: dynamic lattice mapping
-// (static ids go through the frame's lattice map; the static-lattice check was made by k_lattice_map).
+// (static ids go through the frame's lattice map; the static-lattice check was made by k_lattice_map).  FPB1: one frame
+// per workgroup (the LDS offsets of an ion follow from its number; otherwise they are looked up).
 // h.contig: 2 = the workgroup's atoms are one run of doubles in memory (statics then mobiles, nothing else),
-// 1 = static_idx / mobile_idx are two consecutive ranges, 0 = arbitrary index lists.
-template <int CELL, int LG, int NW, int DYN, int DBG>
+// 3 = the same in 16-byte pieces, 1 = static_idx / mobile_idx are two consecutive ranges, 0 = arbitrary index lists.
+template <int CELL, int LG, int NW, int DYN, int FPB1, int DBG>
 __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr full)
 {
     constexpr int VP = 1 << LG;
     constexpr int NT = NW * 64;
     constexpr int TPP = 64 >> LG;                               // tasks per pass of 64 lanes
+    constexpr int KSH = LG + 4;                                 // task = landmark << KSH | ion of the window
+    constexpr unsigned KMASK = ~((1u << KSH) - 1u);
+    constexpr unsigned long long LEADS = LG == 3 ? 0x0101010101010101ull : 0x1111111111111111ull;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = h.S, M = h.M, SM = S + M;
-    const int fpb = h.fpb;
+    const int fpb = FPB1 ? 1 : h.fpb;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rcap = h.rcap;
+    const int rcap = h.rcap, IW = h.iw, TT = h.tt;
     const int dbg = DBG ? h.debug_stop : 0;                     // the ablation stops and the census live in the DBG = 1 build
-    // layout: [per-wave buffers] [exp table] [atoms: per frame statics then mobiles] [frame flags]
-    const int IW = h.iw;
-    const int TCAP = h.tcap;
-    char *lp = smem + wave * f3_wave_bytes(rcap, VP, IW, TCAP);
-    double *sd2 = (double *)lp; lp += rcap * VP * 8;
-    unsigned *ttab = (unsigned *)lp; lp += TCAP * 4;
-    unsigned *sv_k = (unsigned *)lp; lp += rcap * 4;
-    uint4 *info = (uint4 *)lp; lp += IW * 16;
-    unsigned *nzc = (unsigned *)lp;
-    double2 *etab = (double2 *)(smem + NW * f3_wave_bytes(rcap, VP, IW, TCAP));
-    double *xyz = (double *)(etab + F3_EXPN);                   // [fpb][S + M][3]; mobiles become centroid - ion
-    u64 *fmax = (u64 *)(xyz + 3 * fpb * SM);                    // [fpb]
+    const F3Layout L = f3_layout(fpb, SM, M, NW, VP, rcap, IW, TT, h.mcap, FPB1);
+    double *xyz = (double *)smem;                               // [fpb][S + M][3]; mobiles become centroid - ion
+    u64 *fmax = (u64 *)(smem + L.fmax);                         // [fpb]
+    uint4 *ioninfo = (uint4 *)(smem + L.ioninfo);               // [fpb * M]
+    double *etab = (double *)(smem + L.etab);
+    char *wp = smem + L.wave0 + wave * L.wbytes;
+    double *sd2 = (double *)wp;
+    unsigned *ionrec = (unsigned *)(wp + L.o_ionrec);
+    unsigned *ttab = (unsigned *)(wp + L.o_ttab);
+    unsigned *sv = (unsigned *)(wp + L.o_sv);
+    unsigned *nzc = (unsigned *)(wp + L.o_nzc);
+    unsigned char *mark = (unsigned char *)(wp + L.o_mark);
     const Pbc &P = h.P;
     const i64 f0 = h.fbeg + (i64)blockIdx.x * fpb;
-    const int nf = (int)((h.F - f0) < fpb ? (h.F - f0) : fpb);
+    const int nf = FPB1 ? 1 : (int)((h.F - f0) < fpb ? (h.F - f0) : fpb);
     const u64 errw = (u64)(S + 1 + M);
+    const Fill3Args __attribute__((address_space(4))) &g = *full;
 
     if (tid < fpb) fmax[tid] = 0ull;
-    double2 etv = make_double2(0.0, 0.0);
+    double etv = 0.0;
     if (tid < F3_EXPN) etv = h.exptab[tid];                    // in flight beside the frame loads; parked below
-    for (int q = lane; q < TCAP; q += 64) ttab[q] = 0u;     // stale entries must stay valid (landmark 0, ion 0)
-    if (lane < IW) info[lane] = make_uint4(0u, 0u, 0u, 0u);
+    for (int q = lane; q < TT; q += 64) ttab[q] = 0u;          // stale entries must stay valid tasks (landmark 0, ion 0)
+    for (int q = lane; q < rcap + 16; q += 64) sv[q] = 0u;
+    for (int q = lane; q < (FPB1 ? IW : 4 * IW); q += 64) ionrec[q] = 0u;      // stale tasks look their ion up
     // ---- phase 1a: copy this workgroup's atoms into LDS, eight independent loads per thread in flight ----
     {
         const double *fbase = h.frames + f0 * h.A * 3;
@@ -330,144 +355,149 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     }
     if (tid < F3_EXPN) etab[tid] = etv;
     __syncthreads();
-    // ---- phase 1b: wrap in place (Step 0), static-lattice check (helpers.pyx:57-80) ----
+    // ---- phase 1b: wrap in place (Step 0), static-lattice check (helpers.pyx:57-80); a mobile ion becomes its
+    //      offset vector centroid - ion (helpers.pyx:100) and leaves its candidate list behind ----
     for (int a = tid; a < nf * SM; a += NT) {
         int fl = 0;
-        for (int q = 1; q < nf; q++) fl += a >= q * SM;
+        if (!FPB1) for (int q = 1; q < nf; q++) fl += a >= q * SM;
         const int r = a - fl * SM;
         double *d = xyz + 3 * a;
         double x = d[0], y = d[1], z = d[2];
         wrapc3<CELL>(P, x, y, z);
-        d[0] = x; d[1] = y; d[2] = z;
-        if (!DYN && r < S) {
-            const double *rp = h.ref_static + 3 * r;
-            const double rx = rp[0], ry = rp[1], rz_ = rp[2];
-            // plain displacement: it bounds the periodic one, and while it is shorter than 0.45 cell heights
-            // the shifted atom is inside the cell, where the reference's wrap changes it by rounding only -
-            // no error, no beyond-delta flag (safe2 is below both bounds)
-            const double ex = x - rx, ey = y - ry, ez = z - rz_;
-            const double e2 = (ex * ex + ey * ey) + ez * ez;
-            if (!(e2 <= h.safe2)) {
-                // PBCCalculator.distances(ref, atom) (util/PBCCalculator.pyx:64-103), squared; the sqrt is
-                // taken only inside the rounding band around static_movement_threshold^2
-                double qx = x + (P.cen[0] - rx), qy = y + (P.cen[1] - ry), qz = z + (P.cen[2] - rz_);
-                wrapc3<CELL>(P, qx, qy, qz);
-                const double dx = -qx + P.cen[0], dy = -qy + P.cen[1], dz = -qz + P.cen[2];
-                const double d2 = (dx * dx + dy * dy) + dz * dz;
-                if (d2 > h.delta2) {
-                    atomicOr(&fmax[fl], 1ull);
-                    if (d2 > h.thr2_lo && (d2 > h.thr2_hi || sqrt(d2) > h.static_thr))
-                        atomicMin(h.err, (u64)(h.frame0 + f0 + fl) * errw + (u64)r);
+        if (r < S) {
+            d[0] = x; d[1] = y; d[2] = z;
+            if (!DYN) {
+                const double *rp = h.ref_static + 3 * r;
+                const double rx = rp[0], ry = rp[1], rz_ = rp[2];
+                // plain displacement: it bounds the periodic one, and while it is shorter than 0.45 cell heights
+                // the shifted atom is inside the cell, where the reference's wrap changes it by rounding only -
+                // no error, no beyond-delta flag (safe2 is below both bounds)
+                const double ex = x - rx, ey = y - ry, ez = z - rz_;
+                const double e2 = (ex * ex + ey * ey) + ez * ez;
+                if (!(e2 <= h.safe2)) {
+                    // PBCCalculator.distances(ref, atom) (util/PBCCalculator.pyx:64-103), squared; the sqrt is
+                    // taken only inside the rounding band around static_movement_threshold^2
+                    double qx = x + (P.cen[0] - rx), qy = y + (P.cen[1] - ry), qz = z + (P.cen[2] - rz_);
+                    wrapc3<CELL>(P, qx, qy, qz);
+                    const double dx = -qx + P.cen[0], dy = -qy + P.cen[1], dz = -qz + P.cen[2];
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (d2 > h.delta2) {
+                        atomicOr(&fmax[fl], 1ull);
+                        if (d2 > h.thr2_lo && (d2 > h.thr2_hi || sqrt(d2) > h.static_thr))
+                            atomicMin(h.err, (u64)(h.frame0 + f0 + fl) * errw + (u64)r);
+                    }
                 }
             }
+        } else {
+            d[0] = P.cen[0] - x; d[1] = P.cen[1] - y; d[2] = P.cen[2] - z;
+            // the ion's list in the primary table, and its bin in the fallback table (taken by the frames in which
+            // a static atom moved beyond delta: that is known after the barrier)
+            const int b = bin_of3<CELL>(P, x, y, z, g.pG0, g.pG1, g.pG2);
+            const i32 lo = g.p_off[b], hi = g.p_off[b + 1];
+            unsigned fb = 0u;
+            if (h.has_fallback) fb = (unsigned)bin_of3<CELL>(P, x, y, z, g.fG0, g.fG1, g.fG2);
+            ioninfo[fl * M + (r - S)] = make_uint4((unsigned)lo, (unsigned)(hi - lo), fb, 0u);
         }
     }
     __syncthreads();
-    // fmax[fl] != 0: some static atom of frame fl moved beyond delta -> the frame takes the loose table
-    if (tid < nf) {
-        bool tight = DYN ? (h.frame_dmax[f0 + tid] * h.frame_dmax[f0 + tid] <= h.delta2) : (fmax[tid] == 0ull);
-        if (h.force_loose) tight = false;
+    // fmax[fl] != 0: some static atom of frame fl moved beyond delta -> the frame takes the fallback table
+    if (tid < nf && h.has_fallback) {
+        const bool tight = DYN ? (h.frame_dmax[f0 + tid] * h.frame_dmax[f0 + tid] <= h.delta2) : (fmax[tid] == 0ull);
         if (!tight) atomicAdd(&h.scal[2], 1ull);
     }
     if (dbg == 1) return;
 
-    // phase-2 constants: scalar loads from the device copy of the arguments, issued after the barrier
-    const Fill3Args __attribute__((address_space(4))) &g = *full;
-    const uint4 *vh = g.vh;
-    const double2 *vr = g.vr;
-    const ExpK ek = expk_make(g.midpoint, g.steepness, g.rz);
-    // per-lane constants of the (task, vertex) passes
-    const int hh = lane & (VP - 1), gl0 = lane & ~(VP - 1);     // my vertex, first lane of my task
-    const unsigned long long grpmask = (VP == 8 ? 0xffull : 0xfull) << gl0, below = (1ull << gl0) - 1ull;
-    const unsigned long long leadmask = VP == 8 ? 0x0101010101010101ull : 0x1111111111111111ull;
+    // phase-2 constants
+    const char *vh = (const char *)g.vh;
+    const char *vr = (const char *)g.vr;
+    const unsigned *pack = g.pack;
+    const ExpK ek = expk_make(g.midpoint, g.steepness);
+    const int hh = lane & (VP - 1), gi = lane >> LG;            // my vertex, my task of a pass
+    const unsigned hh16 = (unsigned)hh << 4;
     const unsigned long long ltmask = (1ull << lane) - 1ull;
+    const unsigned xyz_s = 24u * (unsigned)S;                   // byte offset of the first mobile ion in a frame of xyz[]
 
-    // ---- phase 2: every wave on its own (windows of IW ions, a lane each); no workgroup barrier from here on ----
+    // ---- phase 2: every wave on its own (windows of IW ions); no workgroup barrier from here on ----
     const int nions = nf * M;
     for (int ib0 = wave * IW; ib0 < nions; ib0 += NW * IW) {
         const int nib = (nions - ib0) < IW ? (nions - ib0) : IW;
-        // owner lanes: bin -> candidate list, offset vector (helpers.pyx:100)
+        // ---- A: a lane per ion of the window: its list, the first task of the list (a prefix sum) ----
         int fl = 0, j = 0, nL = 0;
-        const i32 *mylist = nullptr;
-        const unsigned char *mycrit = nullptr;
+        unsigned lo = 0u;
         if (lane < nib) {
             const int ion = ib0 + lane;
-            for (int q = 1; q < nf; q++) fl += ion >= q * M;
+            if (!FPB1) for (int q = 1; q < nf; q++) fl += ion >= q * M;
             j = ion - fl * M;
-            double *mp = xyz + 3 * (fl * SM + S + j);
-            const double px = mp[0], py = mp[1], pz = mp[2];
-            bool tight = DYN ? (h.frame_dmax[f0 + fl] * h.frame_dmax[f0 + fl] <= h.delta2) : (fmax[fl] == 0ull);
-            if (h.force_loose) tight = false;
-            if (tight) {
-                const int b = bin_of3<CELL>(P, px, py, pz, g.tG0, g.tG1, g.tG2);
-                const i32 lo = g.t_off[b];
-                nL = g.t_off[b + 1] - lo; mylist = g.t_list + lo; mycrit = g.t_crit + lo;
-            } else {
-                const int b = bin_of3<CELL>(P, px, py, pz, g.lG0, g.lG1, g.lG2);
-                const i32 lo = g.l_off[b];
-                nL = g.l_off[b + 1] - lo; mylist = g.l_list + lo; mycrit = g.l_crit + lo;
-            }
-            mp[0] = P.cen[0] - px; mp[1] = P.cen[1] - py; mp[2] = P.cen[2] - pz;
-            nzc[lane] = 0u;
-            // byte offsets into xyz[]: my offset vector, the statics of my frame; my frame
-            info[lane] = make_uint4(24u * (unsigned)(fl * SM + S + j), 24u * (unsigned)(fl * SM), (unsigned)fl, 0u);
-        }
-        const int inL = wave_add_scan(nL), exL = inL - nL;
-        int ion_s = 0;
-        while (ion_s < nib) {
-            // batch [ion_s, ion_e): whole ions, at most TCAP tasks
-            const int preL = __shfl(exL, ion_s);
-            const unsigned long long fit = __ballot(lane >= ion_s && lane < nib && inL - preL <= TCAP);
-            if (!fit) { if (lane == 0) atomicAdd(&h.scal[3], 1ull); break; }       // cannot happen (host checks)
-            const int ion_e = ion_s + __popcll(fit);
-            const int nlt = __shfl(inL, ion_e - 1) - preL;
-            if (lane >= ion_s && lane < ion_e) {
-                // task = landmark | critical vertex << 22 | ion << 26; four list entries in flight per lane
-                for (int c0 = 0; c0 < nL; c0 += 4) {
-                    unsigned e[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) e[u] = c0 + u < nL ? ((unsigned)mylist[c0 + u] | ((unsigned)mycrit[c0 + u] << 22)) : 0u;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) if (c0 + u < nL) ttab[exL - preL + c0 + u] = e[u] | ((unsigned)lane << 26);
+            const uint4 ii = ioninfo[ion];
+            lo = ii.x; nL = (int)ii.y;
+            if (h.has_fallback) {
+                const bool tight = DYN ? (h.frame_dmax[f0 + fl] * h.frame_dmax[f0 + fl] <= h.delta2) : (fmax[fl] == 0ull);
+                if (!tight) {
+                    const i32 flo = g.f_off[ii.z];
+                    nL = g.f_off[ii.z + 1] - flo; lo = g.f_base + (unsigned)flo;
                 }
             }
-            if (dbg == 9 && lane == 0) { atomicAdd(&h.scal[5], (u64)nlt); atomicAdd(&h.scal[7], 1ull); }
-            __builtin_amdgcn_wave_barrier();
-            // ---- D0: one lane per task tests the task's CRITICAL vertex (the one with the least room in this ion's
-            //      bin, candidates.hip); the tasks that pass are compacted in place ----
-            int t_end = 0;
-            const int nlt0 = dbg == 2 ? 0 : nlt;        // ablation: stop after the task table
-            for (int t0 = 0; t0 < nlt0; t0 += 64) {
-                const int t = t0 + lane;
-                const bool act = t < nlt0;
-                const unsigned tk = ttab[act ? t : 0];
-                const unsigned k = tk & 0x3fffffu, cv = (tk >> 22) & 7u;
-                const uint4 iv = info[tk >> 26];
-                const uint4 rec = vh[k * VP + cv];
-                const double hk = __hiloint2double((int)rec.w, (int)rec.z);
-                unsigned voff = rec.x;
-                if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)iv.z) * S + (i64)rec.y];
-                const double *sp = (const double *)((const char *)xyz + (iv.y + voff));
-                const double *op = (const double *)((const char *)xyz + iv.x);
+        }
+        const int inL = wave_add_scan(nL), exL = inL - nL;
+        const int nlt = __builtin_amdgcn_readlane(inL, 63);     // candidate tasks of the window
+        if (nlt > h.mcap) { if (lane == 0) atomicAdd(&h.scal[3], 1ull); break; }      // cannot happen (host sizes mcap)
+        for (int q = 4 * lane; q < nlt; q += 256) *(unsigned *)(mark + q) = 0u;
+        if (lane < nib) {
+            if (nL > 0) mark[exL] = (unsigned char)lane;
+            if (FPB1) ionrec[lane] = lo - (unsigned)exL;
+            else ((uint4 *)ionrec)[lane] = make_uint4(lo - (unsigned)exL, 24u * (unsigned)(fl * SM + S + j), 24u * (unsigned)(fl * SM), (unsigned)fl);
+            nzc[lane] = 0u;
+        }
+        if (DBG && dbg == 9 && lane == 0) { atomicAdd(&h.scal[5], (u64)nlt); atomicAdd(&h.scal[7], 1ull); }
+        const unsigned ionbase = xyz_s + 24u * (unsigned)ib0;   // FPB1: byte offset of the window's first offset vector
+        int t_end = 0, carry = 0;
+        const int nlt0 = (DBG && dbg == 2) ? 0 : nlt;           // ablation: stop after the owner stage
+        for (int base = 0; base < nlt0; base += 64) {
+            // ---- D0: a lane per candidate task: its ion (maximum scan over the start markers), its list entry, the
+            //      CRITICAL vertex of (bin, landmark) tested; the tasks that pass are appended to the task table ----
+            {
+                const int t = base + lane;
+                const unsigned long long vmask = first_lanes(nlt0 - base);
+                int mk = 0;
+                if (F3_LANES(vmask)) mk = (int)mark[t];
+                int ion = wave_max_scan(mk);
+                ion = ion > carry ? ion : carry;
+                carry = __builtin_amdgcn_readlane(ion, 63);
+                unsigned entry = 0u, ionoff, statoff = 0u, tfl = 0u;
+                if (FPB1) {
+                    const unsigned l0 = ionrec[ion];
+                    if (F3_LANES(vmask)) entry = pack[l0 + (unsigned)t];
+                    ionoff = ionbase + 24u * (unsigned)ion;
+                } else {
+                    const uint4 ir = ((const uint4 *)ionrec)[ion];
+                    if (F3_LANES(vmask)) entry = pack[ir.x + (unsigned)t];
+                    ionoff = ir.y; statoff = ir.z; tfl = ir.w;
+                }
+                const uint4 *rp = (const uint4 *)(vh + entry);
+                unsigned voff = rp->x;
+                if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)tfl) * S + (i64)rp->y];
+                const double hk = __hiloint2double((int)rp->w, (int)rp->z);
+                const double *sp = (const double *)(smem + (statoff + voff));
+                const double *op = (const double *)(smem + ionoff);
                 double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];
                 wrapc3<CELL>(P, qx, qy, qz);
                 const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
                 const double d2 = (dx * dx + dy * dy) + dz * dz;
-                const bool keep = act && !(d2 > hk);
-                const unsigned long long km = __ballot(keep);
-                if (keep) ttab[t_end + __popcll(km & ltmask)] = tk;
+                const unsigned long long km = __ballot(!(d2 > hk)) & vmask;
+                if (F3_LANES(km)) ttab[mask_rank(km, t_end)] = (entry & KMASK) | (unsigned)ion;
                 t_end += __popcll(km);
             }
-            if (dbg == 9 && lane == 0) atomicAdd(&h.scal[4], (u64)t_end);
-            if (dbg == 3) t_end = 0;                     // ablation: stop after the critical-vertex test
-            __builtin_amdgcn_wave_barrier();
-            const int pend = (t_end + TPP - 1) / TPP;           // passes of TPP tasks over [0, t_end)
+            if (t_end <= TT - 64 && base + 64 < nlt0) continue;         // room for another pass of candidates
+            if (DBG && dbg == 9 && lane == 0) atomicAdd(&h.scal[4], (u64)t_end);
+            if (DBG && dbg == 3) t_end = 0;                     // ablation: stop after the critical-vertex test
+            // ---- the task table is drained: passes of TPP tasks over [0, t_end) ----
+            const int pend = (t_end + TPP - 1) / TPP;
             int cursor = 0;
-            while (true) {
+            while (cursor < pend) {
                 // ---- D1: one squared distance per (task, vertex) lane (helpers.pyx:174-178 before the sqrt),
-                //      compared with (rz * vcd)^2; tasks with every vertex inside go to the region of survivors.
-                //      Two passes per iteration (loads and arithmetic of both first) while the region has room for
-                //      every task of both ----
+                //      compared with the exact threshold; tasks with every vertex inside go to the region of
+                //      survivors.  Two passes per iteration (loads and arithmetic of both first) while the region has
+                //      room for every task of both ----
                 int cnt = 0;
                 while (cursor < pend && cnt + TPP <= rcap) {
                     const bool two = cursor + 1 < pend && cnt + 2 * TPP <= rcap;
@@ -477,62 +507,68 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         if (u == 1 && !two) { bad[1] = ~0ull; tk[1] = 0u; d2[1] = 0.0; break; }
-                        const int t = TPP * (cursor + u) + (lane >> LG);
-                        tk[u] = ttab[t < TCAP ? t : 0];
-                        const unsigned k = tk[u] & 0x3fffffu;
-                        const uint4 iv = info[tk[u] >> 26];
-                        const uint4 rec = vh[k * VP + hh];
-                        const double hk = __hiloint2double((int)rec.w, (int)rec.z);
-                        unsigned voff = rec.x;
-                        if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)iv.z) * S + (i64)rec.y];
-                        const double *sp = (const double *)((const char *)xyz + (iv.y + voff));
-                        const double *op = (const double *)((const char *)xyz + iv.x);
+                        const int tb = TPP * (cursor + u);
+                        tk[u] = ttab[tb + gi];
+                        const uint4 *rp = (const uint4 *)(vh + ((tk[u] & KMASK) | hh16));
+                        unsigned voff = rp->x, ionoff, statoff = 0u;
+                        const unsigned ion = tk[u] & ~KMASK;
+                        if (FPB1) {
+                            ionoff = ionbase + 24u * ion;
+                            if (DYN) voff = 24u * (unsigned)g.lattice_map[f0 * S + (i64)rp->y];
+                        } else {
+                            const uint4 ir = ((const uint4 *)ionrec)[ion];
+                            ionoff = ir.y; statoff = ir.z;
+                            if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)ir.w) * S + (i64)rp->y];
+                        }
+                        const double hk = __hiloint2double((int)rp->w, (int)rp->z);
+                        const double *sp = (const double *)(smem + (statoff + voff));
+                        const double *op = (const double *)(smem + ionoff);
                         double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];
                         wrapc3<CELL>(P, qx, qy, qz);
                         const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
                         d2[u] = (dx * dx + dy * dy) + dz * dz;
-                        bad[u] = __ballot(!(t < t_end) || d2[u] > hk);
+                        bad[u] = __ballot(d2[u] > hk) | ~first_lanes((t_end - tb) << LG);
                     }
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         if (u == 1 && !two) break;
-                        const bool aliveg = (bad[u] & grpmask) == 0ull;
-                        const unsigned long long leaders = __ballot(aliveg) & leadmask;
-                        if (aliveg) {
-                            const int q = cnt + __popcll(leaders & below);
-                            sd2[q * VP + hh] = d2[u];
-                            if (hh == 0) sv_k[q] = tk[u];
-                        }
-                        cnt += __popcll(leaders);
+                        // scalar unit: the tasks whose lanes are all inside (bit 0 of every group of VP = the OR of the group)
+                        unsigned long long x = bad[u];
+                        if (LG == 3) x |= x >> 4;
+                        x |= x >> 2; x |= x >> 1;
+                        const unsigned long long leads = ~x & LEADS;
+                        unsigned long long am = leads | (leads << 1);
+                        am |= am << 2;
+                        if (LG == 3) am |= am << 4;
+                        const int q = mask_rank(leads << (VP - 1), cnt);       // survivors before my task
+                        if (F3_LANES(am)) sd2[q * VP + hh] = d2[u];
+                        if (F3_LANES(leads)) sv[q] = tk[u];
+                        cnt += __popcll(leads);
                     }
                     cursor += two ? 2 : 1;
                 }
-                if (dbg == 9 && lane == 0) atomicAdd(&h.scal[6], (u64)cnt);
-                if (dbg == 4) cnt = 0;
-                __builtin_amdgcn_wave_barrier();
+                if (DBG && dbg == 9 && lane == 0) atomicAdd(&h.scal[6], (u64)cnt);
+                if (DBG && dbg == 4) cnt = 0;
                 // ---- E: one logistic factor per (survivor, vertex) (helpers.pyx:196-205), in place; two items per
-                //      lane and iteration, loads first.  Padded vertices (1 / vcd stored as 0) give the factor 1 ----
-                const int items = cnt * VP;
+                //      lane and iteration, loads first ----
+                const int items = cnt << LG;
                 for (int i0 = 0; i0 < items; i0 += 128) {
-                    double d2[2];
-                    double2 c[2];
+                    double d2[2], rv[2];
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
-                        const int i = i0 + 64 * u + lane;
-                        const int ii = i < items ? i : 0;
-                        const unsigned kk = sv_k[ii >> LG];
-                        d2[u] = sd2[ii];
-                        c[u] = vr[(i64)(kk & 0x3fffffu) * VP + (ii & (VP - 1))];
+                        const int ib = i0 + 64 * u;
+                        const unsigned kk = sv[(ib >> LG) + gi];
+                        d2[u] = sd2[ib + lane];
+                        rv[u] = *(const double *)(vr + (((kk & KMASK) | hh16) >> 1));
                     }
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
-                        const int i = i0 + 64 * u + lane;
-                        const double f = vertex_factor(d2[u], c[u].x, c[u].y, ek, etab);
-                        if (i < items) sd2[i] = c[u].y != 0.0 ? f : 1.0;
+                        const int ib = i0 + 64 * u;
+                        const double f = vertex_factor(d2[u], rv[u], ek, etab);
+                        if (F3_LANES(first_lanes(items - ib < 0 ? 0 : items - ib))) sd2[ib + lane] = f;
                     }
                 }
-                if (dbg == 5) cnt = 0;                   // ablation: stop after the logistic factors
-                __builtin_amdgcn_wave_barrier();
+                if (DBG && dbg == 5) cnt = 0;                   // ablation: stop after the logistic factors
                 // ---- T: ci *= temp in vertex order (helpers.pyx:208) and the n-th root (:212), one lane per
                 //      survivor; the row entry of a component is the number of earlier non-zero components of its
                 //      ion (the survivors are in task order: ion-major, ascending landmark) ----
@@ -540,8 +576,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 unsigned kk = 0;
                 const bool tact = lane < cnt;
                 if (tact) {
-                    kk = sv_k[lane];
-                    const int nv = (int)g.nvtab[kk & 0x3fffffu];
+                    kk = sv[lane];
+                    const int nv = (int)g.nvtab[kk >> KSH];
                     const double2 *fp = (const double2 *)(sd2 + lane * VP);
                     double2 a = fp[0], b = fp[1];
                     double acc = a.x;
@@ -550,7 +586,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                     if (acc != 0.0) val = root_chain(acc, nv);
                 }
                 const bool nz = tact && val != 0.0;
-                const int ion = tact ? (int)(kk >> 26) : -1;
+                const int ion = tact ? (int)(kk & ~KMASK) : -1;
                 const int prev = __builtin_amdgcn_update_dpp(-1, ion, 0x138, 0xf, 0xf, false);      // wave_shr:1
                 const int next = __builtin_amdgcn_update_dpp(-1, ion, 0x130, 0xf, 0xf, false);      // wave_shl:1
                 const unsigned long long starts = __ballot(tact && prev != ion), nzm = __ballot(nz);
@@ -559,20 +595,16 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                     const int e = (int)nzc[ion] + __popcll(nzm & ltmask & ~((1ull << start) - 1ull));
                     if (nz && g.row_val != nullptr) {
                         const i64 row = f0 * M + ib0 + (i64)ion;                  // rows are frame-major
-                        if (e < g.W) { g.row_idx[(i64)e * g.N + row] = (i32)(kk & 0x3fffffu); g.row_val[(i64)e * g.N + row] = val; }
+                        if (e < g.W) { g.row_idx[(i64)e * g.N + row] = (i32)(kk >> KSH); g.row_val[(i64)e * g.N + row] = val; }
                         else atomicAdd(&h.scal[3], 1ull);
                     }
-                    __builtin_amdgcn_wave_barrier();
                     if (next != ion) nzc[ion] = (unsigned)(e + (nz ? 1 : 0));     // the ion's last survivor of this round
                 }
-                __builtin_amdgcn_wave_barrier();
-                if (cursor >= pend) break;
             }
-            ion_s = ion_e;
+            t_end = 0;
         }
-        __builtin_amdgcn_wave_barrier();
         if (lane < nib) {
-            const int nnz = dbg >= 2 && dbg <= 5 ? 1 : (int)nzc[lane];
+            const int nnz = (DBG && dbg >= 2 && dbg <= 5) ? 1 : (int)nzc[lane];
             const i64 row = (f0 + fl) * M + j;
             g.row_nnz[row] = nnz < g.W ? nnz : g.W;
             if (nnz == 0) {                                               // helpers.pyx:116-120
@@ -580,7 +612,6 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 else atomicAdd(&h.scal[0], 1ull);
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -592,24 +623,53 @@ static int f3_env_int(const char *name, int dflt)
     return e && *e ? atoi(e) : dflt;
 }
 
+// The reference zeroes a component when RN(RN(sqrt(d2)) / vcd) > rz for one of its vertices (helpers.pyx:176,197-199).
+// Both roundings are monotone in d2, so the decision is "d2 > T2" for T2 = the largest double that is not zeroed:
+// found by bisection over the (ordered) bit patterns of the non-negative doubles with the host's IEEE sqrt and division.
+static double f3_exact_d2_threshold(double vcd, double rz)
+{
+    auto zeroed = [&](double d2) {
+        volatile double dist = std::sqrt(d2);
+        volatile double t = dist / vcd;
+        return t > rz;
+    };
+    if (!(vcd > 0.0) || rz != rz) return INFINITY;              // degenerate basis: nothing is ever zeroed by a NaN compare
+    if (zeroed(0.0)) return -1.0;                                // every distance is beyond the cut-off
+    if (!zeroed(INFINITY)) return INFINITY;
+    auto bits = [](double x) { unsigned long long b; memcpy(&b, &x, 8); return b; };
+    auto dbl = [](unsigned long long b) { double x; memcpy(&x, &b, 8); return x; };
+    unsigned long long a = 0ull, b = bits(INFINITY);             // a: not zeroed, b: zeroed
+    const double guess = (rz * vcd) * (rz * vcd);
+    if (guess > 0.0 && guess < 1e300) {                          // the answer is within a few ulp of (rz vcd)^2
+        const double glo = guess * (1.0 - 1e-13), ghi = guess * (1.0 + 1e-13);
+        if (!zeroed(glo)) a = bits(glo);
+        if (zeroed(ghi)) b = bits(ghi);
+    }
+    while (b - a > 1ull) {
+        const unsigned long long m = a + (b - a) / 2ull;
+        if (zeroed(dbl(m))) b = m; else a = m;
+    }
+    return dbl(a);
+}
+
 // tables the third-generation kernel reads, built once per basis
 static int fill3_basis_tables(sit_ctx *c)
 {
-    if (c->d_hi2p) return SIT_OK;
+    if (c->d_vh) return SIT_OK;
     const i64 n = c->D * c->Vp;
     std::vector<i32> v((size_t)n);
-    std::vector<double> vcd((size_t)n), hi2((size_t)n), vr((size_t)(2 * n));
+    std::vector<double> vcd((size_t)n), t2((size_t)n), vr((size_t)n);
     HIP_TRY(c, hipMemcpy(v.data(), c->d_verts, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(vcd.data(), c->d_vcd, (size_t)n * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(hi2.data(), c->d_hi2, (size_t)n * 8, hipMemcpyDeviceToHost));
     std::vector<unsigned char> nv((size_t)c->D, 0);
     for (i64 k = 0; k < c->D; k++) {
         int cnt = 0;
         for (i64 hh = 0; hh < c->Vp; hh++) {
             const size_t e = (size_t)(k * c->Vp + hh);
             const bool valid = v[e] >= 0 && (i64)cnt == hh;    // vertices are a prefix (the reference breaks at -1)
-            if (valid) cnt++; else hi2[e] = INFINITY;
-            vr[2 * e] = vcd[e]; vr[2 * e + 1] = valid ? 1.0 / vcd[e] : 0.0;      // 0 marks a padded vertex
+            if (valid) cnt++;
+            t2[e] = valid ? f3_exact_d2_threshold(vcd[e], c->rz) : INFINITY;
+            vr[e] = valid ? 1.0 / vcd[e] : -INFINITY;          // -inf: the factor of a padded vertex is exactly 1
         }
         nv[(size_t)k] = (unsigned char)cnt;
     }
@@ -617,21 +677,15 @@ static int fill3_basis_tables(sit_ctx *c)
     for (i64 e = 0; e < n; e++) {
         const unsigned vi = v[(size_t)e] < 0 ? 0u : (unsigned)v[(size_t)e];
         unsigned long long bits;
-        memcpy(&bits, &hi2[(size_t)e], 8);
+        memcpy(&bits, &t2[(size_t)e], 8);
         vh[4 * e] = 24u * vi; vh[4 * e + 1] = vi; vh[4 * e + 2] = (unsigned)(bits & 0xffffffffull); vh[4 * e + 3] = (unsigned)(bits >> 32);
     }
     int rc;
-    if ((rc = dev_upload(c, &c->d_vh, vh.data(), 4 * n))) return rc;
-    if ((rc = dev_upload(c, &c->d_hi2p, hi2.data(), n))) return rc;
-    if ((rc = dev_upload(c, &c->d_vr, vr.data(), 2 * n))) return rc;
+    if ((rc = dev_upload(c, &c->d_vr, vr.data(), n))) return rc;
     if ((rc = dev_upload(c, &c->d_nv, nv.data(), c->D))) return rc;
-    std::vector<double> tab(2 * F3_EXPN);
-    for (int jj = 0; jj < F3_EXPN; jj++) {
-        const long double t = exp2l((long double)jj / F3_EXPN);
-        tab[2 * jj] = (double)t;
-        tab[2 * jj + 1] = (double)(t - (long double)tab[2 * jj]);
-    }
-    if ((rc = dev_upload(c, &c->d_exptab, tab.data(), 2 * F3_EXPN))) return rc;
+    std::vector<double> tab(F3_EXPN);
+    for (int jj = 0; jj < F3_EXPN; jj++) tab[jj] = (double)exp2l((long double)jj / F3_EXPN);
+    if ((rc = dev_upload(c, &c->d_exptab, tab.data(), F3_EXPN))) return rc;
     double hm = 1e300;
     for (int i = 0; i < 3; i++) {
         const double *r = c->pbc.ci + 3 * i;
@@ -639,11 +693,37 @@ static int fill3_basis_tables(sit_ctx *c)
         if (hgt < hm) hm = hgt;
     }
     c->hmin = hm;
+    if ((rc = dev_upload(c, &c->d_vh, vh.data(), 4 * n))) return rc;      // last: its presence marks the tables as built
     return SIT_OK;
 }
 
-// Can this context's next fill run on the third-generation kernel?  (Landmarks of at most 8 vertices; the widest
-// candidate list must fit a batch.)
+// list entries as the kernel wants them: landmark << ksh | critical vertex << 4 (the byte offset of that record in vh)
+__global__ __launch_bounds__(256) void k_pack_lists(const i32 *list, const unsigned char *crit, i64 n, int ksh, unsigned *out)
+{
+    const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = ((unsigned)list[i] << ksh) | ((unsigned)crit[i] << 4);
+}
+
+// one array with the entries of the tight table (if there is one) followed by those of the loose table
+static int fill3_pack_lists(sit_ctx *c, bool have_tight)
+{
+    if (c->d_pack && c->pack_gen == c->table_gen && c->pack_tight == (have_tight ? 1 : 0)) return SIT_OK;
+    i32 nt = 0, nl = 0;
+    const i64 nbl = (i64)c->G[0] * c->G[1] * c->G[2], nbt = (i64)c->tG[0] * c->tG[1] * c->tG[2];
+    HIP_TRY(c, hipMemcpyAsync(&nl, c->d_bin_off + nbl, 4, hipMemcpyDeviceToHost, c->stream));
+    if (have_tight) HIP_TRY(c, hipMemcpyAsync(&nt, c->d_tbin_off + nbt, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_pack, (i64)nt + (i64)nl + 1))) return rc;
+    const int ksh = (c->Vp == 8 ? 3 : 2) + 4;
+    if (nt > 0) k_pack_lists<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_tbin_list, c->d_tbin_crit, nt, ksh, c->d_pack);
+    if (nl > 0) k_pack_lists<<<dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_bin_list, c->d_bin_crit, nl, ksh, c->d_pack + nt);
+    HIP_TRY(c, hipGetLastError());
+    c->pack_nt = nt; c->pack_gen = c->table_gen; c->pack_tight = have_tight ? 1 : 0;
+    return SIT_OK;
+}
+
+// Can this context's next fill run on the third-generation kernel?  (Landmarks of at most 8 vertices.)
 bool fill3_eligible(sit_ctx *c)
 {
     if (c->fill_kernel != 3) return false;
@@ -652,28 +732,30 @@ bool fill3_eligible(sit_ctx *c)
     return true;
 }
 
-// the instantiation for this cell / landmark width / waves per workgroup / mapping mode
+// the instantiation for this cell / landmark width / waves per workgroup / mapping mode / frames per workgroup
 static hipError_t f3_dispatch(sit_ctx *c, const Fill3Head &h, Fill3ArgsPtr full, unsigned grid, size_t lds, int nw, int vp,
                               bool diag, bool dynmap)
 {
-#define F3_LAUNCH(CELL, LGV, NWV, DY, DB)                                                                                      \
+#define F3_LAUNCH(CELL, LGV, NWV, DY, F1, DB)                                                                                  \
     do {                                                                                                                   \
-        hipError_t e = lds_limit((const void *)k_fill3<CELL, LGV, NWV, DY, DB>, lds, c->device);                           \
+        hipError_t e = lds_limit((const void *)k_fill3<CELL, LGV, NWV, DY, F1, DB>, lds, c->device);                       \
         if (e != hipSuccess) return e;                                                                                     \
-        k_fill3<CELL, LGV, NWV, DY, DB><<<dim3(grid), dim3(NWV * 64), lds, c->stream>>>(h, full);                          \
+        k_fill3<CELL, LGV, NWV, DY, F1, DB><<<dim3(grid), dim3(NWV * 64), lds, c->stream>>>(h, full);                      \
     } while (0)
-#define F3_PICK3(CELL, LGV, NWV, DY)                                                                                           \
-    do { if (h.debug_stop) F3_LAUNCH(CELL, LGV, NWV, DY, 1); else F3_LAUNCH(CELL, LGV, NWV, DY, 0); } while (0)
-#define F3_PICK2(CELL, LGV, NWV)                                                                                               \
-    do { if (dynmap) F3_PICK3(CELL, LGV, NWV, 1); else F3_PICK3(CELL, LGV, NWV, 0); } while (0)
+#define F3_PICK3(CELL, LGV, NWV, F1)                                                                                           \
+    do {                                                                                                                   \
+        if (dynmap) F3_LAUNCH(CELL, LGV, NWV, 1, F1, 0);                                                                   \
+        else if (h.debug_stop) F3_LAUNCH(CELL, LGV, NWV, 0, F1, 1);                                                        \
+        else F3_LAUNCH(CELL, LGV, NWV, 0, F1, 0);                                                                          \
+    } while (0)
 #define F3_PICK(CELL, LGV)                                                                                                     \
     do {                                                                                                                   \
-        if (nw == 16) F3_PICK2(CELL, LGV, 16); else if (nw == 8) F3_PICK2(CELL, LGV, 8); else F3_PICK2(CELL, LGV, 4);      \
+        if (nw == 16) F3_PICK3(CELL, LGV, 16, 1); else if (nw == 8) F3_PICK3(CELL, LGV, 8, 1);                             \
+        else if (h.fpb == 1) F3_PICK3(CELL, LGV, 4, 1); else F3_PICK3(CELL, LGV, 4, 0);                                    \
     } while (0)
     if (diag) { if (vp == 8) F3_PICK(1, 3); else F3_PICK(1, 2); }
     else { if (vp == 8) F3_PICK(0, 3); else F3_PICK(0, 2); }
 #undef F3_PICK
-#undef F3_PICK2
 #undef F3_PICK3
 #undef F3_LAUNCH
     return hipGetLastError();
@@ -681,17 +763,21 @@ static hipError_t f3_dispatch(sit_ctx *c, const Fill3Head &h, Fill3ArgsPtr full,
 
 // Survivor slots and task-table size of a wave depend on what the data does (C5 keeps six components per ion, C3
 // one): the first fill of a kind times the candidates on the leading frames and the process remembers the choice.
-struct F3Tuned { i64 key[8]; int rcap, tcap; };
+struct F3Tuned { i64 key[8]; int rcap, tt; };
 static std::mutex g_f3_mutex;
 static std::vector<F3Tuned> g_f3_tuned;
 
-// Everything fill3_launch allocates, ahead of time (the pipelined call: an allocation stalls copies in flight)
+#define F3_ARGS_BYTES 1024          // the argument block; the counters of the trial launches sit behind it
+#define F3_TRIAL_WORDS 17
+
+// Everything fill3_launch allocates that does not depend on the pruning tables, ahead of time (the pipelined call:
+// an allocation stalls copies in flight)
 int fill3_prepare(sit_ctx *c)
 {
     int rc = fill3_basis_tables(c);
     if (rc) return rc;
     if (!c->d_fill_args) {
-        if ((rc = dev_alloc(c, &c->d_fill_args, (i64)std::max(sizeof(Fill3Args), (size_t)1024)))) return rc;
+        if ((rc = dev_alloc(c, &c->d_fill_args, (i64)(F3_ARGS_BYTES + F3_TRIAL_WORDS * 8)))) return rc;
         c->fill_args_host.clear();
     }
     return SIT_OK;
@@ -699,38 +785,39 @@ int fill3_prepare(sit_ctx *c)
 
 int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64 f_hi)
 {
+    static_assert(sizeof(Fill3Args) <= F3_ARGS_BYTES, "argument block");
     if (f_hi < 0) f_hi = c->F;
     const i64 S = c->S, M = c->M;
-    SIT_REQUIRE(c, c->D * c->Vp < (1LL << 31) && c->F * S < (1LL << 40) && c->A < (1LL << 25), "sit_fill: sizes too large");
-    int rc = fill3_basis_tables(c);
+    SIT_REQUIRE(c, c->D * c->Vp < (1LL << 27) && c->F * S < (1LL << 40) && c->A < (1LL << 25), "sit_fill: sizes too large");
+    int rc = fill3_prepare(c);
     if (rc) return rc;
     const bool have_tight = c->tight_delta >= 0;
+    if ((rc = fill3_pack_lists(c, have_tight))) return rc;
     Fill3Args a;
     memset(&a, 0, sizeof(a));
-    a.vh = (const uint4 *)c->d_vh; a.vr = (const double2 *)c->d_vr; a.nvtab = c->d_nv;
-    a.l_off = c->d_bin_off; a.l_list = c->d_bin_list; a.l_crit = c->d_bin_crit;
-    a.t_off = have_tight ? c->d_tbin_off : c->d_bin_off; a.t_list = have_tight ? c->d_tbin_list : c->d_bin_list;
-    a.t_crit = have_tight ? c->d_tbin_crit : c->d_bin_crit;
+    a.vh = (const uint4 *)c->d_vh; a.vr = c->d_vr; a.nvtab = c->d_nv;
+    a.pack = c->d_pack;
+    a.f_off = c->d_bin_off; a.fG0 = c->G[0]; a.fG1 = c->G[1]; a.fG2 = c->G[2];
+    a.f_base = (unsigned)c->pack_nt;
+    if (have_tight) { a.p_off = c->d_tbin_off; a.pG0 = c->tG[0]; a.pG1 = c->tG[1]; a.pG2 = c->tG[2]; }
+    else { a.p_off = c->d_bin_off; a.pG0 = c->G[0]; a.pG1 = c->G[1]; a.pG2 = c->G[2]; }
     a.lattice_map = p->dynamic_lattice_mapping ? c->d_lattice_map : nullptr;
     a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx; a.row_val = store ? c->d_row_val : nullptr;
     a.N = c->N; a.D = (int)c->D; a.W = (int)c->rows_W;
-    if (have_tight) { a.tG0 = c->tG[0]; a.tG1 = c->tG[1]; a.tG2 = c->tG[2]; }
-    else { a.tG0 = c->G[0]; a.tG1 = c->G[1]; a.tG2 = c->G[2]; }
-    a.lG0 = c->G[0]; a.lG1 = c->G[1]; a.lG2 = c->G[2];
     a.check_zeros = p->check_for_zeros;
-    a.midpoint = c->midpoint; a.steepness = c->steepness; a.rz = c->rz;
+    a.midpoint = c->midpoint; a.steepness = c->steepness;
 
     Fill3Head h;
     memset(&h, 0, sizeof(h));
     h.P = c->pbc; h.frames = c->d_frames; h.static_idx = c->d_static_idx; h.mobile_idx = c->d_mobile_idx;
     h.ref_static = c->d_ref_static;
     h.frame_dmax = p->dynamic_lattice_mapping ? c->d_frame_dmax : nullptr;
-    h.exptab = (const double2 *)c->d_exptab;
+    h.exptab = c->d_exptab;
     h.err = c->d_err; h.scal = c->d_scal; h.F = f_hi; h.fbeg = f_lo; h.A = c->A; h.frame0 = c->frame0;
     h.S = (int)S; h.M = (int)M;
     const bool dynmap = a.lattice_map != nullptr;
-    h.debug_stop = f3_env_int("SITATOR_DEBUG_STOP", 0);
-    h.force_loose = have_tight ? 0 : 1;
+    h.debug_stop = dynmap ? 0 : f3_env_int("SITATOR_DEBUG_STOP", 0);
+    h.has_fallback = have_tight ? 1 : 0;
     h.s0 = (int)c->idx_s0; h.m0 = (int)c->idx_m0;
     h.delta2 = have_tight ? c->tight_delta * c->tight_delta : -1.0;
     h.thr2_lo = c->static_thr * c->static_thr * (1.0 - 1e-14);
@@ -747,7 +834,6 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     int fpb = f3_env_int("SITATOR_FILL_FPB", 0);
     int rcap = f3_env_int("SITATOR_FILL_RCAP", 0);
     const int vp = (int)c->Vp;
-    const size_t frame_bytes = (size_t)(S + M) * 24;
     int iw = f3_env_int("SITATOR_FILL_IW", 0);
     if (fpb < 1) { i64 f = 64 / M; if (f < 1) f = 1; if (f > 32) f = 32; fpb = (int)f; }      // about 64 ions per workgroup
     if (fpb > 32) fpb = 32;
@@ -756,52 +842,59 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     rcap = (rcap + 7) / 8 * 8;
     if (rcap > 64) rcap = 64;
     if (rcap < 64 / vp) rcap = 64 / vp;                        // a pass of 64 / vp tasks must fit an empty region
+    const i64 wmax = have_tight ? std::max(c->W_tight, c->W) : c->W;       // longest candidate list an ion can meet
     auto iw_for = [&](int nwv, int fpbv) {
-        // ions per wave window: the workgroup's ions dealt evenly, at least 16 (the owner lanes of a window work alone)
-        if (iw >= 1 && iw <= 64) return (iw + 3) / 4 * 4;
-        const i64 per = ((i64)fpbv * M + nwv - 1) / nwv;
-        return (int)(per < 16 ? 16 : (per > 64 ? 64 : (per + 3) / 4 * 4));
+        // ions per wave window: the workgroup's ions dealt evenly, at least 16; at most 4096 candidate tasks
+        int v;
+        if (iw >= 1 && iw <= 64) v = (iw + 3) / 4 * 4;
+        else {
+            const i64 per = ((i64)fpbv * M + nwv - 1) / nwv;
+            v = (int)(per < 16 ? 16 : (per > 64 ? 64 : (per + 3) / 4 * 4));
+        }
+        while (v > 4 && (i64)v * wmax > 4096) v -= 4;
+        return v;
     };
-    // tasks of a wave batch: 128, or more where the candidate lists are long (C3: 7 per ion, C5: 9) so that a batch
-    // still holds a window's ions
-    int tcap = f3_env_int("SITATOR_FILL_TCAP", 0);
-    const bool tcap_auto = tcap < 64 || tcap > 1024;
-    if (tcap_auto) tcap = F3_TCAP;
-    tcap = (tcap + 63) / 64 * 64;
+    auto mcap_for = [&](int iwv) { return (int)(((i64)iwv * wmax + 63) / 64 * 64); };
+    // entries of a wave's task table (what passed the critical-vertex test and waits for its eight lanes): 128, more
+    // where the candidate lists are long (C3: 7 per ion, C5: 9)
+    int tt = f3_env_int("SITATOR_FILL_TCAP", 0);
+    const bool tt_auto = tt < 64 || tt > 1024;
+    if (tt_auto) tt = 128;
+    tt = (tt + 63) / 64 * 64;
     auto lds_bytes = [&](int nwv, int fpbv, int rcapv) {
-        return (size_t)nwv * f3_wave_bytes(rcapv, vp, iw_for(nwv, fpbv), tcap) + F3_EXPN * 16 + (size_t)fpbv * frame_bytes + (size_t)fpbv * 8 + 32;
+        const int iwv = iw_for(nwv, fpbv);
+        return (size_t)f3_layout(fpbv, (int)(S + M), (int)M, nwv, vp, rcapv, iwv, tt, mcap_for(iwv), fpbv == 1 ? 1 : 0).total + 32;
     };
     if (nw != 4 && nw != 8 && nw != 16) {
         // small frames: 4 waves and several workgroups per CU; a frame that leaves room for one workgroup only: 16
+        while (fpb > 1 && lds_bytes(4, fpb, rcap) > 53 * 1024) fpb--;
         const size_t b4 = lds_bytes(4, fpb, rcap);
         nw = b4 <= 53 * 1024 ? 4 : (b4 <= 72 * 1024 ? 8 : 16);
     }
+    if (nw != 4) fpb = 1;                                       // several frames per workgroup only with four waves
     if (rcap_auto) {
         // fewer survivor slots per wave when that admits one more workgroup per CU (a full region only costs a round)
         // (workgroups are admitted with some slack: 5 x 31.5 KB did not run five per CU, 5 x 29.5 KB did)
         auto wg_per_cu = [&](int r) { const size_t b = (lds_bytes(nw, fpb, r) + 1535) / 1024 * 1024; size_t k = (160 * 1024) / b; return k > 8 ? (size_t)8 : k; };
-        for (int r : {40, 32}) if (wg_per_cu(r) > wg_per_cu(rcap)) rcap = r;
+        for (int r : {40, 32}) if (r >= 64 / vp && wg_per_cu(r) > wg_per_cu(rcap)) rcap = r;
     }
-    if (tcap_auto) {
-        // a batch should hold the ions of a window: (mean candidates per ion + 1) x ions, in steps of 64 up to 512,
-        // as long as that does not cost a workgroup per CU (C3: 1.79 -> 1.58 ms, C5: 3.29 -> 3.16 ms)
+    if (tt_auto) {
+        // the table should hold what a window's candidates leave behind: about half of (mean candidates per ion + 1) x
+        // ions, in steps of 64 up to 512, as long as that does not cost a workgroup per CU
         const double per_ion = (have_tight ? c->tight_mean_candidates : c->mean_candidates) + 1.0;
-        int want = (int)(per_ion * iw_for(nw, fpb));
-        want = want < F3_TCAP ? F3_TCAP : (want > 512 ? 512 : (want + 63) / 64 * 64);
-        auto wgs = [&](int t) { const int keep = tcap; tcap = t; const size_t b = (lds_bytes(nw, fpb, rcap) + 1535) / 1024 * 1024; tcap = keep; return (160 * 1024) / b; };
-        const size_t base = wgs(F3_TCAP);
-        int pick = F3_TCAP;
-        for (int t = F3_TCAP + 64; t <= want; t += 64) if (wgs(t) == base) pick = t;
-        tcap = pick;
+        int want = (int)(0.5 * per_ion * iw_for(nw, fpb)) + 64;
+        want = want < 128 ? 128 : (want > 512 ? 512 : (want + 63) / 64 * 64);
+        auto wgs = [&](int t) { const int keep = tt; tt = t; const size_t b = (lds_bytes(nw, fpb, rcap) + 1535) / 1024 * 1024; tt = keep; return (160 * 1024) / b; };
+        const size_t base = wgs(128);
+        int pick = 128;
+        for (int t = 192; t <= want; t += 64) if (wgs(t) == base) pick = t;
+        tt = pick;
     }
     while (fpb > 1 && lds_bytes(nw, fpb, rcap) > 160 * 1024 - 512) fpb--;
     SIT_REQUIRE(c, lds_bytes(nw, fpb, rcap) <= 160 * 1024 - 256, "sit_fill: one frame's atoms do not fit in LDS");
     iw = iw_for(nw, fpb);
-    h.fpb = fpb; h.iw = iw;
-    if (!c->d_fill_args) {
-        if ((rc = dev_alloc(c, &c->d_fill_args, (i64)std::max(sizeof(Fill3Args), (size_t)1024)))) return rc;
-        c->fill_args_host.clear();
-    }
+    SIT_REQUIRE(c, (i64)iw * wmax <= 65536, "sit_fill: candidate lists too long for the third-generation kernel");
+    h.fpb = fpb; h.iw = iw; h.mcap = mcap_for(iw);
     if (c->fill_args_host.size() != sizeof(Fill3Args) || memcmp(c->fill_args_host.data(), &a, sizeof(Fill3Args)) != 0) {
         c->fill_args_host.assign((const char *)&a, (const char *)&a + sizeof(Fill3Args));
         HIP_TRY(c, hipMemcpyAsync(c->d_fill_args, c->fill_args_host.data(), sizeof(Fill3Args), hipMemcpyHostToDevice, c->stream));
@@ -821,36 +914,40 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     h.contig = contig;
 
     // ---- survivor slots / task-table size: measured once per kind of fill ----
-    if (rcap_auto && tcap_auto && h.debug_stop == 0 && f3_env_int("SITATOR_FILL_AUTOTUNE", 1) && (f_hi - f_lo) * M >= (1 << 18)) {
+    if (rcap_auto && tt_auto && h.debug_stop == 0 && f3_env_int("SITATOR_FILL_AUTOTUNE", 1) && (f_hi - f_lo) * M >= (1 << 18)) {
         const i64 key[8] = {S, M, c->D, vp, have_tight ? c->W_tight : c->W, (i64)nw * 64 + fpb, dynmap ? 1 : 0, (i64)(c->tight_mean_candidates * 4.0 + 0.5)};   // candidates per ion in quarters: trajectories of one system share a key
         bool found = false;
         {
             std::lock_guard<std::mutex> lock(g_f3_mutex);
-            for (const F3Tuned &t : g_f3_tuned) if (memcmp(t.key, key, sizeof(key)) == 0) { rcap = t.rcap; tcap = t.tcap; found = true; break; }
+            for (const F3Tuned &t : g_f3_tuned) if (memcmp(t.key, key, sizeof(key)) == 0) { rcap = t.rcap; tt = t.tt; found = true; break; }
         }
         if (!found) {
             const double per_ion = (have_tight ? c->tight_mean_candidates : c->mean_candidates) + 1.0;
-            int want = (int)(per_ion * iw);
-            want = want < F3_TCAP ? F3_TCAP : (want > 512 ? 512 : (want + 63) / 64 * 64);
+            int want = (int)(0.5 * per_ion * iw) + 64;
+            want = want < 128 ? 128 : (want > 512 ? 512 : (want + 63) / 64 * 64);
             const int min_rcap = 64 / vp > 32 ? 64 / vp : 32;
             const int NC = 5;
-            const int cand[NC][2] = {{rcap, tcap}, {rcap, want}, {64, want}, {min_rcap, want}, {min_rcap, want > 256 ? 256 : want}};
+            const int cand[NC][2] = {{rcap, tt}, {rcap, want}, {64, want}, {min_rcap, want}, {min_rcap, want > 256 ? 256 : want}};
             hipEvent_t e0, e1;
             HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
+            // the trial launches write the rows of the leading frames (the launch proper writes them again) but report
+            // into words of their own: errors and counts of earlier launches of a pipelined call stay untouched
             Fill3Head ht = h;
+            ht.err = (u64 *)(c->d_fill_args + F3_ARGS_BYTES); ht.scal = ht.err + 1;
+            HIP_TRY(c, hipMemsetAsync(ht.err, 0, F3_TRIAL_WORDS * 8, c->stream));
             ht.F = std::min<i64>(f_hi, f_lo + (i64)4096 * fpb);               // the leading frames: ~3 rounds of workgroups
             const unsigned gt = (unsigned)((ht.F - f_lo + fpb - 1) / fpb);
             float best = 1e30f;
-            int br = rcap, bt = tcap;
-            const int keep_tcap = tcap;
+            int br = rcap, bt = tt;
+            const int keep_tt = tt;
             for (int q = 0; q < NC; q++) {
                 bool dup = false;
                 for (int q2 = 0; q2 < q; q2++) dup = dup || (cand[q2][0] == cand[q][0] && cand[q2][1] == cand[q][1]);
                 if (dup) continue;
-                tcap = cand[q][1];
+                tt = cand[q][1];
                 const size_t ldq = lds_bytes(nw, fpb, cand[q][0]);
                 if (ldq > 160 * 1024 - 512) continue;
-                ht.rcap = cand[q][0]; ht.tcap = cand[q][1];
+                ht.rcap = cand[q][0]; ht.tt = cand[q][1];
                 float tq = 1e30f;
                 for (int rep = 0; rep < 5; rep++) {                            // the first launch of a shape warms it up; best of four
                     HIP_TRY(c, hipEventRecord(e0, c->stream));
@@ -863,22 +960,18 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
                 }
                 if (tq < best * (q == 0 ? 1.0f : 0.96f)) { best = tq; br = cand[q][0]; bt = cand[q][1]; }   // the default wins ties (a 60 us trial has jitter)
             }
-            tcap = keep_tcap;
+            tt = keep_tt;
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-            rcap = br; tcap = bt;
-            F3Tuned t; memcpy(t.key, key, sizeof(key)); t.rcap = rcap; t.tcap = tcap;
+            rcap = br; tt = bt;
+            F3Tuned t; memcpy(t.key, key, sizeof(key)); t.rcap = rcap; t.tt = tt;
             { std::lock_guard<std::mutex> lock(g_f3_mutex); g_f3_tuned.push_back(t); }
-            // what the trial launches reported does not count
-            HIP_TRY(c, hipMemsetAsync(c->d_err, 0xFF, sizeof(u64), c->stream));
-            HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64) * 16, c->stream));
         }
     }
-    if (tcap < (int)c->W) tcap = ((int)c->W + 63) / 64 * 64;   // the longest candidate list must fit a batch
     const size_t lds = lds_bytes(nw, fpb, rcap);
     SIT_REQUIRE(c, lds <= 160 * 1024 - 256, "sit_fill: one frame's atoms do not fit in LDS");
-    h.rcap = rcap; h.tcap = tcap;
+    h.rcap = rcap; h.tt = tt;
     if (f3_env_int("SITATOR_DEBUG_SHAPE", 0))
-        fprintf(stderr, "k_fill3 shape: nw %d fpb %d rcap %d iw %d tcap %d, %zu bytes of LDS per workgroup\n", nw, fpb, rcap, iw, tcap, lds);
+        fprintf(stderr, "k_fill3 shape: nw %d fpb %d rcap %d iw %d tt %d mcap %d, %zu bytes of LDS per workgroup\n", nw, fpb, rcap, iw, tt, h.mcap, lds);
     c->last_fpb = fpb; c->last_kernel = 3; c->last_iw = rcap; c->last_nw = nw;
     const unsigned grid = (unsigned)((f_hi - f_lo + fpb - 1) / fpb);
     if (f_hi <= f_lo) return SIT_OK;

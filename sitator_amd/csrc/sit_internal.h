@@ -65,12 +65,15 @@ struct sit_ctx {
     i64 fallback_frames = 0;
     int last_fpb = 0;
     double *d_frame_dmax = nullptr;   // [F] per-frame displacement maximum (dynamic mapping)
-    // third-generation fill (fill3.hip): inf-padded bounds, {vcd, 1/vcd} pairs, vertex counts, exp table
-    double *d_hi2p = nullptr;         // [D,Vp] as d_hi2 but +inf on padded vertices
-    unsigned *d_vh = nullptr;         // [D,Vp,4] {24 * static id, static id, d_hi2p as two words}: one load per (landmark, vertex)
-    double *d_vr = nullptr;           // [D,Vp,2] {vcd, correctly rounded 1/vcd}
+    // third-generation fill (fill3.hip): vertex records, reciprocal centre distances, vertex counts, exp table, lists
+    unsigned *d_vh = nullptr;         // [D,Vp,4] {24 * static id, static id, exact squared-distance threshold as two words}
+    double *d_vr = nullptr;           // [D,Vp] 1 / vcd (-inf on padded vertices)
     unsigned char *d_nv = nullptr;    // [D] vertices per landmark
-    double *d_exptab = nullptr;       // [128,2] {hi, lo} of 2^(j/128)
+    double *d_exptab = nullptr;       // [128] 2^(j/128)
+    unsigned *d_pack = nullptr;       // list entries of the tight table, then of the loose table, as record offsets
+    i64 pack_nt = 0;                  // entries of the tight part
+    i64 table_gen = 0, pack_gen = -1; // pruning tables built so far (candidates.hip); the build d_pack was made from
+    int pack_tight = -1;
     bool idx_contig = false;          // static_idx / mobile_idx are consecutive atom ranges
     i64 idx_s0 = 0, idx_m0 = 0;
     double hmin = 0;                  // smallest perpendicular height of the cell
