@@ -18,14 +18,16 @@
 //     RN(RN(sqrt(d2)) / vcd) > cutoff is false, found on the host by bisection over the doubles (sqrt and the division
 //     are monotone, so the comparison d2 > T2 is the reference's decision bit for bit).  Which tasks keep all their
 //     lanes is worked out on the scalar unit from the ballot (shift-or folds, inverse ballot as the execution mask);
-//   * survivors go to the wave's region (their squared distances, 64 bytes each); the logistic factors are evaluated
-//     one lane per (survivor, vertex) IN PLACE - the zero pattern is settled, so sqrt / division / exp / reciprocal
-//     only need to be accurate: Newton sequences without their final correctly-rounding step, a 128-entry exp table
-//     (values within ~1e-14 relative of the reference, the bar is 1e-6) - multiplied in vertex order by one lane per
-//     survivor, and that lane writes the row entry directly (its position in the row is a population count over the
-//     wave's non-zero mask);
+//   * the same lanes go on to the logistic factor of their vertex - the zero pattern is settled, so sqrt / division /
+//     exp / reciprocal only need to be accurate: Newton sequences without their final correctly-rounding step, a
+//     128-entry exp table (values within ~1e-14 relative of the reference, the bar is 1e-6) - and multiply the
+//     factors of a task with three DPP steps; the first lane of a surviving task appends (product, task) to the
+//     wave's list of survivors: 12 bytes each, where a region of squared distances for a separate factor stage
+//     took 64 and set the number of workgroups per CU;
+//   * one lane per survivor takes the n-th root and writes the row entry directly (its position in the row is a
+//     population count over the wave's non-zero mask);
 //   * nothing in phase 2 is shared between waves but the read-only frame: no workgroup barrier after phase 1.
-// LDS per workgroup is ~30 KB at 64 ions and 512 statics (five workgroups = 20 waves per CU).
+// LDS per workgroup is ~21 KB at 64 ions and 512 statics (seven workgroups = 28 waves per CU).
 // Kept from fill2: tight/loose pruning tables, error keys, slot-major sparse rows.
 #include <cmath>
 #include <cstdio>
@@ -42,12 +44,12 @@
 // read with scalar loads from a device copy (the kernel is short of scalar registers: arguments parked there are
 // loaded where they are used)
 struct Fill3Args {
-    const uint4 *vh;                  // [D,Vp] {24 * static id (byte offset of the vertex in a frame), static id, exact
-                                      //         squared-distance threshold as two words (+inf on padding)}
-    const double *vr;                 // [D,Vp] 1 / vcd (-inf on padding: the factor of a padded vertex is exactly 1)
+    const uint4 *vh;                  // [D,Vp] 32-byte records {24 * static id (byte offset of the vertex in a frame),
+                                      //   static id, exact squared-distance threshold (+inf on padding), 1 / vcd (-inf on
+                                      //   padding: the factor of a padded vertex is exactly 1), 8 bytes unused}
     const unsigned char *nvtab;       // [D]
     const unsigned *pack;             // list entries of the primary table, then of the fallback table:
-                                      // landmark << (LG + 4) | critical vertex << 4 = byte offset of that record in vh
+                                      // landmark << (LG + 5) | critical vertex << 5 = byte offset of that record in vh
     const i32 *p_off, *f_off;         // bin offsets of the primary (tight) and the fallback (loose) table
     const i32 *lattice_map;           // [F,S] or null
     i32 *row_nnz, *row_idx;
@@ -77,25 +79,25 @@ typedef const Fill3Args __attribute__((address_space(4))) *Fill3ArgsPtr;
 // LDS of a workgroup, in bytes from the start of the dynamic allocation
 struct F3Layout {
     int fmax, ioninfo, etab, wave0;                      // after xyz[fpb][S + M][3] at offset 0
-    int o_ionrec, o_ttab, o_sv, o_nzc, o_mark, wbytes;   // inside a wave's region (sd2 at its offset 0)
+    int o_ionrec, o_ttab, o_sv, o_nzc, o_mark, wbytes;   // inside a wave's region (prod at its offset 0)
     int total;
 };
 // rcap survivor slots (multiple of 8, <= 64), windows of iw ions (multiple of 4, <= 64), a task table of tt entries
 // (multiple of 64), mcap marker bytes (multiple of 64, >= the candidates of a window)
-__host__ __device__ inline F3Layout f3_layout(int fpb, int SM, int M, int nw, int vp, int rcap, int iw, int tt, int mcap, int fpb1)
+__host__ __device__ inline F3Layout f3_layout(int fpb, int SM, int M, int nw, int rcap, int iw, int tt, int mcap, int fpb1)
 {
     F3Layout L;
     int o = fpb * SM * 24;
     L.fmax = o; o += fpb * 8;
-    o = (o + 15) & ~15;
-    L.ioninfo = o; o += fpb * M * 16;                    // {first entry, entries, fallback bin, -} per ion
+    L.ioninfo = o; o += fpb * M * 8;                     // {first entry, entries | fallback bin << 8} per ion
     L.etab = o; o += F3_EXPN * 8;
+    o = (o + 15) & ~15;
     L.wave0 = o;
-    int w = rcap * vp * 8;                               // sd2: squared distances, then logistic factors, of the survivors
+    int w = rcap * 8;                                    // prod: the product of the logistic factors of every survivor
+    w = (w + 15) & ~15;
     L.o_ionrec = w; w += iw * (fpb1 ? 4 : 16);           // per ion of the window: first entry - first task (and LDS offsets)
-    w = (w + 7) & ~7;
-    L.o_ttab = w; w += tt * 4;                           // landmark << (LG + 4) | ion of the window
-    L.o_sv = w; w += (rcap + 16) * 4;                    // the task of every survivor (a partly filled pass reads on)
+    L.o_ttab = w; w += tt * 4;                           // landmark << (LG + 5) | ion of the window
+    L.o_sv = w; w += rcap * 4;                           // the task of every survivor
     L.o_nzc = w; w += iw * 4;                            // entries written per ion
     L.o_mark = w; w += mcap;                             // the ion that starts at a candidate task (0 elsewhere)
     L.wbytes = (w + 15) & ~15;
@@ -262,6 +264,71 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
     return (b0 * G1 + b1) * G2 + b2;
 }
 
+// NP passes of TPP tasks from the task table (cursor, cursor + 1): distances, thresholds, factors, products; the tasks
+// that keep all their lanes are appended to the survivors (prod, sv); cnt grows.  A macro: it lives inside the kernel's
+// locals (a lambda made the compiler spill its captures).
+#define F3_D1E_PASSES(NP)                                                                                                  \
+    do {                                                                                                                   \
+        double d2_[NP], rv_[NP], f_[NP];                                                                                   \
+        unsigned tk_[NP];                                                                                                  \
+        unsigned long long bad_[NP];                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < NP; u++) {                                                                   \
+            const int tb = TPP * (cursor + u);                                                                             \
+            tk_[u] = ttab[tb + gi];                                                                                        \
+            const uint4 *rp = (const uint4 *)(vh + ((tk_[u] & KMASK) | hh32));                                             \
+            const uint4 r0 = rp[0];                                                                                        \
+            const uint2 r1 = *(const uint2 *)(rp + 1);                                                                     \
+            unsigned voff = r0.x, ionoff, statoff = 0u;                                                                    \
+            const unsigned ion_ = tk_[u] & ~KMASK;                                                                         \
+            if (FPB1) {                                                                                                    \
+                ionoff = ionbase + 24u * ion_;                                                                             \
+                if (DYN) voff = 24u * (unsigned)g.lattice_map[f0 * S + (i64)r0.y];                                         \
+            } else {                                                                                                       \
+                const uint4 ir = ((const uint4 *)ionrec)[ion_];                                                            \
+                ionoff = ir.y; statoff = ir.z;                                                                             \
+                if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)ir.w) * S + (i64)r0.y];                           \
+            }                                                                                                              \
+            const double hk = __hiloint2double((int)r0.w, (int)r0.z);                                                      \
+            rv_[u] = __hiloint2double((int)r1.y, (int)r1.x);                                                               \
+            const double *sp = (const double *)(smem + (statoff + voff));                                                  \
+            const double *op = (const double *)(smem + ionoff);                                                            \
+            double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];                                             \
+            wrapc3<CELL>(P, qx, qy, qz);                                                                                   \
+            const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];                                       \
+            d2_[u] = (dx * dx + dy * dy) + dz * dz;                                                                        \
+            bad_[u] = __ballot(d2_[u] > hk) | ~first_lanes((t_end - tb) << LG);                                            \
+        }                                                                                                                  \
+        if (!(DBG && dbg == 4)) {                                                                                          \
+            _Pragma("unroll") for (int u = 0; u < NP; u++) f_[u] = vertex_factor(d2_[u], rv_[u], ek, etab);                \
+            _Pragma("unroll") for (int u = 0; u < NP; u++) {                                                               \
+                f_[u] *= dpp_row_shl<1>(f_[u]);                                                                            \
+                f_[u] *= dpp_row_shl<2>(f_[u]);                                                                            \
+                if (LG == 3) f_[u] *= dpp_row_shl<4>(f_[u]);                                                               \
+            }                                                                                                              \
+            _Pragma("unroll") for (int u = 0; u < NP; u++) {                                                               \
+                /* scalar unit: the tasks whose lanes are all inside (bit 0 of every group of VP = the OR of the group) */  \
+                unsigned long long x = bad_[u];                                                                            \
+                if (LG == 3) x |= x >> 4;                                                                                  \
+                x |= x >> 2; x |= x >> 1;                                                                                  \
+                const unsigned long long leads = ~x & LEADS;                                                               \
+                if (F3_LANES(leads)) {                                                                                     \
+                    const int q = mask_rank(leads, cnt);                     /* survivors before my task */                \
+                    prod[q] = f_[u]; sv[q] = tk_[u];                                                                       \
+                }                                                                                                          \
+                cnt += __popcll(leads);                                                                                    \
+            }                                                                                                              \
+        }                                                                                                                  \
+    } while (0)
+
+// the value of lane + N of the same row of 16 lanes (lanes without such a neighbour keep their own)
+template <int N>
+__device__ __forceinline__ double dpp_row_shl(double x)
+{
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x100 + N, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, 0x100 + N, 0xf, 0xf, false));
+}
+
 // LG: log2 of the padded vertices per landmark (2 or 3).  NW: waves per workgroup.  DYN: dynamic lattice mapping
 // (static ids go through the frame's lattice map; the static-lattice check was made by k_lattice_map).  FPB1: one frame
 // per workgroup (the LDS offsets of an ion follow from its number; otherwise they are looked up).
@@ -273,7 +340,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     constexpr int VP = 1 << LG;
     constexpr int NT = NW * 64;
     constexpr int TPP = 64 >> LG;                               // tasks per pass of 64 lanes
-    constexpr int KSH = LG + 4;                                 // task = landmark << KSH | ion of the window
+    constexpr int KSH = LG + 5;                                 // task = landmark << KSH | ion of the window
     constexpr unsigned KMASK = ~((1u << KSH) - 1u);
     constexpr unsigned long long LEADS = LG == 3 ? 0x0101010101010101ull : 0x1111111111111111ull;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -282,13 +349,13 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rcap = h.rcap, IW = h.iw, TT = h.tt;
     const int dbg = DBG ? h.debug_stop : 0;                     // the ablation stops and the census live in the DBG = 1 build
-    const F3Layout L = f3_layout(fpb, SM, M, NW, VP, rcap, IW, TT, h.mcap, FPB1);
+    const F3Layout L = f3_layout(fpb, SM, M, NW, rcap, IW, TT, h.mcap, FPB1);
     double *xyz = (double *)smem;                               // [fpb][S + M][3]; mobiles become centroid - ion
     u64 *fmax = (u64 *)(smem + L.fmax);                         // [fpb]
-    uint4 *ioninfo = (uint4 *)(smem + L.ioninfo);               // [fpb * M]
+    uint2 *ioninfo = (uint2 *)(smem + L.ioninfo);               // [fpb * M]
     double *etab = (double *)(smem + L.etab);
     char *wp = smem + L.wave0 + wave * L.wbytes;
-    double *sd2 = (double *)wp;
+    double *prod = (double *)wp;
     unsigned *ionrec = (unsigned *)(wp + L.o_ionrec);
     unsigned *ttab = (unsigned *)(wp + L.o_ttab);
     unsigned *sv = (unsigned *)(wp + L.o_sv);
@@ -304,7 +371,6 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     double etv = 0.0;
     if (tid < F3_EXPN) etv = h.exptab[tid];                    // in flight beside the frame loads; parked below
     for (int q = lane; q < TT; q += 64) ttab[q] = 0u;          // stale entries must stay valid tasks (landmark 0, ion 0)
-    for (int q = lane; q < rcap + 16; q += 64) sv[q] = 0u;
     for (int q = lane; q < (FPB1 ? IW : 4 * IW); q += 64) ionrec[q] = 0u;      // stale tasks look their ion up
     // ---- phase 1a: copy this workgroup's atoms into LDS, eight independent loads per thread in flight ----
     {
@@ -396,7 +462,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
             const i32 lo = g.p_off[b], hi = g.p_off[b + 1];
             unsigned fb = 0u;
             if (h.has_fallback) fb = (unsigned)bin_of3<CELL>(P, x, y, z, g.fG0, g.fG1, g.fG2);
-            ioninfo[fl * M + (r - S)] = make_uint4((unsigned)lo, (unsigned)(hi - lo), fb, 0u);
+            ioninfo[fl * M + (r - S)] = make_uint2((unsigned)lo, (unsigned)(hi - lo) | (fb << 8));
         }
     }
     __syncthreads();
@@ -409,11 +475,10 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
 
     // phase-2 constants
     const char *vh = (const char *)g.vh;
-    const char *vr = (const char *)g.vr;
     const unsigned *pack = g.pack;
     const ExpK ek = expk_make(g.midpoint, g.steepness);
     const int hh = lane & (VP - 1), gi = lane >> LG;            // my vertex, my task of a pass
-    const unsigned hh16 = (unsigned)hh << 4;
+    const unsigned hh32 = (unsigned)hh << 5;
     const unsigned long long ltmask = (1ull << lane) - 1ull;
     const unsigned xyz_s = 24u * (unsigned)S;                   // byte offset of the first mobile ion in a frame of xyz[]
 
@@ -428,13 +493,14 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
             const int ion = ib0 + lane;
             if (!FPB1) for (int q = 1; q < nf; q++) fl += ion >= q * M;
             j = ion - fl * M;
-            const uint4 ii = ioninfo[ion];
-            lo = ii.x; nL = (int)ii.y;
+            const uint2 ii = ioninfo[ion];
+            lo = ii.x; nL = (int)(ii.y & 255u);
             if (h.has_fallback) {
                 const bool tight = DYN ? (h.frame_dmax[f0 + fl] * h.frame_dmax[f0 + fl] <= h.delta2) : (fmax[fl] == 0ull);
                 if (!tight) {
-                    const i32 flo = g.f_off[ii.z];
-                    nL = g.f_off[ii.z + 1] - flo; lo = g.f_base + (unsigned)flo;
+                    const unsigned fb = ii.y >> 8;
+                    const i32 flo = g.f_off[fb];
+                    nL = g.f_off[fb + 1] - flo; lo = g.f_base + (unsigned)flo;
                 }
             }
         }
@@ -494,95 +560,33 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
             const int pend = (t_end + TPP - 1) / TPP;
             int cursor = 0;
             while (cursor < pend) {
-                // ---- D1: one squared distance per (task, vertex) lane (helpers.pyx:174-178 before the sqrt),
-                //      compared with the exact threshold; tasks with every vertex inside go to the region of
-                //      survivors.  Two passes per iteration (loads and arithmetic of both first) while the region has
-                //      room for every task of both ----
+                // ---- D1 + E: one squared distance per (task, vertex) lane (helpers.pyx:174-178 before the sqrt),
+                //      compared with the exact threshold, and the logistic factor of the vertex (helpers.pyx:196-205);
+                //      the factors of a task are multiplied across its lanes and the tasks with every vertex inside
+                //      are appended to the survivors.  Two passes per iteration (loads and arithmetic of both
+                //      interleaved) while the list has room for every task of both ----
                 int cnt = 0;
                 while (cursor < pend && cnt + TPP <= rcap) {
-                    const bool two = cursor + 1 < pend && cnt + 2 * TPP <= rcap;
-                    double d2[2];
-                    unsigned tk[2];
-                    unsigned long long bad[2];
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        if (u == 1 && !two) { bad[1] = ~0ull; tk[1] = 0u; d2[1] = 0.0; break; }
-                        const int tb = TPP * (cursor + u);
-                        tk[u] = ttab[tb + gi];
-                        const uint4 *rp = (const uint4 *)(vh + ((tk[u] & KMASK) | hh16));
-                        unsigned voff = rp->x, ionoff, statoff = 0u;
-                        const unsigned ion = tk[u] & ~KMASK;
-                        if (FPB1) {
-                            ionoff = ionbase + 24u * ion;
-                            if (DYN) voff = 24u * (unsigned)g.lattice_map[f0 * S + (i64)rp->y];
-                        } else {
-                            const uint4 ir = ((const uint4 *)ionrec)[ion];
-                            ionoff = ir.y; statoff = ir.z;
-                            if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)ir.w) * S + (i64)rp->y];
-                        }
-                        const double hk = __hiloint2double((int)rp->w, (int)rp->z);
-                        const double *sp = (const double *)(smem + (statoff + voff));
-                        const double *op = (const double *)(smem + ionoff);
-                        double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];
-                        wrapc3<CELL>(P, qx, qy, qz);
-                        const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
-                        d2[u] = (dx * dx + dy * dy) + dz * dz;
-                        bad[u] = __ballot(d2[u] > hk) | ~first_lanes((t_end - tb) << LG);
+                    if (cursor + 1 < pend && cnt + 2 * TPP <= rcap) {
+                        F3_D1E_PASSES(2);
+                        cursor += 2;
+                    } else {
+                        F3_D1E_PASSES(1);
+                        cursor += 1;
                     }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        if (u == 1 && !two) break;
-                        // scalar unit: the tasks whose lanes are all inside (bit 0 of every group of VP = the OR of the group)
-                        unsigned long long x = bad[u];
-                        if (LG == 3) x |= x >> 4;
-                        x |= x >> 2; x |= x >> 1;
-                        const unsigned long long leads = ~x & LEADS;
-                        unsigned long long am = leads | (leads << 1);
-                        am |= am << 2;
-                        if (LG == 3) am |= am << 4;
-                        const int q = mask_rank(leads << (VP - 1), cnt);       // survivors before my task
-                        if (F3_LANES(am)) sd2[q * VP + hh] = d2[u];
-                        if (F3_LANES(leads)) sv[q] = tk[u];
-                        cnt += __popcll(leads);
-                    }
-                    cursor += two ? 2 : 1;
                 }
                 if (DBG && dbg == 9 && lane == 0) atomicAdd(&h.scal[6], (u64)cnt);
-                if (DBG && dbg == 4) cnt = 0;
-                // ---- E: one logistic factor per (survivor, vertex) (helpers.pyx:196-205), in place; two items per
-                //      lane and iteration, loads first ----
-                const int items = cnt << LG;
-                for (int i0 = 0; i0 < items; i0 += 128) {
-                    double d2[2], rv[2];
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int ib = i0 + 64 * u;
-                        const unsigned kk = sv[(ib >> LG) + gi];
-                        d2[u] = sd2[ib + lane];
-                        rv[u] = *(const double *)(vr + (((kk & KMASK) | hh16) >> 1));
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int ib = i0 + 64 * u;
-                        const double f = vertex_factor(d2[u], rv[u], ek, etab);
-                        if (F3_LANES(first_lanes(items - ib < 0 ? 0 : items - ib))) sd2[ib + lane] = f;
-                    }
-                }
                 if (DBG && dbg == 5) cnt = 0;                   // ablation: stop after the logistic factors
-                // ---- T: ci *= temp in vertex order (helpers.pyx:208) and the n-th root (:212), one lane per
-                //      survivor; the row entry of a component is the number of earlier non-zero components of its
-                //      ion (the survivors are in task order: ion-major, ascending landmark) ----
+                // ---- T: the n-th root (helpers.pyx:212) of the product (:208), one lane per survivor; the row entry of
+                //      a component is the number of earlier non-zero components of its ion (the survivors are in task
+                //      order: ion-major, ascending landmark) ----
                 double val = 0.0;
                 unsigned kk = 0;
                 const bool tact = lane < cnt;
                 if (tact) {
                     kk = sv[lane];
                     const int nv = (int)g.nvtab[kk >> KSH];
-                    const double2 *fp = (const double2 *)(sd2 + lane * VP);
-                    double2 a = fp[0], b = fp[1];
-                    double acc = a.x;
-                    acc *= a.y; acc *= b.x; acc *= b.y;
-                    if (VP == 8) { a = fp[2]; b = fp[3]; acc *= a.x; acc *= a.y; acc *= b.x; acc *= b.y; }
+                    const double acc = prod[lane];
                     if (acc != 0.0) val = root_chain(acc, nv);
                 }
                 const bool nz = tact && val != 0.0;
@@ -673,15 +677,17 @@ static int fill3_basis_tables(sit_ctx *c)
         }
         nv[(size_t)k] = (unsigned char)cnt;
     }
-    std::vector<unsigned> vh((size_t)(4 * n));
+    std::vector<unsigned> vh((size_t)(8 * n));
     for (i64 e = 0; e < n; e++) {
         const unsigned vi = v[(size_t)e] < 0 ? 0u : (unsigned)v[(size_t)e];
-        unsigned long long bits;
-        memcpy(&bits, &t2[(size_t)e], 8);
-        vh[4 * e] = 24u * vi; vh[4 * e + 1] = vi; vh[4 * e + 2] = (unsigned)(bits & 0xffffffffull); vh[4 * e + 3] = (unsigned)(bits >> 32);
+        unsigned long long tb, rb;
+        memcpy(&tb, &t2[(size_t)e], 8);
+        memcpy(&rb, &vr[(size_t)e], 8);
+        unsigned *r = &vh[8 * (size_t)e];
+        r[0] = 24u * vi; r[1] = vi; r[2] = (unsigned)(tb & 0xffffffffull); r[3] = (unsigned)(tb >> 32);
+        r[4] = (unsigned)(rb & 0xffffffffull); r[5] = (unsigned)(rb >> 32); r[6] = 0u; r[7] = 0u;
     }
     int rc;
-    if ((rc = dev_upload(c, &c->d_vr, vr.data(), n))) return rc;
     if ((rc = dev_upload(c, &c->d_nv, nv.data(), c->D))) return rc;
     std::vector<double> tab(F3_EXPN);
     for (int jj = 0; jj < F3_EXPN; jj++) tab[jj] = (double)exp2l((long double)jj / F3_EXPN);
@@ -693,15 +699,15 @@ static int fill3_basis_tables(sit_ctx *c)
         if (hgt < hm) hm = hgt;
     }
     c->hmin = hm;
-    if ((rc = dev_upload(c, &c->d_vh, vh.data(), 4 * n))) return rc;      // last: its presence marks the tables as built
+    if ((rc = dev_upload(c, &c->d_vh, vh.data(), 8 * n))) return rc;      // last: its presence marks the tables as built
     return SIT_OK;
 }
 
-// list entries as the kernel wants them: landmark << ksh | critical vertex << 4 (the byte offset of that record in vh)
+// list entries as the kernel wants them: landmark << ksh | critical vertex << 5 (the byte offset of that record in vh)
 __global__ __launch_bounds__(256) void k_pack_lists(const i32 *list, const unsigned char *crit, i64 n, int ksh, unsigned *out)
 {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = ((unsigned)list[i] << ksh) | ((unsigned)crit[i] << 4);
+    if (i < n) out[i] = ((unsigned)list[i] << ksh) | ((unsigned)crit[i] << 5);
 }
 
 // one array with the entries of the tight table (if there is one) followed by those of the loose table
@@ -715,7 +721,7 @@ static int fill3_pack_lists(sit_ctx *c, bool have_tight)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     int rc;
     if ((rc = dev_alloc(c, &c->d_pack, (i64)nt + (i64)nl + 1))) return rc;
-    const int ksh = (c->Vp == 8 ? 3 : 2) + 4;
+    const int ksh = (c->Vp == 8 ? 3 : 2) + 5;
     if (nt > 0) k_pack_lists<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_tbin_list, c->d_tbin_crit, nt, ksh, c->d_pack);
     if (nl > 0) k_pack_lists<<<dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_bin_list, c->d_bin_crit, nl, ksh, c->d_pack + nt);
     HIP_TRY(c, hipGetLastError());
@@ -788,14 +794,14 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     static_assert(sizeof(Fill3Args) <= F3_ARGS_BYTES, "argument block");
     if (f_hi < 0) f_hi = c->F;
     const i64 S = c->S, M = c->M;
-    SIT_REQUIRE(c, c->D * c->Vp < (1LL << 27) && c->F * S < (1LL << 40) && c->A < (1LL << 25), "sit_fill: sizes too large");
+    SIT_REQUIRE(c, c->D * c->Vp < (1LL << 26) && c->F * S < (1LL << 40) && c->A < (1LL << 25), "sit_fill: sizes too large");
     int rc = fill3_prepare(c);
     if (rc) return rc;
     const bool have_tight = c->tight_delta >= 0;
     if ((rc = fill3_pack_lists(c, have_tight))) return rc;
     Fill3Args a;
     memset(&a, 0, sizeof(a));
-    a.vh = (const uint4 *)c->d_vh; a.vr = c->d_vr; a.nvtab = c->d_nv;
+    a.vh = (const uint4 *)c->d_vh; a.nvtab = c->d_nv;
     a.pack = c->d_pack;
     a.f_off = c->d_bin_off; a.fG0 = c->G[0]; a.fG1 = c->G[1]; a.fG2 = c->G[2];
     a.f_base = (unsigned)c->pack_nt;
@@ -838,7 +844,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     if (fpb < 1) { i64 f = 64 / M; if (f < 1) f = 1; if (f > 32) f = 32; fpb = (int)f; }      // about 64 ions per workgroup
     if (fpb > 32) fpb = 32;
     const bool rcap_auto = rcap < 8;
-    if (rcap_auto) rcap = 48;
+    if (rcap_auto) rcap = 64;
     rcap = (rcap + 7) / 8 * 8;
     if (rcap > 64) rcap = 64;
     if (rcap < 64 / vp) rcap = 64 / vp;                        // a pass of 64 / vp tasks must fit an empty region
@@ -863,7 +869,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     tt = (tt + 63) / 64 * 64;
     auto lds_bytes = [&](int nwv, int fpbv, int rcapv) {
         const int iwv = iw_for(nwv, fpbv);
-        return (size_t)f3_layout(fpbv, (int)(S + M), (int)M, nwv, vp, rcapv, iwv, tt, mcap_for(iwv), fpbv == 1 ? 1 : 0).total + 32;
+        return (size_t)f3_layout(fpbv, (int)(S + M), (int)M, nwv, rcapv, iwv, tt, mcap_for(iwv), fpbv == 1 ? 1 : 0).total + 32;
     };
     if (nw != 4 && nw != 8 && nw != 16) {
         // small frames: 4 waves and several workgroups per CU; a frame that leaves room for one workgroup only: 16

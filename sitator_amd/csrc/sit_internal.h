@@ -65,9 +65,8 @@ struct sit_ctx {
     i64 fallback_frames = 0;
     int last_fpb = 0;
     double *d_frame_dmax = nullptr;   // [F] per-frame displacement maximum (dynamic mapping)
-    // third-generation fill (fill3.hip): vertex records, reciprocal centre distances, vertex counts, exp table, lists
-    unsigned *d_vh = nullptr;         // [D,Vp,4] {24 * static id, static id, exact squared-distance threshold as two words}
-    double *d_vr = nullptr;           // [D,Vp] 1 / vcd (-inf on padded vertices)
+    // third-generation fill (fill3.hip): vertex records, vertex counts, exp table, lists
+    unsigned *d_vh = nullptr;         // [D,Vp,8] {24 * static id, static id, exact squared-distance threshold, 1 / vcd, -}
     unsigned char *d_nv = nullptr;    // [D] vertices per landmark
     double *d_exptab = nullptr;       // [128] 2^(j/128)
     unsigned *d_pack = nullptr;       // list entries of the tight table, then of the loose table, as record offsets
