@@ -263,6 +263,9 @@ def long_cases(ref, only=None):
             ("mcl_max2", {"clustering_algorithm": "mcl", "max_mobile_per_site": 2})], 30),
         ("c3_long", ("C3", 448, 200, 2003), dict(p_hop=1.0 / 60), both[:1], 6),
         ("c4_long", ("C4", 256, 200, 2004), dict(p_hop=1.0 / 60), both[:1], 6),
+        # the C2 shape on non-orthogonal cells (the kernels' full 3x3 wraps at size): hexagonal and triclinic
+        ("c2h_long", ("C2h", 64, 200, 2012), dict(p_hop=1.0 / 60), both[:1], 20),
+        ("c2t_long", ("C2t", 64, 200, 2013), dict(p_hop=1.0 / 60), both[:1], 20),
     ]
     for name, (cfg, M, F, seed), kw, variants, head in plan:
         if only and name not in only:

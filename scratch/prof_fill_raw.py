@@ -8,7 +8,7 @@ cfg = sys.argv[2] if len(sys.argv) > 2 else "C2"
 host = synth.config_host(cfg)
 ctx, *_ = _setup(host, synth.CONFIG_MOBILE[cfg], F, seed=2, kernel=os.environ.get("F_KERNEL", "3"))
 ts = []
-for i in range(4):
+for i in range(int(os.environ.get("F_REPS", "4"))):
     rc, nz, err = ctx.fill(check_for_zeros=False)
     ts.append(ctx.timers()["fill"])
 print("stop", os.environ.get("SITATOR_DEBUG_STOP", "0"), cfg, "F", F, "rc", rc, "fill ms", [round(t, 4) for t in ts], "fpb", ctx.info()["frames_per_workgroup"], "kernel", ctx.info()["fill_kernel"])

@@ -171,7 +171,7 @@ extern "C" void sit_destroy(sit_ctx *c)
     if (!c) return;
     (void)sit_comm_destroy(c);
     (void)hipSetDevice(c->device);
-    void *ptrs[] = {c->d_ref_static, c->d_verts, c->d_vcd, c->d_hi2, c->d_bin_off, c->d_bin_list,
+    void *ptrs[] = {c->d_ref_static, c->d_verts, c->d_vcd, c->d_bin_off, c->d_bin_list,
                     c->frames_owned ? c->d_frames : nullptr, c->d_static_idx, c->d_mobile_idx,
                     c->d_lattice_map, c->d_tbin_off, c->d_tbin_list, c->d_fill_args, c->d_frame_dmax, c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs,
                     c->d_counts, c->d_col_ptr, c->d_col_k, c->d_col_val, c->d_cen_dense, c->d_fit_centers,
@@ -370,23 +370,17 @@ extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const 
     const i64 Vp = (V + 3) / 4 * 4;
     c->Vp = Vp;
     std::vector<i32> v32((size_t)(D * Vp), -1);
-    std::vector<double> vcdp((size_t)(D * Vp), 1.0), hi2((size_t)(D * Vp), 0.0);
+    std::vector<double> vcdp((size_t)(D * Vp), 1.0);
     for (i64 k = 0; k < D; k++)
         for (i64 h = 0; h < V; h++) {
             v32[(size_t)(k * Vp + h)] = (i32)verts[k * V + h];
             const double d = vcd[k * V + h];
-            if (verts[k * V + h] >= 0) {
-                vcdp[(size_t)(k * Vp + h)] = d;
-                // d^2 > hi2  =>  fl(fl(sqrt(d^2)) / vcd) > rz  (three roundings of 2^-53 each << 1e-14)
-                const double r = c->rz * d;
-                hi2[(size_t)(k * Vp + h)] = r * r * (1.0 + 1e-14);
-            }
+            if (verts[k * V + h] >= 0) vcdp[(size_t)(k * Vp + h)] = d;
         }
     int rc;
     if ((rc = dev_upload(c, &c->d_ref_static, ref_static, S * 3))) return rc;
     if ((rc = dev_upload(c, &c->d_verts, v32.data(), D * Vp))) return rc;
     if ((rc = dev_upload(c, &c->d_vcd, vcdp.data(), D * Vp))) return rc;
-    if ((rc = dev_upload(c, &c->d_hi2, hi2.data(), D * Vp))) return rc;
     // loose table: valid for any frame the static-lattice check accepts (displacement <= static_thr), 1 A bins
     if ((rc = sit_build_candidates(c, static_thr, 1.0, &c->d_bin_off, &c->d_bin_list, &c->d_bin_crit, c->G, &c->W, &c->mean_candidates))) return rc;
     c->cell_diagonal = true;
@@ -394,7 +388,7 @@ extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const 
         for (int j = 0; j < 3; j++)
             if (i != j && (c->pbc.cm[3 * i + j] != 0.0 || c->pbc.ci[3 * i + j] != 0.0)) c->cell_diagonal = false;
     const char *fk = getenv("SITATOR_FILL_KERNEL");
-    c->fill_kernel = (fk && fk[0] == '1') ? 1 : ((fk && fk[0] == '2') ? 2 : 3);
+    c->fill_kernel = (fk && fk[0] == '1') ? 1 : 3;
     for (void **q : {(void **)&c->d_vh, (void **)&c->d_nv}) if (*q) { sit_dfree(c, *q); *q = nullptr; }
     c->tight_valid = false;
     c->rows_valid = false; c->assign_valid = false; c->map_valid = false;

@@ -260,6 +260,47 @@ static int launch_fill_v1(sit_ctx *c, const sit_fill_params *p)
     return SIT_OK;
 }
 
+// per-frame maximum static displacement of a strided sample of frames (own-index distance)
+__global__ __launch_bounds__(256) void k_sample_dmax(Pbc P, const double *frames, const i32 *static_idx,
+                                                     const double *ref_static, i64 F, i64 A, i64 S, i64 stride,
+                                                     double *out)
+{
+    __shared__ double red[256];
+    const i64 f = (i64)blockIdx.x * stride;
+    double m = 0.0;
+    if (f < F)
+        for (i64 s = threadIdx.x; s < S; s += 256) {
+            const double *p = frames + (f * A + static_idx[s]) * 3;
+            double x = p[0], y = p[1], z = p[2];
+            wrap3(P, x, y, z);
+            const double d = dist_sw(P, ref_static[3 * s], ref_static[3 * s + 1], ref_static[3 * s + 2], x, y, z);
+            m = d > m ? d : m;
+        }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+int sample_static_dmax(sit_ctx *c, std::vector<double> &out)
+{
+    i64 ns = c->F < 2048 ? c->F : 2048;
+    if (ns <= 0) { out.clear(); return SIT_OK; }
+    const i64 stride = c->F / ns;
+    int rc = ensure_scratch(c, ns * 8);
+    if (rc) return rc;
+    k_sample_dmax<<<dim3((unsigned)ns), dim3(256), 0, c->stream>>>(c->pbc, c->d_frames, c->d_static_idx, c->d_ref_static,
+                                                                   c->F, c->A, c->S, stride, (double *)c->d_scratch);
+    HIP_TRY(c, hipGetLastError());
+    out.resize((size_t)ns);
+    HIP_TRY(c, hipMemcpyAsync(out.data(), c->d_scratch, (size_t)ns * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
 // The tight pruning table: candidates for the static displacement actually present.  delta is
 // estimated from a strided sample of frames; every frame's true maximum is measured again inside
 // the fill kernel, and a frame above delta takes the loose table, so delta only steers speed.
@@ -267,16 +308,15 @@ static int ensure_tight_table(sit_ctx *c)
 {
     if (c->tight_valid) return SIT_OK;
     std::vector<double> sample;
-    int rc = fill2_sample_dmax(c, sample);
+    int rc = sample_static_dmax(c, sample);
     if (rc) return rc;
     double mx = 0.0;
     for (double d : sample) if (d == d && d <= c->static_thr && d > mx) mx = d;
     double delta = mx * 1.15 + 0.02;
     if (delta > c->static_thr) delta = c->static_thr;
-    if ((rc = sit_build_candidates(c, delta, 0.5, &c->d_tbin_off, &c->d_tbin_list, &c->d_tbin_crit, c->tG, &c->W_tight, &c->tight_mean_candidates))) return rc;
-    if (c->W_tight > 128) {  // F2_WTASK: an ion's tasks must fit one wave batch -> loose table for everything
-        delta = -1.0;
-    }
+    static const double tight_bin = [] { const char *v = getenv("SITATOR_TIGHT_BIN"); const double x = v ? atof(v) : 0.0; return x >= 0.1 && x <= 2.0 ? x : 0.5; }();
+    if ((rc = sit_build_candidates(c, delta, tight_bin, &c->d_tbin_off, &c->d_tbin_list, &c->d_tbin_crit, c->tG, &c->W_tight, &c->tight_mean_candidates))) return rc;
+    if (c->W_tight > 255) delta = -1.0;     // the kernel keeps a list length in eight bits: loose table for everything
     c->tight_delta = delta;
     c->tight_valid = true;
     return SIT_OK;
@@ -339,9 +379,9 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
     HIP_TRY(c, hipSetDevice(c->device));
     if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
     const i64 N = c->N, W = c->W;
-    const bool v2 = c->fill_kernel >= 2 && c->W <= 128;   // F2_WTASK
+    const bool v3 = c->fill_kernel == 3 && fill3_eligible(c);
     bool assign = p->assign != 0;
-    bool store = true;   // rows feed the predict kernel (wave-level fusion: see DESIGN.md)
+    bool store = true;   // the assignment is a second kernel that reads the stored rows
     if (assign) SIT_REQUIRE(c, c->K > 0 && c->d_col_ptr, "sit_fill: assign requested but no centres set");
     int rc;
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -360,7 +400,7 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
             if ((rc = dev_alloc(c, &c->d_confs, N))) return rc;
             c->assign_N = N;
         }
-        if (v2 && c->F > 0 && (rc = ensure_tight_table(c))) return rc;
+        if (v3 && c->F > 0 && (rc = ensure_tight_table(c))) return rc;
         if ((rc = reset_fill_words(c))) return rc;
         if (c->F == 0) {
             if (n_all_zero) *n_all_zero = 0;
@@ -370,8 +410,7 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         }
         StageTimer timer(c, T_FILL);
         if (p->dynamic_lattice_mapping && (rc = launch_lattice_map(c, p))) return rc;
-        if (v2 && fill3_eligible(c)) rc = fill3_launch(c, p, store);
-        else if (v2) { c->last_kernel = 2; rc = fill2_launch(c, p, store, assign, p->predict_threshold); }
+        if (v3) rc = fill3_launch(c, p, store);
         else { c->last_kernel = 1; rc = launch_fill_v1(c, p); }
         if (rc) return rc;
         timer.stop();
@@ -389,7 +428,7 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         c->fallback_frames = (i64)hs[2];
         const int kind = decode_error(c, hkey, err);
         if (kind != SIT_OK) { c->assign_valid = false; return kind; }
-        if (v2 && hs[3]) { c->assign_valid = false; c->msg = "landmark row wider than the pruning bound (internal error)"; return SIT_ERR_CAPACITY; }
+        if (v3 && hs[3]) { c->assign_valid = false; c->msg = "landmark row wider than the pruning bound (internal error)"; return SIT_ERR_CAPACITY; }
         return SIT_OK;
     }
     return SIT_ERR_CAPACITY;
@@ -523,7 +562,7 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
         return sit_fill(c, p, n_all_zero, err);
     }
     if ((rc = set_frame_meta(c, F, A, static_idx, S, mobile_idx, M, frame0))) return rc;
-    if (!(c->W <= 128 && fill3_eligible(c))) {
+    if (!fill3_eligible(c)) {
         if ((rc = sit_set_frames(c, frames, F, A, static_idx, S, mobile_idx, M, frame0))) return rc;
         return sit_fill(c, p, n_all_zero, err);
     }

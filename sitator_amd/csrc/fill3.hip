@@ -18,13 +18,13 @@
 //     RN(RN(sqrt(d2)) / vcd) > cutoff is false, found on the host by bisection over the doubles (sqrt and the division
 //     are monotone, so the comparison d2 > T2 is the reference's decision bit for bit).  Which tasks keep all their
 //     lanes is worked out on the scalar unit from the ballot (shift-or folds, inverse ballot as the execution mask);
-//   * the same lanes go on to the logistic factor of their vertex - the zero pattern is settled, so sqrt / division /
-//     exp / reciprocal only need to be accurate: Newton sequences without their final correctly-rounding step, a
-//     128-entry exp table (values within ~1e-14 relative of the reference, the bar is 1e-6) - and multiply the
-//     factors of a task with three DPP steps; the first lane of a surviving task appends (product, task) to the
-//     wave's list of survivors: 12 bytes each, where a region of squared distances for a separate factor stage
-//     took 64 and set the number of workgroups per CU;
-//   * one lane per survivor takes the n-th root and writes the row entry directly (its position in the row is a
+//   * the same lanes go on to the logistic term of their vertex, 1 + exp(steepness (t - midpoint)) - the zero pattern is
+//     settled, so sqrt / division / exp / reciprocal only need to be accurate: Newton sequences without their final
+//     correctly-rounding step, a 128-entry exp table (values within ~1e-14 relative of the reference, the bar is 1e-6)
+//     - and multiply the terms of a task with three DPP steps; the first lane of a surviving task appends (product,
+//     task) to the wave's list of survivors: 12 bytes each, where a region of squared distances for a separate
+//     factor stage took 64 and set the number of workgroups per CU;
+//   * one lane per survivor takes the reciprocal n-th root of the product and writes the row entry directly (its position in the row is a
 //     population count over the wave's non-zero mask);
 //   * nothing in phase 2 is shared between waves but the read-only frame: no workgroup barrier after phase 1.
 // LDS per workgroup is ~21 KB at 64 ions and 512 statics (seven workgroups = 28 waves per CU).
@@ -93,7 +93,7 @@ __host__ __device__ inline F3Layout f3_layout(int fpb, int SM, int M, int nw, in
     L.etab = o; o += F3_EXPN * 8;
     o = (o + 15) & ~15;
     L.wave0 = o;
-    int w = rcap * 8;                                    // prod: the product of the logistic factors of every survivor
+    int w = rcap * 8;                                    // prod: the product of the terms 1 + e of every survivor
     w = (w + 15) & ~15;
     L.o_ionrec = w; w += iw * (fpb1 ? 4 : 16);           // per ion of the window: first entry - first task (and LDS offsets)
     L.o_ttab = w; w += tt * 4;                           // landmark << (LG + 5) | ion of the window
@@ -130,7 +130,7 @@ __device__ __forceinline__ double rcp_nr(double b)
     return __builtin_fma(y, e, y);
 }
 
-// The constants of exp_tab / vertex_factor, held in VECTOR registers: the kernel is short of scalar registers (every
+// The constants of exp_tab / vertex_term, held in VECTOR registers: the kernel is short of scalar registers (every
 // constant the compiler parks there pushes another value into a spill lane and costs VALU instructions to move).
 struct ExpK {
     double log2e_128, magic, ln2_128_hi, ln2_128_lo, c5, c4, c3, mid, steep;
@@ -167,25 +167,36 @@ __device__ __forceinline__ double exp_tab(double x, const double *tab, const Exp
     return __builtin_ldexp(__builtin_fma(t, p, t), ni >> 7);
 }
 
-// one logistic factor of helpers.pyx:186-205 from the squared distance of a vertex that is inside the cut-off
-// (rvcd = -inf on a padded vertex: t = -inf, e = exp(-700), the factor exactly 1)
-__device__ __forceinline__ double vertex_factor(double d2, double rvcd, const ExpK &k, const double *tab)
+// 1 / (logistic factor) of helpers.pyx:186-205 = 1 + exp(steepness (t - midpoint)) from the squared distance of a vertex
+// that is inside the cut-off (rvcd = -inf on a padded vertex: t = -inf, e = exp(-700), the term exactly 1).  The
+// reciprocal is taken once per component, of the product of its terms (<= 1e4^8, no overflow).
+__device__ __forceinline__ double vertex_term(double d2, double rvcd, const ExpK &k, const double *tab)
 {
     d2 = __builtin_fmax(d2, 1e-300);                   // an ion exactly on a static atom: t - midpoint is the same
     const double tt = sqrt_nr(d2) * rvcd;
-    const double e = exp_tab(k.steep * (tt - k.mid), tab, k);
-    return rcp_nr(1.0 + e);
+    return 1.0 + exp_tab(k.steep * (tt - k.mid), tab, k);
 }
 
-__device__ __attribute__((noinline)) double pow_generic3(double acc, int nv) { return pow(acc, 1.0 / nv); }
-// pow(acc, 1.0 / nv) of helpers.pyx:212 for acc in (0, 1]
-__device__ __forceinline__ double root_chain(double acc, int nv)
+// 1 / sqrt(x): v_rsq_f64 seed and two Newton steps
+__device__ __forceinline__ double rsqrt_nr(double x)
 {
-    if (nv == 8) return sqrt_nr(sqrt_nr(sqrt_nr(acc)));
-    if (nv == 4) return sqrt_nr(sqrt_nr(acc));
-    if (nv == 2) return sqrt_nr(acc);
-    if (nv == 1) return acc;
-    return pow_generic3(acc, nv);
+    double y = __builtin_amdgcn_rsq(x);
+    double e = __builtin_fma(-x * y, y, 1.0);
+    y = __builtin_fma(0.5 * y, e, y);
+    e = __builtin_fma(-x * y, y, 1.0);
+    return __builtin_fma(0.5 * y, e, y);
+}
+
+__device__ __attribute__((noinline)) double pow_generic3(double p, int nv) { return pow(1.0 / p, 1.0 / nv); }
+// pow(ci, 1.0 / nv) of helpers.pyx:212 for ci = 1 / p, p in [1, 1e32]
+__device__ __forceinline__ double root_chain(double p, int nv)
+{
+    if (nv == 16) return sqrt_nr(sqrt_nr(sqrt_nr(rsqrt_nr(p))));
+    if (nv == 8) return sqrt_nr(sqrt_nr(rsqrt_nr(p)));
+    if (nv == 4) return sqrt_nr(rsqrt_nr(p));
+    if (nv == 2) return rsqrt_nr(p);
+    if (nv == 1) return rcp_nr(p);
+    return pow_generic3(p, nv);
 }
 
 // ---- wave helpers --------------------------------------------------------------------------------------------------
@@ -299,16 +310,18 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
             bad_[u] = __ballot(d2_[u] > hk) | ~first_lanes((t_end - tb) << LG);                                            \
         }                                                                                                                  \
         if (!(DBG && dbg == 4)) {                                                                                          \
-            _Pragma("unroll") for (int u = 0; u < NP; u++) f_[u] = vertex_factor(d2_[u], rv_[u], ek, etab);                \
+            _Pragma("unroll") for (int u = 0; u < NP; u++) f_[u] = vertex_term(d2_[u], rv_[u], ek, etab);                \
             _Pragma("unroll") for (int u = 0; u < NP; u++) {                                                               \
                 f_[u] *= dpp_row_shl<1>(f_[u]);                                                                            \
                 f_[u] *= dpp_row_shl<2>(f_[u]);                                                                            \
-                if (LG == 3) f_[u] *= dpp_row_shl<4>(f_[u]);                                                               \
+                if (LG >= 3) f_[u] *= dpp_row_shl<4>(f_[u]);                                                               \
+                if (LG >= 4) f_[u] *= dpp_row_shl<8>(f_[u]);                                                               \
             }                                                                                                              \
             _Pragma("unroll") for (int u = 0; u < NP; u++) {                                                               \
                 /* scalar unit: the tasks whose lanes are all inside (bit 0 of every group of VP = the OR of the group) */  \
                 unsigned long long x = bad_[u];                                                                            \
-                if (LG == 3) x |= x >> 4;                                                                                  \
+                if (LG >= 4) x |= x >> 8;                                                                                  \
+                if (LG >= 3) x |= x >> 4;                                                                                  \
                 x |= x >> 2; x |= x >> 1;                                                                                  \
                 const unsigned long long leads = ~x & LEADS;                                                               \
                 if (F3_LANES(leads)) {                                                                                     \
@@ -320,16 +333,16 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
         }                                                                                                                  \
     } while (0)
 
-// the value of lane + N of the same row of 16 lanes (lanes without such a neighbour keep their own)
+// the value of lane + N of the same row of 16 lanes (0 for lanes without such a neighbour)
 template <int N>
 __device__ __forceinline__ double dpp_row_shl(double x)
 {
     const int lo = __double2loint(x), hi = __double2hiint(x);
-    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, 0x100 + N, 0xf, 0xf, false),
-                            __builtin_amdgcn_update_dpp(lo, lo, 0x100 + N, 0xf, 0xf, false));
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(hi, 0x100 + N, 0xf, 0xf, true),
+                            __builtin_amdgcn_mov_dpp(lo, 0x100 + N, 0xf, 0xf, true));
 }
 
-// LG: log2 of the padded vertices per landmark (2 or 3).  NW: waves per workgroup.  DYN: dynamic lattice mapping
+// LG: log2 of the padded vertices per landmark (2, 3 or 4).  NW: waves per workgroup.  DYN: dynamic lattice mapping
 // (static ids go through the frame's lattice map; the static-lattice check was made by k_lattice_map).  FPB1: one frame
 // per workgroup (the LDS offsets of an ion follow from its number; otherwise they are looked up).
 // h.contig: 2 = the workgroup's atoms are one run of doubles in memory (statics then mobiles, nothing else),
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     constexpr int TPP = 64 >> LG;                               // tasks per pass of 64 lanes
     constexpr int KSH = LG + 5;                                 // task = landmark << KSH | ion of the window
     constexpr unsigned KMASK = ~((1u << KSH) - 1u);
-    constexpr unsigned long long LEADS = LG == 3 ? 0x0101010101010101ull : 0x1111111111111111ull;
+    constexpr unsigned long long LEADS = LG == 4 ? 0x0001000100010001ull : (LG == 3 ? 0x0101010101010101ull : 0x1111111111111111ull);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = h.S, M = h.M, SM = S + M;
     const int fpb = FPB1 ? 1 : h.fpb;
@@ -532,11 +545,11 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 unsigned entry = 0u, ionoff, statoff = 0u, tfl = 0u;
                 if (FPB1) {
                     const unsigned l0 = ionrec[ion];
-                    if (F3_LANES(vmask)) entry = pack[l0 + (unsigned)t];
+                    if (F3_LANES(vmask)) entry = *(const unsigned *)((const char *)pack + ((l0 + (unsigned)t) << 2));
                     ionoff = ionbase + 24u * (unsigned)ion;
                 } else {
                     const uint4 ir = ((const uint4 *)ionrec)[ion];
-                    if (F3_LANES(vmask)) entry = pack[ir.x + (unsigned)t];
+                    if (F3_LANES(vmask)) entry = *(const unsigned *)((const char *)pack + ((ir.x + (unsigned)t) << 2));
                     ionoff = ir.y; statoff = ir.z; tfl = ir.w;
                 }
                 const uint4 *rp = (const uint4 *)(vh + entry);
@@ -586,8 +599,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 if (tact) {
                     kk = sv[lane];
                     const int nv = (int)g.nvtab[kk >> KSH];
-                    const double acc = prod[lane];
-                    if (acc != 0.0) val = root_chain(acc, nv);
+                    val = root_chain(prod[lane], nv);
                 }
                 const bool nz = tact && val != 0.0;
                 const int ion = tact ? (int)(kk & ~KMASK) : -1;
@@ -656,36 +668,37 @@ static double f3_exact_d2_threshold(double vcd, double rz)
     return dbl(a);
 }
 
+// vertices per landmark as the kernel pads them: 4, 8 or 16 lanes per task
+static int f3_vp(const sit_ctx *c) { return c->Vp <= 4 ? 4 : (c->Vp <= 8 ? 8 : 16); }
+
 // tables the third-generation kernel reads, built once per basis
 static int fill3_basis_tables(sit_ctx *c)
 {
     if (c->d_vh) return SIT_OK;
-    const i64 n = c->D * c->Vp;
-    std::vector<i32> v((size_t)n);
-    std::vector<double> vcd((size_t)n), t2((size_t)n), vr((size_t)n);
-    HIP_TRY(c, hipMemcpy(v.data(), c->d_verts, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(vcd.data(), c->d_vcd, (size_t)n * 8, hipMemcpyDeviceToHost));
+    const i64 nsrc = c->D * c->Vp, vp3 = f3_vp(c), n = c->D * vp3;
+    std::vector<i32> v((size_t)nsrc);
+    std::vector<double> vcd((size_t)nsrc);
+    HIP_TRY(c, hipMemcpy(v.data(), c->d_verts, (size_t)nsrc * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(vcd.data(), c->d_vcd, (size_t)nsrc * 8, hipMemcpyDeviceToHost));
     std::vector<unsigned char> nv((size_t)c->D, 0);
+    std::vector<unsigned> vh((size_t)(8 * n));
     for (i64 k = 0; k < c->D; k++) {
         int cnt = 0;
-        for (i64 hh = 0; hh < c->Vp; hh++) {
-            const size_t e = (size_t)(k * c->Vp + hh);
-            const bool valid = v[e] >= 0 && (i64)cnt == hh;    // vertices are a prefix (the reference breaks at -1)
+        for (i64 hh = 0; hh < vp3; hh++) {
+            const size_t src = (size_t)(k * c->Vp + hh);
+            const bool valid = hh < c->Vp && v[src] >= 0 && (i64)cnt == hh;    // vertices are a prefix (the reference breaks at -1)
             if (valid) cnt++;
-            t2[e] = valid ? f3_exact_d2_threshold(vcd[e], c->rz) : INFINITY;
-            vr[e] = valid ? 1.0 / vcd[e] : -INFINITY;          // -inf: the factor of a padded vertex is exactly 1
+            const double t2 = valid ? f3_exact_d2_threshold(vcd[src], c->rz) : INFINITY;
+            const double rv = valid ? 1.0 / vcd[src] : -INFINITY;              // -inf: the term of a padded vertex is exactly 1
+            const unsigned vi = valid ? (unsigned)v[src] : 0u;
+            unsigned long long tb, rb;
+            memcpy(&tb, &t2, 8);
+            memcpy(&rb, &rv, 8);
+            unsigned *r = &vh[8 * (size_t)(k * vp3 + hh)];
+            r[0] = 24u * vi; r[1] = vi; r[2] = (unsigned)(tb & 0xffffffffull); r[3] = (unsigned)(tb >> 32);
+            r[4] = (unsigned)(rb & 0xffffffffull); r[5] = (unsigned)(rb >> 32); r[6] = 0u; r[7] = 0u;
         }
         nv[(size_t)k] = (unsigned char)cnt;
-    }
-    std::vector<unsigned> vh((size_t)(8 * n));
-    for (i64 e = 0; e < n; e++) {
-        const unsigned vi = v[(size_t)e] < 0 ? 0u : (unsigned)v[(size_t)e];
-        unsigned long long tb, rb;
-        memcpy(&tb, &t2[(size_t)e], 8);
-        memcpy(&rb, &vr[(size_t)e], 8);
-        unsigned *r = &vh[8 * (size_t)e];
-        r[0] = 24u * vi; r[1] = vi; r[2] = (unsigned)(tb & 0xffffffffull); r[3] = (unsigned)(tb >> 32);
-        r[4] = (unsigned)(rb & 0xffffffffull); r[5] = (unsigned)(rb >> 32); r[6] = 0u; r[7] = 0u;
     }
     int rc;
     if ((rc = dev_upload(c, &c->d_nv, nv.data(), c->D))) return rc;
@@ -719,9 +732,10 @@ static int fill3_pack_lists(sit_ctx *c, bool have_tight)
     HIP_TRY(c, hipMemcpyAsync(&nl, c->d_bin_off + nbl, 4, hipMemcpyDeviceToHost, c->stream));
     if (have_tight) HIP_TRY(c, hipMemcpyAsync(&nt, c->d_tbin_off + nbt, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    SIT_REQUIRE(c, (i64)nt + (i64)nl < (1LL << 30), "sit_fill: candidate tables too large for the third-generation kernel");
     int rc;
     if ((rc = dev_alloc(c, &c->d_pack, (i64)nt + (i64)nl + 1))) return rc;
-    const int ksh = (c->Vp == 8 ? 3 : 2) + 5;
+    const int ksh = (f3_vp(c) == 16 ? 4 : (f3_vp(c) == 8 ? 3 : 2)) + 5;
     if (nt > 0) k_pack_lists<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_tbin_list, c->d_tbin_crit, nt, ksh, c->d_pack);
     if (nl > 0) k_pack_lists<<<dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_bin_list, c->d_bin_crit, nl, ksh, c->d_pack + nt);
     HIP_TRY(c, hipGetLastError());
@@ -729,11 +743,11 @@ static int fill3_pack_lists(sit_ctx *c, bool have_tight)
     return SIT_OK;
 }
 
-// Can this context's next fill run on the third-generation kernel?  (Landmarks of at most 8 vertices.)
+// Can this context's next fill run on the third-generation kernel?  (Landmarks of at most 16 vertices.)
 bool fill3_eligible(sit_ctx *c)
 {
     if (c->fill_kernel != 3) return false;
-    if (c->Vp != 4 && c->Vp != 8) return false;
+    if (c->Vp > 16) return false;
     if (c->D >= (1LL << 22) || c->M > 30000 || c->W > 255) return false;
     return true;
 }
@@ -759,8 +773,8 @@ static hipError_t f3_dispatch(sit_ctx *c, const Fill3Head &h, Fill3ArgsPtr full,
         if (nw == 16) F3_PICK3(CELL, LGV, 16, 1); else if (nw == 8) F3_PICK3(CELL, LGV, 8, 1);                             \
         else if (h.fpb == 1) F3_PICK3(CELL, LGV, 4, 1); else F3_PICK3(CELL, LGV, 4, 0);                                    \
     } while (0)
-    if (diag) { if (vp == 8) F3_PICK(1, 3); else F3_PICK(1, 2); }
-    else { if (vp == 8) F3_PICK(0, 3); else F3_PICK(0, 2); }
+    if (diag) { if (vp == 16) F3_PICK(1, 4); else if (vp == 8) F3_PICK(1, 3); else F3_PICK(1, 2); }
+    else { if (vp == 16) F3_PICK(0, 4); else if (vp == 8) F3_PICK(0, 3); else F3_PICK(0, 2); }
 #undef F3_PICK
 #undef F3_PICK3
 #undef F3_LAUNCH
@@ -794,7 +808,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     static_assert(sizeof(Fill3Args) <= F3_ARGS_BYTES, "argument block");
     if (f_hi < 0) f_hi = c->F;
     const i64 S = c->S, M = c->M;
-    SIT_REQUIRE(c, c->D * c->Vp < (1LL << 26) && c->F * S < (1LL << 40) && c->A < (1LL << 25), "sit_fill: sizes too large");
+    SIT_REQUIRE(c, c->D * f3_vp(c) < (1LL << 26) && c->F * S < (1LL << 40) && c->A < (1LL << 25), "sit_fill: sizes too large");
     int rc = fill3_prepare(c);
     if (rc) return rc;
     const bool have_tight = c->tight_delta >= 0;
@@ -839,7 +853,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     int nw = f3_env_int("SITATOR_FILL_WAVES", 0);
     int fpb = f3_env_int("SITATOR_FILL_FPB", 0);
     int rcap = f3_env_int("SITATOR_FILL_RCAP", 0);
-    const int vp = (int)c->Vp;
+    const int vp = f3_vp(c);
     int iw = f3_env_int("SITATOR_FILL_IW", 0);
     if (fpb < 1) { i64 f = 64 / M; if (f < 1) f = 1; if (f > 32) f = 32; fpb = (int)f; }      // about 64 ions per workgroup
     if (fpb > 32) fpb = 32;

@@ -44,7 +44,6 @@ struct sit_ctx {
     double *d_ref_static = nullptr;   // [S,3]
     i32 *d_verts = nullptr;           // [D,V], -1 padded
     double *d_vcd = nullptr;          // [D,V]
-    double *d_hi2 = nullptr;          // [D,V] squared screening bounds (fill2.hip)
     // result-preserving landmark pruning: fractional-coordinate bins -> candidate landmarks
     int G[3] = {1, 1, 1};
     i32 *d_bin_off = nullptr;         // [nbins+1]
@@ -52,7 +51,7 @@ struct sit_ctx {
     unsigned char *d_bin_crit = nullptr, *d_tbin_crit = nullptr;   // critical vertex of every list entry (candidates.hip)
     i64 W = 0;                        // row width = longest candidate list (loose table)
     double mean_candidates = 0;
-    // tight table: built for the static displacement actually present (fill2.hip)
+    // tight table: built for the static displacement actually present (fill.hip ensure_tight_table)
     int tG[3] = {1, 1, 1};
     i32 *d_tbin_off = nullptr, *d_tbin_list = nullptr;
     std::vector<char> fill_args_host; // last uploaded copy of that block
@@ -61,7 +60,7 @@ struct sit_ctx {
     double tight_delta = 0, tight_mean_candidates = 0;
     bool tight_valid = false;
     bool cell_diagonal = false;
-    int fill_kernel = 2;              // SITATOR_FILL_KERNEL=1 selects the first-generation kernel
+    int fill_kernel = 3;              // SITATOR_FILL_KERNEL=1 selects the first-generation kernel (the general fallback)
     i64 fallback_frames = 0;
     int last_fpb = 0;
     double *d_frame_dmax = nullptr;   // [F] per-frame displacement maximum (dynamic mapping)
@@ -328,8 +327,6 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
 // pruning table for static displacements up to `displacement`, built and kept on the device (candidates.hip)
 int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32 **d_off, i32 **d_list,
                          unsigned char **d_crit, int G_out[3], i64 *W, double *mean);
-int fill2_sample_dmax(sit_ctx *c, std::vector<double> &out);
-int fill2_launch(sit_ctx *c, const sit_fill_params *p, bool store, bool assign, double threshold);
 bool fill3_eligible(sit_ctx *c);
 int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo = 0, i64 f_hi = -1);   // frames [f_lo, f_hi)
 int download_staged(sit_ctx *c, hipStream_t stream, void *dst, const void *src, size_t bytes);   // fill.hip: large read-backs

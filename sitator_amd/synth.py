@@ -341,9 +341,26 @@ def config_host(name):
         return sc_grid((16, 16, 8), cell=np.diag([64.0, 70.4, 38.4]))
     if name == "C5":
         return fcc_mixed(G=4, a=5.4, shape=np.diag([1.0, 1.0, 1.45]))
+    # the C2 shape on non-orthogonal cells (full 3x3 wraps in the kernels): hexagonal like C1, triclinic like C1b
+    if name == "C2h":
+        return sc_grid((8, 8, 8), cell=hexagonal_cell(32.0, 35.2))
+    if name == "C2t":
+        return sc_grid((8, 8, 8), cell=np.array([[32.0, 0, 0], [-5.3, 34.8, 0], [4.0, -2.7, 38.0]]))
     raise KeyError(name)
 
 
-CONFIG_MOBILE = {"C1": 4, "C1b": 4, "C2": 64, "C3": 448, "C4": 256, "C5": 160}
-CONFIG_FRAMES = {"C1": 2000, "C1b": 1000, "C2": 100000, "C3": 250000, "C4": 1000000, "C5": 500000}
-CONFIG_SEED = {"C1": 1, "C1b": 11, "C2": 2, "C3": 3, "C4": 4, "C5": 5}
+CONFIG_MOBILE = {"C1": 4, "C1b": 4, "C2": 64, "C3": 448, "C4": 256, "C5": 160, "C2h": 64, "C2t": 64}
+CONFIG_FRAMES = {"C1": 2000, "C1b": 1000, "C2": 100000, "C3": 250000, "C4": 1000000, "C5": 500000, "C2h": 100000,
+                 "C2t": 100000}
+CONFIG_SEED = {"C1": 1, "C1b": 11, "C2": 2, "C3": 3, "C4": 4, "C5": 5, "C2h": 12, "C2t": 13}
+CONFIG_TEXT = {
+    "C1": "C1: LiAlSiO4-like hexagonal cell a=b=12 A, c=12 A, SCgrid(3,3,3), S=D=27 (V=8), M=4 (BASELINE configs[0])",
+    "C1b": "C1b: triclinic BCCtet(3, 4.2 A), S=54, D=324 (V=4), M=4 (the rich-overlap parity host)",
+    "C2": "C2: SCgrid(8,8,8) orthorhombic 32.0x35.2x38.4 A, S=D=512 (V=8), M=64, A=576 (BASELINE configs[1])",
+    "C3": "C3: LLZO-like SCgrid(8,8,17) 26.0x26.0x55.25 A, S=D=1088 (V=8), M=448, A=1536 (BASELINE configs[2])",
+    "C4": "C4: SCgrid(16,16,8) orthorhombic 64.0x70.4x38.4 A, S=D=2048 (V=8), M=256, A=2304 (BASELINE configs[3])",
+    "C5": "C5: LGPS-like tetragonal FCC host with tetrahedral (V=4) and octahedral (V=6) landmarks, ragged, S=256, "
+          "D=768, M=160 (BASELINE configs[4])",
+    "C2h": "C2h: the C2 shape on a hexagonal cell a=b=32.0 A, gamma=120, c=35.2 A (full 3x3 wraps), S=D=512, M=64",
+    "C2t": "C2t: the C2 shape on a triclinic cell (32,0,0),(-5.3,34.8,0),(4,-2.7,38) A, S=D=512, M=64",
+}

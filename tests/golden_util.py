@@ -13,8 +13,8 @@ PIPELINE_CASES = ["c1_hex_scgrid", "c1b_tri_bcctet", "c2_cut_ortho", "c5_cut_fcc
 # Long cuts of the BASELINE configurations (hops, unassigned transition samples, late clusters, jumps).  Their frames
 # are regenerated from the stored recipe and checked against the stored digest; landmark vectors are stored for a
 # leading block of frames only.  C3 / C4 are too heavy for the dense CPU oracle and are GPU-only.
-LONG_CASES = ["c2_long_ortho", "c5_long_fcc_ragged", "c3_long", "c4_long"]
-LONG_CASES_CPU = ["c2_long_ortho", "c5_long_fcc_ragged"]
+LONG_CASES = ["c2_long_ortho", "c5_long_fcc_ragged", "c3_long", "c4_long", "c2h_long", "c2t_long"]
+LONG_CASES_CPU = ["c2_long_ortho", "c5_long_fcc_ragged", "c2h_long", "c2t_long"]
 
 
 def load(name):

@@ -33,12 +33,13 @@ def _setup(host, M, F, seed, kernel="3", mutate=None):
 
 @pytest.mark.parametrize("cfg,M,F", [("C2", 64, 200), ("C1b", 4, 500), ("C5", 160, 40)])
 def test_fill_generations_agree(cfg, M, F):
-    """v1 evaluates pow(acc, 1/n) with the library pow, v2 with square-root chains for n = 1, 2, 4, 8, v3 also
-    replaces the library exp by a table-driven one (<= 0.52 ulp): same sparsity pattern, values within a few ulp."""
+    """The first generation (the general fallback) evaluates the reference's expressions with the library's sqrt,
+    division, exp and pow; the third decides the zero pattern with exact squared-distance thresholds and evaluates
+    the values with shortened Newton sequences and a table-driven exp: same sparsity pattern, values within ~1e-14."""
     from sitator_amd import synth
     host = synth.config_host(cfg)
     out = []
-    for kern in ("1", "2", "3"):
+    for kern in ("1", "3"):
         ctx, *_ = _setup(host, M, F, seed=77, kernel=kern)
         rc, nz, err = ctx.fill()
         assert rc == 0
@@ -309,10 +310,12 @@ def test_wide_landmarks_take_the_generic_passes(oracle):
     np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(18))
 def test_random_geometry_rows_match_oracle(oracle, seed):
     """Fuzz: random triclinic cells (some smaller than the cut-off, so periodic images matter), random ragged
-    landmark definitions (1-9 vertices, repeated statics allowed), mobile atoms anywhere (also outside the cell)."""
+    landmark definitions (1-17 vertices, repeated statics allowed: 4, 8 and 16 lanes per landmark in the
+    third-generation kernel, 17 vertices fall back to the first generation), mobile atoms anywhere (also outside the
+    cell)."""
     from sitator_amd import _lib
     rng = np.random.default_rng(1000 + seed)
     L = rng.uniform(5.0, 14.0, size=3) if seed % 3 else rng.uniform(3.0, 5.0, size=3)
@@ -323,7 +326,7 @@ def test_random_geometry_rows_match_oracle(oracle, seed):
         cell[2, 1] = rng.uniform(-0.3, 0.3) * L[1]
     S, M, F = int(rng.integers(6, 40)), int(rng.integers(1, 9)), 25
     D = int(rng.integers(3, 30))
-    Vmax = [1, 3, 4, 6, 8, 9][seed % 6]
+    Vmax = [1, 3, 4, 6, 8, 9, 12, 16, 17][seed % 9]
     ref_static = rng.uniform(0, 1, size=(S, 3)) @ cell
     verts = np.full((D, Vmax), -1, dtype=np.int64)
     for k in range(D):
@@ -342,6 +345,7 @@ def test_random_geometry_rows_match_oracle(oracle, seed):
     ctx.set_frames(frames, static_idx, mobile_idx)
     rc, nz, err = ctx.fill(check_for_zeros=False)
     assert rc == 0
+    assert ctx.info()["fill_kernel"] == (3 if Vmax <= 16 else 1)
     exp, nz_exp = oracle.fill(cell, oracle.wrap_points(cell, frames), static_idx, mobile_idx, ref_static, verts, vcd,
                               check_for_zeros=False)
     got = ctx.rows_dense()
