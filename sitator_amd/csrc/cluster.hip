@@ -215,57 +215,67 @@ __device__ __forceinline__ bool predict_row_head(const PredArgs &a, i64 row, int
 
 // Rows of at most four entries are assigned here; wider rows are listed for k_predict_rows_wide (its register-hungry
 // merges would otherwise set the occupancy of this kernel too: 0.31 -> 0.48 ms at C2, where no row is wide).
-__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a, i32 *wide_list, unsigned *wide_count)
+// The list is kept in SEGMENTS, one per workgroup of the listing kernel (workgroup b walks the row blocks b, b + G, ...
+// and appends to wide_list[b * seg_cap ...], wide_count[b] = its length, zeroed before the launch): where most rows
+// are wide (C5) a single counter took a quarter of a million contended atomics per pass.
+__device__ __forceinline__ void list_wide_rows(bool wide, i64 row, i32 *seg, unsigned *seg_count, int lane)
 {
-    const i64 row = (i64)blockIdx.x * PRED_BLOCK + threadIdx.x;
-    int n = 0;
-    double xn = 0.0;
-    const bool live = row < a.N && predict_row_head(a, row, n, xn);
-    const bool wide = live && n > 4;
     const unsigned long long wm = __ballot(wide);
-    if (wm) {                                                      // one atomic per wave
-        const int lane = threadIdx.x & 63, leader = __ffsll((long long)wm) - 1;
+    if (wm) {                                                      // one atomic per wave, on the workgroup's own counter
+        const int leader = __ffsll((long long)wm) - 1;
         unsigned base = 0;
-        if (lane == leader) base = atomicAdd(wide_count, (unsigned)__popcll(wm));
+        if (lane == leader) base = atomicAdd(seg_count, (unsigned)__popcll(wm));
         base = __shfl(base, leader);
-        if (wide) wide_list[base + __popcll(wm & ((1ull << lane) - 1ull))] = (i32)row;
+        if (wide) seg[base + __popcll(wm & ((1ull << lane) - 1ull))] = (i32)row;
     }
-    if (live && !wide) predict_row_merge(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
+}
+
+__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a, i32 *wide_list, unsigned *wide_count, i64 seg_cap)
+{
+    i32 *seg = wide_list + (i64)blockIdx.x * seg_cap;
+    unsigned *seg_count = wide_count + blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    for (i64 r0 = (i64)blockIdx.x * PRED_BLOCK; r0 < a.N; r0 += (i64)gridDim.x * PRED_BLOCK) {
+        const i64 row = r0 + threadIdx.x;
+        int n = 0;
+        double xn = 0.0;
+        const bool live = row < a.N && predict_row_head(a, row, n, xn);
+        const bool wide = live && n > 4;
+        list_wide_rows(wide, row, seg, seg_count, lane);
+        if (live && !wide) predict_row_merge(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
+    }
 }
 
 // The same with the centres' CSC arrays resident in LDS (they are a few tens of KB: 480 centres of ~8 landmarks at
 // C2).  The merge makes ~35 scattered 4-8 byte reads per row; from global memory each is a 64-address vector load and
 // the kernel is bound by the texture-address path, from LDS they cost a few cycles.  Workgroups are persistent (the
-// arrays are staged once per workgroup) and walk the rows in blocks of PRED_LDS_BLOCK.
-#define PRED_LDS_BLOCK 512
+// arrays are staged once per workgroup) and walk the rows in blocks of their size.
+#define PRED_LDS_BLOCK 512          // threads of a workgroup while several fit a CU; 1024 when the arrays leave room for one or two
 // hist_K > 0: the labels are counted on the way (np.bincount of :92) - per workgroup in LDS, flushed once.
-__global__ __launch_bounds__(PRED_LDS_BLOCK) void k_predict_rows_lds(PredArgs a, i32 *wide_list, unsigned *wide_count, int nnzc,
-                                                                    int hist_K, u64 *counts)
+template <int NTMAX>                 // 512 (registers for six waves per SIMD) or 1024
+__global__ __launch_bounds__(NTMAX) void k_predict_rows_lds(PredArgs a, i32 *wide_list, unsigned *wide_count, i64 seg_cap, int nnzc,
+                                                            int hist_K, u64 *counts)
 {
     extern __shared__ __attribute__((aligned(16))) char pl_smem[];
     double *l_val = (double *)pl_smem;
     i32 *l_ptr = (i32 *)(l_val + nnzc);
     i32 *l_k = l_ptr + (a.D + 1);
     unsigned *hist = (unsigned *)(l_k + nnzc);
-    for (int q = threadIdx.x; q < hist_K; q += PRED_LDS_BLOCK) hist[q] = 0u;
-    for (int q = threadIdx.x; q < nnzc; q += PRED_LDS_BLOCK) { l_val[q] = a.col_val[q]; l_k[q] = a.col_k[q]; }
-    for (int q = threadIdx.x; q <= (int)a.D; q += PRED_LDS_BLOCK) l_ptr[q] = a.col_ptr[q];
+    const int NT = NTMAX;                                          // launched with exactly NTMAX threads
+    for (int q = threadIdx.x; q < hist_K; q += NT) hist[q] = 0u;
+    for (int q = threadIdx.x; q < nnzc; q += NT) { l_val[q] = a.col_val[q]; l_k[q] = a.col_k[q]; }
+    for (int q = threadIdx.x; q <= (int)a.D; q += NT) l_ptr[q] = a.col_ptr[q];
     __syncthreads();
+    i32 *seg = wide_list + (i64)blockIdx.x * seg_cap;
+    unsigned *seg_count = wide_count + blockIdx.x;
     const int lane = threadIdx.x & 63;
-    for (i64 r0 = (i64)blockIdx.x * PRED_LDS_BLOCK; r0 < a.N; r0 += (i64)gridDim.x * PRED_LDS_BLOCK) {
+    for (i64 r0 = (i64)blockIdx.x * NT; r0 < a.N; r0 += (i64)gridDim.x * NT) {
         const i64 row = r0 + threadIdx.x;
         int n = 0;
         double xn = 0.0;
         const bool live = row < a.N && predict_row_head(a, row, n, xn);
         const bool wide = live && n > 4;
-        const unsigned long long wm = __ballot(wide);
-        if (wm) {                                                  // one atomic per wave
-            const int leader = __ffsll((long long)wm) - 1;
-            unsigned base = 0;
-            if (lane == leader) base = atomicAdd(wide_count, (unsigned)__popcll(wm));
-            base = __shfl(base, leader);
-            if (wide) wide_list[base + __popcll(wm & ((1ull << lane) - 1ull))] = (i32)row;
-        }
+        list_wide_rows(wide, row, seg, seg_count, lane);
         if (live && !wide) {
             const i64 to = predict_row_merge(a, row, n, xn, l_ptr, l_k, l_val);
             if (hist_K > 0 && to >= 0) atomicAdd(&hist[to], 1u);
@@ -273,23 +283,32 @@ __global__ __launch_bounds__(PRED_LDS_BLOCK) void k_predict_rows_lds(PredArgs a,
     }
     if (hist_K > 0) {
         __syncthreads();
-        for (int q = threadIdx.x; q < hist_K; q += PRED_LDS_BLOCK) { const unsigned v = hist[q]; if (v) atomicAdd(&counts[q], (u64)v); }
+        for (int q = threadIdx.x; q < hist_K; q += NT) { const unsigned v = hist[q]; if (v) atomicAdd(&counts[q], (u64)v); }
     }
 }
 
-__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_wide(PredArgs a, const i32 *wide_list, const unsigned *wide_count, u64 *counts)
+// one wide row, centres from `col_*` (global memory or LDS)
+__device__ __forceinline__ void predict_wide_row(const PredArgs &a, i64 row, const i32 *col_ptr, const i32 *col_k, const double *col_val,
+                                                 u64 *counts)
 {
-    const i64 nw = (i64)*wide_count;
-    for (i64 q = (i64)blockIdx.x * PRED_BLOCK + threadIdx.x; q < nw; q += (i64)gridDim.x * PRED_BLOCK) {
-        const i64 row = wide_list[q];
-        int n;
-        double xn;
-        if (!predict_row_head(a, row, n, xn)) continue;
-        i64 to;
-        if (n <= 8) to = predict_row_merge_wide<8>(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
-        else if (n <= 16) to = predict_row_merge_wide<16>(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
-        else to = predict_row_generic(a, row, n, xn);
-        if (counts && to >= 0) atomicAdd(&counts[to], 1ull);       // the narrow rows were counted by k_predict_rows_lds
+    int n;
+    double xn;
+    if (!predict_row_head(a, row, n, xn)) return;
+    i64 to;
+    if (n <= 8) to = predict_row_merge_wide<8>(a, row, n, xn, col_ptr, col_k, col_val);
+    else if (n <= 16) to = predict_row_merge_wide<16>(a, row, n, xn, col_ptr, col_k, col_val);
+    else to = predict_row_generic(a, row, n, xn);
+    if (counts && to >= 0) atomicAdd(&counts[to], 1ull);           // the narrow rows were counted by k_predict_rows_lds
+}
+
+// the listed rows: workgroup j takes the segments j, j + gridDim.x, ... of the nseg the listing kernel wrote
+__global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_wide(PredArgs a, const i32 *wide_list, const unsigned *wide_count, i64 seg_cap,
+                                                                  int nseg, u64 *counts)
+{
+    for (int sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+        const i64 nw = (i64)wide_count[sg];
+        const i32 *seg = wide_list + (i64)sg * seg_cap;
+        for (i64 q = threadIdx.x; q < nw; q += PRED_BLOCK) predict_wide_row(a, seg[q], a.col_ptr, a.col_k, a.col_val, counts);
     }
 }
 
@@ -297,27 +316,26 @@ __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_wide(PredArgs a, co
 // waves per SIMD anyway, so up to ~150 KB of LDS cost no occupancy).  C5: 645 centres x ~12 landmarks = 93 KB.
 #define PRED_WIDE_LDS_BLOCK 768
 __global__ __launch_bounds__(PRED_WIDE_LDS_BLOCK) void k_predict_rows_wide_lds(PredArgs a, const i32 *wide_list, const unsigned *wide_count,
-                                                                              int nnzc, u64 *counts)
+                                                                              i64 seg_cap, int nseg, int nnzc, u64 *counts)
 {
     extern __shared__ __attribute__((aligned(16))) char pl_smem[];
+    __shared__ unsigned any;
     double *l_val = (double *)pl_smem;
     i32 *l_ptr = (i32 *)(l_val + nnzc);
     i32 *l_k = l_ptr + (a.D + 1);
-    const i64 nw = (i64)*wide_count;
-    if ((i64)blockIdx.x * PRED_WIDE_LDS_BLOCK >= nw) return;     // nothing for this workgroup: skip the staging
+    if (threadIdx.x == 0) any = 0u;
+    __syncthreads();
+    for (int sg = blockIdx.x + threadIdx.x * gridDim.x; sg < nseg; sg += gridDim.x * PRED_WIDE_LDS_BLOCK)
+        if (wide_count[sg]) any = 1u;
+    __syncthreads();
+    if (!any) return;                                              // nothing for this workgroup: skip the staging
     for (int q = threadIdx.x; q < nnzc; q += PRED_WIDE_LDS_BLOCK) { l_val[q] = a.col_val[q]; l_k[q] = a.col_k[q]; }
     for (int q = threadIdx.x; q <= (int)a.D; q += PRED_WIDE_LDS_BLOCK) l_ptr[q] = a.col_ptr[q];
     __syncthreads();
-    for (i64 q = (i64)blockIdx.x * PRED_WIDE_LDS_BLOCK + threadIdx.x; q < nw; q += (i64)gridDim.x * PRED_WIDE_LDS_BLOCK) {
-        const i64 row = wide_list[q];
-        int n;
-        double xn;
-        if (!predict_row_head(a, row, n, xn)) continue;
-        i64 to;
-        if (n <= 8) to = predict_row_merge_wide<8>(a, row, n, xn, l_ptr, l_k, l_val);
-        else if (n <= 16) to = predict_row_merge_wide<16>(a, row, n, xn, l_ptr, l_k, l_val);
-        else to = predict_row_generic(a, row, n, xn);
-        if (counts && to >= 0) atomicAdd(&counts[to], 1ull);
+    for (int sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+        const i64 nw = (i64)wide_count[sg];
+        const i32 *seg = wide_list + (i64)sg * seg_cap;
+        for (i64 q = threadIdx.x; q < nw; q += PRED_WIDE_LDS_BLOCK) predict_wide_row(a, seg[q], l_ptr, l_k, l_val, counts);
     }
 }
 
@@ -394,40 +412,49 @@ static int run_predict(sit_ctx *c, double threshold)
     a.labels = c->d_labels; a.confs = c->d_confs;
     a.N = c->rows_N; a.K = c->K; a.D = c->D; a.normed = c->centers_normed; a.threshold = threshold;
     const unsigned grid = (unsigned)((c->N + PRED_BLOCK - 1) / PRED_BLOCK);
-    if ((rc = ensure_scratch(c, c->N * 4 + 64))) return rc;
-    unsigned *wcount = (unsigned *)c->d_scratch;
-    i32 *wlist = (i32 *)c->d_scratch + 16;
+    if (c->num_cu <= 0) {
+        int v = 0;
+        c->num_cu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0 ? v : 256;
+    }
+    const int ncu = c->num_cu;
     StageTimer t(c, T_PREDICT);
     bool counted = false;
     if (c->max_col <= PRED_MAXCOL) {
         const size_t csc = (size_t)c->csc_nnz * 12 + (size_t)(c->D + 1) * 4 + 16, lds = csc + (size_t)c->K * 4;
         const char *pl = getenv("SITATOR_PREDICT_LDS");                 // "0": keep the centres in global memory (A/B, tests)
         const bool no_lds = pl && pl[0] == '0';
-        if (c->num_cu <= 0) {
-            int v = 0;
-            c->num_cu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0 ? v : 256;
-        }
-        const int ncu = c->num_cu;
-        // wide rows are few (none at C2) or most (C5): a grid-stride walk of their list
-        const unsigned gw = (unsigned)std::min<i64>((c->N + PRED_BLOCK - 1) / PRED_BLOCK, 16384);
-        const bool narrow_lds = lds <= 52 * 1024 && !no_lds, wide_lds = csc <= 150 * 1024 && !no_lds;
+        const bool narrow_lds = lds <= 150 * 1024 && !no_lds, wide_lds = csc <= 150 * 1024 && !no_lds;
+        // the listing kernel: persistent workgroups, each with its own segment of the wide-row list
+        // LDS: three or four workgroups of 512 threads per CU; larger centre sets (C3: 1 044 centres, 109 KB) leave room
+        // for two or one, of 1024 threads (from global memory C3's assignment took 2.1 ms per 4.5e7 rows)
+        const int nt = !narrow_lds ? PRED_BLOCK : (lds <= 52 * 1024 ? PRED_LDS_BLOCK : 1024);
+        const int per_cu = !narrow_lds ? 8 : (lds <= 36 * 1024 ? 4 : (lds <= 52 * 1024 ? 3 : (lds <= 78 * 1024 ? 2 : 1)));
+        const i64 blocks = (c->N + nt - 1) / nt;
+        const int nseg = (int)std::min<i64>(blocks, (i64)ncu * per_cu);
+        const i64 seg_cap = (blocks + nseg - 1) / nseg * nt;           // rows a workgroup can meet
+        if ((rc = ensure_scratch(c, ((i64)nseg * seg_cap + nseg + 64) * 4))) return rc;
+        unsigned *wcount = (unsigned *)c->d_scratch;
+        i32 *wlist = (i32 *)c->d_scratch + ((nseg + 63) / 64 * 64);
+        if (getenv("SITATOR_DEBUG_SHAPE")) fprintf(stderr, "predict: lds %zu nt %d per_cu %d nseg %d seg_cap %lld narrow_lds %d wide_lds %d rows_W %lld\n", lds, nt, per_cu, nseg, (long long)seg_cap, (int)narrow_lds, (int)wide_lds, (long long)c->rows_W);
         u64 *cnt = narrow_lds ? (u64 *)c->d_counts : nullptr;            // the LDS kernel counts the labels on the way
-        if ((rc = reset_predict_words(c, narrow_lds, wcount))) return rc;
+        if ((rc = reset_predict_words(c, narrow_lds, wcount, nseg))) return rc;
         if (narrow_lds) {
-            // three or four workgroups of 512 threads per CU
-            const i64 blocks = (c->N + PRED_LDS_BLOCK - 1) / PRED_LDS_BLOCK;
-            const unsigned g2 = (unsigned)std::min<i64>(blocks, (i64)ncu * (lds <= 36 * 1024 ? 4 : 3));
-            HIP_TRY(c, lds_limit((const void *)k_predict_rows_lds, lds, c->device));
-            k_predict_rows_lds<<<dim3(g2), dim3(PRED_LDS_BLOCK), lds, c->stream>>>(a, wlist, wcount, (int)c->csc_nnz, (int)c->K, (u64 *)c->d_counts);
+            if (nt == PRED_LDS_BLOCK) {
+                HIP_TRY(c, lds_limit((const void *)k_predict_rows_lds<PRED_LDS_BLOCK>, lds, c->device));
+                k_predict_rows_lds<PRED_LDS_BLOCK><<<dim3((unsigned)nseg), dim3(nt), lds, c->stream>>>(a, wlist, wcount, seg_cap, (int)c->csc_nnz, (int)c->K, (u64 *)c->d_counts);
+            } else {
+                HIP_TRY(c, lds_limit((const void *)k_predict_rows_lds<1024>, lds, c->device));
+                k_predict_rows_lds<1024><<<dim3((unsigned)nseg), dim3(nt), lds, c->stream>>>(a, wlist, wcount, seg_cap, (int)c->csc_nnz, (int)c->K, (u64 *)c->d_counts);
+            }
             counted = true;
         } else
-            k_predict_rows<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount);
+            k_predict_rows<<<dim3((unsigned)nseg), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, seg_cap);
         if (c->rows_W > 4) {
             if (wide_lds) {
                 HIP_TRY(c, lds_limit((const void *)k_predict_rows_wide_lds, csc, c->device));
-                k_predict_rows_wide_lds<<<dim3((unsigned)ncu), dim3(PRED_WIDE_LDS_BLOCK), csc, c->stream>>>(a, wlist, wcount, (int)c->csc_nnz, cnt);
+                k_predict_rows_wide_lds<<<dim3((unsigned)std::min(ncu, nseg)), dim3(PRED_WIDE_LDS_BLOCK), csc, c->stream>>>(a, wlist, wcount, seg_cap, nseg, (int)c->csc_nnz, cnt);
             } else
-                k_predict_rows_wide<<<dim3(gw), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, cnt);
+                k_predict_rows_wide<<<dim3((unsigned)std::min(nseg, ncu * 8)), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, seg_cap, nseg, cnt);
         }
     } else k_predict_rows_dense<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
     HIP_TRY(c, hipGetLastError());

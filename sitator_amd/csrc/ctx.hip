@@ -105,12 +105,12 @@ __global__ void k_reset_fill_words(u64 *err_block)
     if (t == 0) err_block[0] = ~0ull;
     else if (t <= 16) err_block[t] = 0ull;
 }
-// ... and for the assignment pass: the label counts and the length of the wide-row list
-__global__ void k_reset_predict_words(u64 *counts, i64 K, unsigned *wcount)
+// ... and for the assignment pass: the label counts and the lengths of the segments of the wide-row list
+__global__ void k_reset_predict_words(u64 *counts, i64 K, unsigned *wcount, int nseg)
 {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < K) counts[i] = 0ull;
-    if (i == 0 && wcount) *wcount = 0u;
+    if (i < nseg) wcount[i] = 0u;
 }
 
 int reset_fill_words(sit_ctx *c)
@@ -120,10 +120,10 @@ int reset_fill_words(sit_ctx *c)
     return SIT_OK;
 }
 
-int reset_predict_words(sit_ctx *c, bool counts, unsigned *wcount)
+int reset_predict_words(sit_ctx *c, bool counts, unsigned *wcount, int nseg)
 {
-    const i64 K = counts ? c->K : 0;
-    k_reset_predict_words<<<dim3((unsigned)((K + 255) / 256 > 0 ? (K + 255) / 256 : 1)), dim3(256), 0, c->stream>>>((u64 *)c->d_counts, K, wcount);
+    const i64 K = counts ? c->K : 0, n = std::max<i64>(K, nseg);
+    k_reset_predict_words<<<dim3((unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1)), dim3(256), 0, c->stream>>>((u64 *)c->d_counts, K, wcount, nseg);
     HIP_TRY(c, hipGetLastError());
     return SIT_OK;
 }

@@ -331,7 +331,7 @@ bool fill3_eligible(sit_ctx *c);
 int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo = 0, i64 f_hi = -1);   // frames [f_lo, f_hi)
 int download_staged(sit_ctx *c, hipStream_t stream, void *dst, const void *src, size_t bytes);   // fill.hip: large read-backs
 int reset_fill_words(sit_ctx *c);                                  // ctx.hip: error key and counters in one launch
-int reset_predict_words(sit_ctx *c, bool counts, unsigned *wcount); // label counts and wide-row list length in one launch
+int reset_predict_words(sit_ctx *c, bool counts, unsigned *wcount, int nseg); // label counts and wide-row segment lengths in one launch
 int fill3_prepare(sit_ctx *c);     // the allocations of fill3_launch, ahead of time
 int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S, const i64 *mobile_idx, i64 M, i64 frame0);   // ctx.hip
 // rows [row_lo, row_lo + nrows) of the stored landmark rows through the fit (cluster.hip)
