@@ -36,6 +36,8 @@ def lib():
         L.orc_cutoff_round_to_zero.argtypes = [C.c_double] * 3
         L.orc_fit_centers.restype = C.c_int64
         L.orc_predict.restype = C.c_int64
+        L.orc_fit_centers_csr.restype = C.c_int64
+        L.orc_predict_csr.restype = C.c_int64
         _LIB = L
     return _LIB
 
@@ -177,6 +179,70 @@ def predict(X, centers, threshold, normed=True):
     lib().orc_predict(_d(X), C.c_int64(N), C.c_int64(D), _d(centers), C.c_int64(len(centers)),
                       C.c_double(threshold), C.c_int(int(normed)), _i(labels), _d(confs))
     return labels, confs
+
+
+def to_csr(X):
+    """Dense rows -> (indptr, indices, values), entries in ascending dimension order."""
+    X = np.asarray(X)
+    nz = X != 0
+    indptr = np.zeros(len(X) + 1, dtype=np.int64)
+    np.cumsum(nz.sum(axis=1), out=indptr[1:])
+    rows, cols = np.nonzero(nz)                     # row-major: ascending dimensions inside a row
+    return indptr, np.ascontiguousarray(cols, dtype=np.int64), np.ascontiguousarray(X[rows, cols], dtype=np.float64)
+
+
+def csr_concat(parts):
+    """[(indptr, indices, values), ...] of consecutive row blocks -> one CSR triple."""
+    indptr = [np.zeros(1, dtype=np.int64)]
+    base = 0
+    for ip, _, _ in parts:
+        indptr.append(ip[1:] + base)
+        base += int(ip[-1])
+    return (np.concatenate(indptr), np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts]))
+
+
+def fit_centers_csr(csr, D, threshold, max_iters=10):
+    """:199-315 with the first pass over CSR rows (the same centres as ``fit_centers`` on the dense rows, bit for bit)."""
+    indptr, indices, values = csr
+    ptr = _dp()
+    iters = C.c_int64(0)
+    K = lib().orc_fit_centers_csr(_i(indptr), _i(indices), _d(values), C.c_int64(len(indptr) - 1), C.c_int64(D),
+                                  C.c_double(threshold), C.c_int64(max_iters), C.byref(ptr), C.byref(iters))
+    if K < 0:
+        raise OracleError("ValueError", what="Clustering did not converge after %i iterations" % max_iters)
+    out = np.ctypeslib.as_array(ptr, shape=(K, D)).copy()
+    lib().orc_free(ptr)
+    return out
+
+
+def predict_csr(csr, D, centers, threshold, normed=True):
+    """:129-197 on CSR rows."""
+    indptr, indices, values = csr
+    centers = np.ascontiguousarray(centers, dtype=np.float64)
+    N = len(indptr) - 1
+    labels = np.empty(N, dtype=np.int64)
+    confs = np.empty(N)
+    lib().orc_predict_csr(_i(indptr), _i(indices), _d(values), C.c_int64(N), C.c_int64(D), _d(centers),
+                          C.c_int64(len(centers)), C.c_double(threshold), C.c_int(int(normed)), _i(labels), _d(confs))
+    return labels, confs
+
+
+def cluster_dotprod_csr(csr, D, params, min_samples):
+    """landmark/cluster/dotprod.py:11-33 + fit_predict (:68-127) on CSR rows."""
+    p = {"clustering_threshold": 0.45, "assignment_threshold": 0.8}
+    p.update(params)
+    centers = fit_centers_csr(csr, D, p["clustering_threshold"])
+    labels, confs = predict_csr(csr, D, centers, p["assignment_threshold"], True)
+    n_assigned = int(np.sum(labels >= 0))
+    counts = np.bincount(labels[labels >= 0], minlength=len(centers))
+    ms = int(min_samples) if isinstance(min_samples, (int, np.integer)) else int(np.floor(min_samples * n_assigned))
+    mask = counts >= max(ms, 1)
+    centers, counts = centers[mask], counts[mask]
+    if len(centers) == 0:
+        raise OracleError("ValueError", what="`min_samples` too large")
+    labels, confs = predict_csr(csr, D, centers, p["assignment_threshold"], True)
+    return {"cluster-size": counts, "cluster-labels": labels, "cluster-confs": confs,
+            "cluster-representative-lvecs": centers}
 
 
 def fit_predict(X, threshold, min_samples, predict_threshold=None, predict_normed=True,

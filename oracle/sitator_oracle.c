@@ -280,6 +280,142 @@ i64 orc_fit_centers(const double *X, i64 N, i64 D, double threshold, i64 max_ite
 
 void orc_free(void *p) { free(p); }
 
+static double dot_sparse_self(const double *val, i64 n)
+{
+    double s = 0.0;
+    for (i64 e = 0; e < n; e++) s += val[e] * val[e];
+    return s;
+}
+
+/*
+ * The same stream (util/DotProdClassifier.pyx:199-315) with the rows of the FIRST pass given sparse (CSR, ascending
+ * dimensions): a dot product that skips the zero entries adds the same terms in the same order (s + 0.0 == s), a
+ * running mean that skips them likewise, so the centres are those of orc_fit_centers on the dense rows bit for bit
+ * (tests/test_oracle_golden.py checks that).  Later passes stream the dense centres of the pass before.  It exists so
+ * that the oracle can fit trajectories of the length the product's default (pipelined) path takes: the dense stream
+ * costs N x K x D multiplications.
+ */
+static double dot_sparse(const double *c, const i64 *idx, const double *val, i64 n)
+{
+    double s = 0.0;
+    for (i64 e = 0; e < n; e++) s += c[idx[e]] * val[e];
+    return s;
+}
+
+i64 orc_fit_centers_csr(const i64 *indptr, const i64 *indices, const double *values, i64 N, i64 D, double threshold,
+                        i64 max_iters, double **centers_out, i64 *n_iters_out)
+{
+    i64 cap = 100;                                    /* N_SITES_ALLOC_INCREMENT, :9 */
+    double *cen = (double *)malloc(sizeof(double) * cap * D);
+    double *nrm = (double *)malloc(sizeof(double) * cap);
+    double *diffs = (double *)malloc(sizeof(double) * cap);
+    i64 *cnt = (i64 *)malloc(sizeof(i64) * cap);
+    double *oldbuf = NULL; i64 *oldcnt = NULL;
+    i64 old_n = N, last = -1, K = 0;
+    int converged = 0; i64 it;
+    if (N < 1) { free(cen); free(nrm); free(diffs); free(cnt); *centers_out = NULL; return -1; }
+    for (it = 0; it < max_iters; it++) {
+        const int sparse = oldbuf == NULL;            /* pass 1 streams the rows, later passes the centres */
+        K = 0;
+        for (i64 i = 0; i < old_n; i++) {
+            const i64 *ix = sparse ? indices + indptr[i] : NULL;
+            const double *vx = sparse ? values + indptr[i] : oldbuf + D * i;
+            const i64 nz = sparse ? indptr[i + 1] - indptr[i] : D;
+            const i64 w = sparse ? 1 : oldcnt[i];
+            const double vn = sparse ? sqrt(dot_sparse_self(vx, nz)) : sqrt(dot_seq(vx, vx, D));
+            i64 to = -1;
+            if (i > 0) {
+                for (i64 k = 0; k < K; k++) {         /* :238-240 */
+                    double d = sparse ? dot_sparse(cen + D * k, ix, vx, nz) : dot_seq(cen + D * k, vx, D);
+                    d /= nrm[k];
+                    d /= vn;
+                    diffs[k] = d;
+                }
+                to = argmax_np(diffs, K);
+                if (diffs[to] < threshold) to = -1;   /* :245-247; NaN < thr is false */
+            }
+            if (to == -1) {                           /* :228-231 (the first row), :250-278 */
+                double *c = cen + D * K;
+                if (sparse) { memset(c, 0, sizeof(double) * D); for (i64 e = 0; e < nz; e++) c[ix[e]] = vx[e]; }
+                else memcpy(c, vx, sizeof(double) * D);
+                cnt[K] = w;
+                nrm[K] = vn;
+                K++;
+                if (K == cap) {
+                    cap += 100;
+                    cen = (double *)realloc(cen, sizeof(double) * cap * D);
+                    nrm = (double *)realloc(nrm, sizeof(double) * cap);
+                    diffs = (double *)realloc(diffs, sizeof(double) * cap);
+                    cnt = (i64 *)realloc(cnt, sizeof(i64) * cap);
+                }
+            } else {                                  /* :283-288 */
+                double *c = cen + D * to;
+                const double nold = (double)cnt[to];
+                for (i64 d = 0; d < D; d++) c[d] *= nold;
+                if (sparse) for (i64 e = 0; e < nz; e++) c[ix[e]] += vx[e];
+                else for (i64 d = 0; d < D; d++) c[d] += vx[d];
+                cnt[to] += w;
+                const double nnew = (double)cnt[to];
+                for (i64 d = 0; d < D; d++) c[d] /= nnew;
+                nrm[to] = sqrt(dot_seq(c, c, D));
+            }
+        }
+        /* :290-299 */
+        if (!oldbuf || K > old_n) {
+            free(oldbuf); free(oldcnt);
+            oldbuf = (double *)malloc(sizeof(double) * K * D);
+            oldcnt = (i64 *)malloc(sizeof(i64) * K);
+        }
+        memcpy(oldbuf, cen, sizeof(double) * K * D);
+        memcpy(oldcnt, cnt, sizeof(i64) * K);
+        old_n = K;
+        if (last == K) { converged = 1; it++; break; } /* :304-306 */
+        last = K;
+    }
+    if (n_iters_out) *n_iters_out = it;
+    free(nrm); free(diffs); free(cnt); free(oldcnt);
+    if (!converged) { free(cen); free(oldbuf); *centers_out = NULL; return -1; }
+    free(oldbuf);
+    *centers_out = cen;
+    return K;
+}
+
+/* util/DotProdClassifier.pyx:129-197 (predict) on CSR rows; same terms in the same order as orc_predict */
+i64 orc_predict_csr(const i64 *indptr, const i64 *indices, const double *values, i64 N, i64 D, const double *centers,
+                    i64 K, double threshold, int normed, i64 *labels, double *confs)
+{
+    double *nc = (double *)malloc(sizeof(double) * K * D);
+    double *diffs = (double *)malloc(sizeof(double) * K);
+    i64 zeros = 0;
+    for (i64 k = 0; k < K; k++) {                     /* :155-161 */
+        const double *c = centers + D * k;
+        if (normed) {
+            double n = sqrt(dot_seq(c, c, D));
+            for (i64 d = 0; d < D; d++) nc[D * k + d] = c[d] / n;
+        } else {
+            memcpy(nc + D * k, c, sizeof(double) * D);
+        }
+    }
+    for (i64 i = 0; i < N; i++) {
+        const i64 *ix = indices + indptr[i];
+        const double *vx = values + indptr[i];
+        const i64 nz = indptr[i + 1] - indptr[i];
+        if (nz == 0) { labels[i] = -1; confs[i] = 0.0; zeros++; continue; }
+        double xn = normed ? sqrt(dot_sparse_self(vx, nz)) : 1.0;
+        for (i64 k = 0; k < K; k++) {                 /* :176-179 */
+            double d = dot_sparse(nc + D * k, ix, vx, nz);
+            if (normed) d /= xn;
+            diffs[k] = fabs(d);
+        }
+        i64 to = argmax_np(diffs, K);
+        double conf = diffs[to];
+        if (conf < threshold) { to = -1; conf = 0.0; } /* :184-186 */
+        labels[i] = to; confs[i] = conf;
+    }
+    free(nc); free(diffs);
+    return zeros;
+}
+
 /*
  * util/DotProdClassifier.pyx:129-197 (predict).  Zero rows get label -1 and a confidence
  * the reference leaves uninitialised (np.empty, :152,:168-172); written as 0.0 here.

@@ -13,6 +13,9 @@ def first(pattern):
 
 bench = json.load(open(os.path.join(src, "bench.json")))
 shutil.copy(os.path.join(src, "bench.json"), "profiles/%s_bench.json" % name)
+for cfg in ("C3", "C4", "C5", "C2h", "C2t"):
+    if os.path.exists(os.path.join(src, "bench_%s.json" % cfg)):
+        shutil.copy(os.path.join(src, "bench_%s.json" % cfg), "profiles/%s_bench_%s.json" % (name, cfg))
 shutil.copy(first("prof/*kernel_stats.csv"), "profiles/%s_kernel_stats.csv" % name)
 rows = [l for l in open(first("prof/*kernel_trace.csv")) if l.startswith('"Kind"') or FILL in l or PRED in l]
 open("profiles/%s_kernel_trace_fill_predict.csv" % name, "w").writelines(rows)
@@ -22,7 +25,7 @@ for sub in ("e2e_c2", "e2e_c5", "dyn"):
     open("profiles/%s_%s.txt" % (name, sub), "w").writelines(lines)
 big = 0
 out = {}
-for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq", None)):
+for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("sq", None), ("f64", "F64")):
     f = first(sub + "/*counter_collection.csv")
     rs = [r for r in csv.DictReader(open(f)) if FILL in r["Kernel_Name"] or PRED in r["Kernel_Name"]]
     big = max(int(r["Grid_Size"]) for r in rs if FILL in r["Kernel_Name"])
@@ -46,9 +49,20 @@ json.dump({"kernel": FILL, "bytes_per_launch": traffic, "fetch_size_kib": fill["
                    "bench.py reports this figure only while the library's hash matches"},
           open("profiles/pmc_traffic.json", "w"), indent=1)
 ions = bench["config"]["frames_per_gpu"] * bench["config"]["n_mobile"]
+# the FP64-VALU side of the roofline: instructions per landmark vector, the FP64 arithmetic among
+# them, and the share of the kernel's cycles in which a SIMD issues a vector instruction (SQ_ACTIVE_INST_VALU counts
+# quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE counts the kernel's cycles on each of the 8 XCDs)
+if "SQ_INSTS_VALU" in fill and "GRBM_GUI_ACTIVE" in fill:
+    floor = sum(fill.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+    json.dump({"kernel": FILL, "config": "C2", "insts_per_ion": round(fill["SQ_INSTS_VALU"] / ions, 2),
+               "floor_insts_per_ion": round(floor / ions, 2), "salu_per_ion": round(fill["SQ_INSTS_SALU"] / ions, 2),
+               "issue_frac": round(fill["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (fill["GRBM_GUI_ACTIVE"] / 8.0), 3),
+               "lib_sha16": open(os.path.join(src, "lib_sha16")).read().strip(), "build": name,
+               "note": "wave instructions per (frame, ion); floor = FP64 add / mul / fma / transcendental instructions; "
+                       "issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs"},
+              open("profiles/pmc_valu.json", "w"), indent=1)
 print("bench value %.4g lvec/s, fill %.4f ms, predict %.4f ms, frac %.4f, frac_step %.4f" % (
     bench["value"], bench["stages_ms"]["fill"], bench["stages_ms"]["predict"], bench["roofline"]["frac"], bench["roofline"]["frac_step"]))
-print("ab", bench.get("ab_kernels"))
 print("cpu", bench.get("cpu_baseline"))
 print("e2e", bench["end_to_end_run"])
 print("traffic GB %.4f (fetch x2 %.4f + write %.4f) vs algorithmic %.4f" % (traffic / 1e9, fill["FETCH_SIZE"] * 2048 / 1e9, fill["WRITE_SIZE"] * 1024 / 1e9, ions * 232 / 1e9))

@@ -147,6 +147,7 @@ class LandmarkAnalysis(object):
         static_idx = np.where(sn.static_mask)[0]
         mobile_idx = np.where(sn.mobile_mask)[0]
         prefit = None
+        self._pipelined = False
         if (comm.size == 1 and self._cluster_algo == "dotprod" and not self.dynamic_lattice_mapping and self._pipeline
                 and hasattr(ctx, "upload_fill_fit")):
             # one process, the ordered dotprod clustering: upload, fill and the first pass of fit_centers as one
@@ -158,6 +159,7 @@ class LandmarkAnalysis(object):
                                                           self.relaxed_lattice_checks, self.check_for_zero_landmarks, thr)
             if fitted:
                 prefit = thr
+            self._pipelined = bool(fitted)      # the pipelined call was taken (tests look at this)
             lap("upload")
         else:
             ctx.set_frames(frames, static_idx, mobile_idx, frame0=frame0)

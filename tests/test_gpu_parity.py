@@ -33,6 +33,26 @@ def case(name):
     return _cases[name]
 
 
+@pytest.fixture(params=["separate", "pipelined"])
+def pipe_mode(request, monkeypatch):
+    """Both ways `LandmarkAnalysis.run` reaches the fill and the first fit pass: the separate calls, and the pipelined
+    `sit_upload_fill_fit` (what a run of >= 8192 frames takes by default) with its chunks cut down to 24 frames so that
+    the reference's short goldens go through it chunked (2 to 16 chunks, the later ones merged as they land)."""
+    if request.param == "separate":
+        monkeypatch.setenv("SITATOR_PIPELINE", "0")
+    else:
+        monkeypatch.setenv("SITATOR_PIPELINE", "1")
+        monkeypatch.setenv("SITATOR_PIPE_CHUNK_FRAMES", "24")
+    return request.param
+
+
+def check_path_taken(la, c, kwargs, mode):
+    """The pipelined call applies to one rank, the dotprod plugin, no dynamic mapping, >= 2 chunks of frames."""
+    applies = (mode == "pipelined" and kwargs.get("clustering_algorithm", "dotprod") == "dotprod"
+               and not kwargs.get("dynamic_lattice_mapping", False) and len(c.frames) >= 48)
+    assert bool(getattr(la, "_pipelined", False)) == applies, "unexpected path: pipelined=%r" % getattr(la, "_pipelined", None)
+
+
 def assert_lvecs(mine, ref):
     assert mine.shape == ref.shape
     assert np.array_equal(mine != 0, ref != 0), "sparsity pattern of the landmark vectors differs"
@@ -82,7 +102,7 @@ def test_dotprod_classifier_against_reference():
 
 
 @pytest.mark.parametrize("name,tag", G.all_runs())
-def test_operator_against_reference_golden(name, tag):
+def test_operator_against_reference_golden(name, tag, pipe_mode):
     from sitator_amd import LandmarkAnalysis, errors
     c = case(name)
     exp = c.out(tag)
@@ -107,6 +127,7 @@ def test_operator_against_reference_golden(name, tag):
             assert list(e.mobile_particles) == list(exp["error_mobile_particles"])
         return
     st = la.run(make_sn(c), c.frames)
+    check_path_taken(la, c, c.kwargs(tag), pipe_mode)
     assert np.array_equal(c.frames, frames_before), "input frames must not be modified"
     assert st.real_trajectory is c.frames
     assert_lvecs(la.landmark_vectors, exp["lvecs"])
@@ -128,7 +149,7 @@ def test_operator_against_reference_golden(name, tag):
 
 
 @pytest.mark.parametrize("name,tag", G.long_runs())
-def test_long_cut_against_reference_golden(name, tag):
+def test_long_cut_against_reference_golden(name, tag, pipe_mode):
     """Cuts of C2 / C3 / C4 / C5 run through the TRUE reference (oracle/make_fixtures.py long_cases): hundreds of frames
     with hops, so the stream holds transition samples that stay unassigned, clusters founded late, and jumps.  C5 runs
     the Markov-clustering plugin and the jump detection on the ragged FCC host (BASELINE configs[4])."""
@@ -145,6 +166,7 @@ def test_long_cut_against_reference_golden(name, tag):
         return
     assert np.mean(exp["labels"] < 0) > 0 and len(exp["jumps"]) >= 1, "the fixture must bite"
     st = la.run(make_sn(c), c.frames)
+    check_path_taken(la, c, c.kwargs(tag), pipe_mode)
     assert np.array_equal(st.traj, exp["labels"]), "site indices must be bit-identical"
     assert np.array_equal(np.bincount(st.traj[st.traj >= 0], minlength=st.site_network.n_sites), exp["counts"])
     m = exp["labels"] >= 0
@@ -249,6 +271,44 @@ def test_pipelined_upload_fill_fit_equals_the_separate_calls():
     assert la_p.n_all_zero_lvecs == la_s.n_all_zero_lvecs
     lo = 64 * 9000
     assert np.array_equal(la_p._ctx.rows_dense(lo, 640), la_s._ctx.rows_dense(lo, 640))
+
+
+@pytest.mark.gpu
+def test_default_path_of_a_long_run_against_the_oracle_directly(oracle):
+    """What a user gets for >= 8192 frames - the pipelined call with its default chunking - compared with the ORACLE,
+    not with the product's other path: the oracle fills the 12 288 frames (blocks on the host's cores), streams the
+    786 432 sparse rows through its CSR `fit_centers` (bit-identical to the dense stream, tests/test_oracle_golden.py,
+    which reproduces the true reference's runs) and assigns them; site indices must be identical, fitted centres and
+    confidences within the float bar."""
+    from concurrent.futures import ThreadPoolExecutor
+    from sitator_amd import synth
+    host = synth.config_host("C2")
+    gen = synth.TrajectoryGenerator(host, 64, seed=88, p_hop=1 / 200.0)
+    frames = gen.generate(12288)
+    la, st = _run_c2(frames, gen, host, True, check_for_zero_landmarks=False)
+    assert la._pipelined, "a 12 288-frame run must take the pipelined call"
+    ref = gen.reference_positions()
+    sidx, midx = np.where(gen.static_mask)[0], np.where(gen.mobile_mask)[0]
+    verts, vcd = oracle.site_vertex_distances(host.cell, host.centers, host.vertices, ref[sidx])
+    D = len(host.centers)
+
+    def block(lo):
+        cut = frames[lo:lo + 256]
+        lv, nz = oracle.fill(host.cell, oracle.wrap_points(host.cell, cut), sidx, midx, ref[sidx], verts, vcd,
+                             check_for_zeros=False)
+        return oracle.to_csr(lv), nz
+
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        parts = list(ex.map(block, range(0, len(frames), 256)))
+    assert la.n_all_zero_lvecs == sum(p[1] for p in parts)
+    out = oracle.cluster_dotprod_csr(oracle.csr_concat([p[0] for p in parts]), D, {}, 0.01 / 64.0)
+    labels = out["cluster-labels"].reshape(len(frames), 64)
+    assert np.mean(labels < 0) > 0, "the run must hold unassigned samples"
+    assert np.array_equal(st.traj, labels), "site indices must be identical to the oracle's"
+    assert np.array_equal(np.bincount(st.traj[st.traj >= 0], minlength=st.site_network.n_sites), out["cluster-size"])
+    np.testing.assert_allclose(np.asarray(la.cluster_centers_), out["cluster-representative-lvecs"], rtol=1e-9, atol=1e-300)
+    m = labels >= 0
+    np.testing.assert_allclose(st.confidences[m], out["cluster-confs"].reshape(labels.shape)[m], rtol=RTOL)
 
 
 @pytest.mark.gpu

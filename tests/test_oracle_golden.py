@@ -144,6 +144,42 @@ def test_long_cuts(oracle, name, tag):
         assert o["site_vertices"] == G.vertices_of(exp["site_vertices"])
 
 
+def test_sparse_stream_equals_dense_stream(oracle):
+    """`fit_centers_csr` / `predict_csr` (the oracle's fit for trajectories too long for the dense stream) add the same
+    terms in the same order as the dense functions: identical bits, on the reference's classifier goldens (zero rows
+    and the NaN-argmax quirk included) ..."""
+    z = G.load("dotprod_known_answers")
+    for X in (z["X"], z["quirk/X"]):
+        csr = oracle.to_csr(X)
+        for thr in (0.45, 0.9):
+            dense = oracle.fit_centers(X, thr)
+            assert np.array_equal(oracle.fit_centers_csr(csr, X.shape[1], thr), dense)
+            la, ca = oracle.predict(X, dense, 0.8, True)
+            lb, cb = oracle.predict_csr(csr, X.shape[1], dense, 0.8, True)
+            assert np.array_equal(la, lb) and np.array_equal(ca, cb)
+
+
+@pytest.mark.parametrize("name", ["c2_long_ortho", "c2h_long", "c2t_long"])
+def test_sparse_stream_reproduces_the_reference_run(oracle, name):
+    """... and on the long cuts the TRUE reference was run on: the oracle's landmark vectors, made sparse and streamed
+    through the CSR fit / predict / min_samples filter, give the reference's labels, counts and confidences."""
+    c = case(name)
+    exp = c.out("dotprod")
+    kw = c.kwargs("dotprod")
+    rs = c.ref_positions[c.static_mask]
+    verts, vcd = oracle.site_vertex_distances(c.cell, c.centers, c.vertices, rs)
+    lv, _ = oracle.fill(c.cell, oracle.wrap_points(c.cell, c.frames), np.where(c.static_mask)[0], np.where(c.mobile_mask)[0],
+                        rs, verts, vcd)
+    n_mobile = int(c.mobile_mask.sum())
+    out = oracle.cluster_dotprod_csr(oracle.to_csr(lv), lv.shape[1], kw.get("clustering_params", {}),
+                                     kw.get("minimum_site_occupancy", 0.01) / float(n_mobile))
+    labels = out["cluster-labels"].reshape(len(c.frames), n_mobile)
+    assert np.array_equal(labels, exp["labels"])
+    assert np.array_equal(out["cluster-size"], exp["counts"])
+    m = exp["labels"] >= 0
+    np.testing.assert_allclose(out["cluster-confs"].reshape(labels.shape)[m], exp["confs"][m], rtol=1e-12, atol=1e-15)
+
+
 @pytest.mark.parametrize("n,seed", [(700, 0), (1500, 1)])
 def test_sparse_markov_clustering_equals_dense(oracle, n, seed):
     """The product's scipy.sparse iteration (graphs of >= 600 landmarks) gives the groups of the dense iteration
