@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
 """Headline benchmark: landmark vectors per second of the fill + site-assignment pass.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5|C2h|C2t] [--frames F] [--algo dotprod|mcl]
 
-Workload (BASELINE.json configs[1], "C2"): synthetic 64-mobile / 512-landmark orthorhombic cell
-(SCgrid(8,8,8), 32.0 x 35.2 x 38.4 A, A = 576 atoms), 100 000 frames PER GPU (weak scaling:
-rank r holds frames [r*F, (r+1)*F) of an N*F-frame trajectory).  One "step" = one pass of the hot
-path over the resident trajectory: wrap + static-lattice check + landmark vector of every
-(frame, mobile ion) + cosine assignment to the fitted site centres -> int64 label + float64
-confidence per (frame, ion).  Frames are resident in HBM before the timed region; the site
-centres come from the product's own end-to-end `run()` on the same trajectory (outside the timed
-region; it is run twice - `end_to_end_run.seconds` is the second, warm run, `cold_seconds` the first one of the
+Workload: one GPU - BASELINE.json configs[1], "C2": synthetic 64-mobile / 512-landmark orthorhombic cell
+(SCgrid(8,8,8), 32.0 x 35.2 x 38.4 A, A = 576 atoms), 100 000 frames; several GPUs - configs[3], "C4": 256-mobile /
+2 048-landmark cell, 1 000 000 frames frame-sharded over 8 GPUs = 125 000 frames PER GPU (weak scaling: rank r holds
+frames [r*F, (r+1)*F) of an N*F-frame trajectory).  `--config` picks any other (C3: 448 mobile, 250 000 frames;
+C5: the ragged FCC host, 62 500 frames per GPU, end-to-end run with the mcl plugin and jump detection; C2h / C2t: the
+C2 shape on a hexagonal / triclinic cell).  One "step" = one pass of the hot path over the resident trajectory: wrap +
+static-lattice check + landmark vector of every (frame, mobile ion) + cosine assignment to the fitted site centres ->
+int64 label + float64 confidence per (frame, ion).  Frames are resident in HBM before the timed region; the site
+centres come from the product's own end-to-end `run()` on the same trajectory (outside the timed region; it is run
+twice - `end_to_end_run.seconds` is the second, warm run incl. jump detection, `cold_seconds` the first one of the
 process).
 
 N > 1: one process per GPU.  Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks come from
@@ -18,15 +20,15 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; a bare `python bench.py --gpus N` sta
 processes, before anything touches a GPU).  The ranks talk through the library's own RCCL entry points
 (`sit_comm_*`, sitator_amd/sharding.py `RcclComm`) - the end-to-end run exercises every exchange step of the path
 (first-offender keys, counts, the ordered fit relay, site-centre anchors and sums, occupancy); the timed pass has no
-collective in it (frames shard embarrassingly) and is bracketed by a barrier on both sides.  A gloo group (CPU) is the
-control plane: it carries the 128-byte RCCL unique id and the ranks' agreement that every one of them got its
-communicator; if one did not, the (tiny) exchange steps run over gloo and `end_to_end_run.exchange` says so.
+collective in it (frames shard embarrassingly) and is bracketed by a barrier on both sides.  The set-up (RCCL unique
+id, the ranks' agreement that every one of them got its communicator) is a TCP channel of the package's own
+(`sharding.Control`): no torch in this file or in the package.  A rank without a communicator ends the run non-zero.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the fill kernel that ran: k_fill3 unless the
-tables force an older generation) with the algorithmic bytes of SURVEY.md section 8(d): B = 24*A/M + 16 bytes per
-landmark vector; `roofline.frac_step` is the same for the whole step (fill + assignment).
-`cpu_baseline` = the oracle's C port of the same pass on a bounded cut, one thread (the reference's execution model)
-and all host cores.
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_fill3 unless the tables force the general
+fallback) with the algorithmic bytes of SURVEY.md section 8(d): B = 24*A/M + 16 bytes per landmark vector;
+`roofline.frac_step` is the same for the whole step (fill + assignment); `roofline.limiter` / `roofline.valu` say what
+the counters say limits the kernel (vector-instruction issue, not HBM).  `cpu_baseline` = the oracle's C port of the
+same pass on a bounded cut, one thread (the reference's execution model) and all host cores.
 """
 import argparse
 import hashlib
@@ -47,10 +49,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=100000, help="frames per GPU")
-    ap.add_argument("--config", default="C2")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default: the configuration's own, below)")
+    ap.add_argument("--config", default=None, help="C2 on one GPU, C4 on several (BASELINE.json configs[1] / configs[3])")
+    ap.add_argument("--algo", default=None, help="clustering plugin of the end-to-end run: dotprod, or mcl (the default of C5)")
     ap.add_argument("--cpu-frames", type=int, default=1000, help="frames per core of the CPU-baseline cut (0 = skip)")
     return ap.parse_args()
+
+
+# frames per GPU: BASELINE.json's trajectory lengths, the 8-GPU configurations cut into their per-GPU share
+FRAMES_PER_GPU = {"C1": 2000, "C1b": 1000, "C2": 100000, "C3": 250000, "C4": 125000, "C5": 62500, "C2h": 100000, "C2t": 100000}
 
 
 def launch_ranks(args):
@@ -94,78 +101,40 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    backend = os.environ.get("SITATOR_BENCH_BACKEND", "rccl")     # "gloo": rehearsal of the N>1 path on a 1-GPU box
+    backend = os.environ.get("SITATOR_BENCH_BACKEND", "rccl")     # "tcp": rehearsal of the N>1 path on a 1-GPU box
     import numpy as np
     from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth, _lib, sharding
 
     comm = None
-    stuck_in_rccl = False           # a thread of this process never came back from RCCL: leave with os._exit at the end
     exchange = "none (single process)"
     if world > 1:
-        # control plane: a gloo group (CPU, TCP) carries the RCCL unique id and the agreement on whether every rank
-        # got its communicator; it is also the fallback for the (tiny) exchange steps if RCCL cannot come up
-        import torch
-        import torch.distributed as dist
-        dist.init_process_group("gloo")
-        ndev = _lib.device_count()
-        if backend != "rccl" or os.environ.get("SITATOR_BENCH_SHARE_GPU") == "1":      # rehearsal: several ranks on one GPU
-            local = local % max(ndev, 1)
-        why = ""
-        if backend == "rccl":
-            uid = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                try:
-                    uid = torch.from_numpy(np.frombuffer(_lib.comm_unique_id(), dtype=np.uint8).copy())
-                except Exception as e:      # noqa: BLE001
-                    why = "%s: %s" % (type(e).__name__, e)
-            dist.broadcast(uid, src=0)          # every rank takes part whatever happened on rank 0
-            # ncclCommInitRank is itself a collective: a rank that cannot take part must say so BEFORE the others
-            # enter it (they would wait for it for ever), so the ranks first agree that every one of them is ready
-            if not why and not bool(uid.any()):
-                why = "no unique id from rank 0"
-            if not why and local >= ndev:
-                why = "LOCAL_RANK %d but only %d GPU(s) visible" % (local, ndev)
-            ready = torch.tensor([0 if why else 1])
-            dist.all_reduce(ready, op=dist.ReduceOp.MIN)
-            if int(ready.item()) == 1:
-                # ... and the call itself runs under a watchdog: a rank stuck in it reports that and carries on
-                import threading
-                box = {}
-
-                def _init():
-                    try:
-                        box["comm"] = sharding.RcclComm(local, rank, world, uid.numpy().tobytes())
-                    except Exception as e:      # noqa: BLE001 - reported, and the run goes on over gloo
-                        box["why"] = "%s: %s" % (type(e).__name__, e)
-
-                th = threading.Thread(target=_init, daemon=True)
-                th.start()
-                limit = float(os.environ.get("SITATOR_RCCL_INIT_TIMEOUT", "120"))
-                th.join(limit)
-                if th.is_alive():
-                    why = "ncclCommInitRank did not return within %.0f s" % limit
-                    stuck_in_rccl = True
-                else:
-                    comm = box.get("comm")
-                    why = box.get("why", "")
-            ok = torch.tensor([1 if comm is not None else 0])
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 1:
-                exchange = "rccl"
-                print("[rank %d/%d] RCCL communicator up on GPU %d" % (rank, world, local), file=sys.stderr, flush=True)
-            else:
-                if comm is not None:
-                    comm.close()
-                reasons = [None] * world
-                dist.all_gather_object(reasons, why)
-                exchange = "gloo (no RCCL communicator: %s)" % "; ".join(sorted({r for r in reasons if r}))[:300]
-                comm = sharding.TorchComm(device="cpu")
-                local = local % max(ndev, 1)        # fewer GPUs than ranks: the ranks share what there is
-                print("[rank %d/%d] %s" % (rank, world, exchange), file=sys.stderr, flush=True)
+        # One process per GPU; the exchange steps run on RCCL through the library's own entry points.  The set-up
+        # (unique id, the ranks' agreement that every one of them has its communicator) is a TCP channel of the
+        # package's own - no torch.  A rank that cannot get its communicator ends the run, on every rank, non-zero.
+        if backend == "tcp":                   # rehearsal on a development box: the ranks share what GPUs there are
+            comm = sharding.TcpComm.from_env()
+            local = local % max(_lib.device_count(), 1)
+            exchange = "tcp (rehearsal: ranks share a GPU, no RCCL communicator)"
         else:
-            comm = sharding.TorchComm(device="cpu")
-            exchange = "gloo"
+            try:
+                comm = sharding.RcclComm.from_env(device=local)
+            except RuntimeError as e:
+                print("[rank %d/%d] %s" % (rank, world, e), file=sys.stderr, flush=True)
+                os._exit(3)                    # a fresh process; _exit because a thread may still sit inside RCCL
+            exchange = "rccl"
+            print("[rank %d/%d] RCCL communicator up on GPU %d" % (rank, world, local), file=sys.stderr, flush=True)
 
+    if args.config is None:
+        args.config = "C2" if world == 1 else "C4"
+    if args.frames is None:
+        args.frames = FRAMES_PER_GPU.get(args.config, 100000)
+    if args.algo is None:
+        args.algo = "mcl" if args.config == "C5" else "dotprod"
+    # C5 with the mcl plugin's defaults puts two ions on one merged site of the synthetic FCC host (the reference
+    # raises MultipleOccupancyError there too: a golden); max_mobile_per_site=2 lets the full pipeline through
+    la_kw = {"clustering_algorithm": args.algo}
+    if args.algo == "mcl":
+        la_kw["max_mobile_per_site"] = 2
     host = synth.config_host(args.config)
     M = synth.CONFIG_MOBILE[args.config]
     S, D = len(host.static_pos), len(host.centers)
@@ -189,16 +158,19 @@ def main():
     # The first run of a process also pays for the HIP runtime, the code objects and the first allocations
     # (`cold_seconds`); the second is what a long-lived analysis process sees per trajectory.
     t0 = time.time()
-    LandmarkAnalysis(verbose=False, device=local, comm=comm).run(sn, frames)
+    LandmarkAnalysis(verbose=False, device=local, comm=comm, **la_kw).run(sn, frames)
     t_cold = time.time() - t0
     if comm is not None:
         comm.barrier()
     t0 = time.time()
-    la = LandmarkAnalysis(verbose=False, device=local, comm=comm)
+    la = LandmarkAnalysis(verbose=False, device=local, comm=comm, **la_kw)
     st_full = la.run(sn, frames)
+    t_run = time.time() - t0
+    n_jumps = sum(1 for _ in st_full.jumps())          # jump detection (SiteTrajectory.py:307-373): configs[4]'s last step
     t_e2e = time.time() - t0
     e2e = {"frames": F * world, "seconds": round(t_e2e, 4), "cold_seconds": round(t_cold, 4),
-           "lvec_per_s": round(world * F * M / t_e2e, 1),
+           "algo": args.algo, "run_seconds": round(t_run, 4), "jump_detection_seconds": round(t_e2e - t_run, 4),
+           "jumps": n_jumps, "lvec_per_s": round(world * F * M / t_e2e, 1),
            "wall_s": {k: round(v, 4) for k, v in la.wall_timings.items()},
            "sites": int(st_full.site_network.n_sites), "unassigned_frac": float(st_full.percent_unassigned),
            "fit": {k: v for k, v in la._ctx.info().items() if k.startswith("fit_")},
@@ -304,9 +276,6 @@ def main():
         comm.barrier()
         if hasattr(comm, "close"):
             comm.close()
-    if stuck_in_rccl:               # interpreter shutdown would wait on the thread that RCCL still holds
-        sys.stderr.flush()
-        os._exit(0)
 
 
 def lib_sha():

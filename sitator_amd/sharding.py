@@ -5,13 +5,17 @@ the ordered ``fit_centers`` state is chained from rank to rank.
 
 ``Comm`` is the tiny interface the host code needs.  ``RcclComm`` implements it on the library's own
 RCCL entry points (``sit_comm_*``, csrc/comm.hip: one communicator per context = per GPU, collectives over
-xGMI on the context's stream); the only thing exchanged outside RCCL is the 128-byte ncclUniqueId, over a
-TCP socket on the node (``MASTER_ADDR`` / ``MASTER_PORT`` + 1...).  ``TorchComm`` (``gloo``) is the CPU test
-double of the same interface: it runs here without a GPU (tests/test_sharded_gloo.py).
+xGMI on the context's stream).  What travels outside RCCL is the set-up only: ``Control`` - one TCP connection per
+rank to rank 0 (``MASTER_ADDR`` / ``MASTER_PORT`` + 1 ...) - carries the 128-byte ncclUniqueId and the ranks' agreement
+that every one of them can enter ``ncclCommInitRank`` (itself a collective: a rank that stays out would leave the
+others waiting in it) and came out of it.  No torch anywhere; the CPU test double of the ``Comm`` interface
+(``gloo``) lives with the tests (tests/torch_comm.py).
 """
+import json
 import os
 import socket
 import struct
+import threading
 import time
 
 import numpy as np
@@ -35,63 +39,172 @@ class Comm(object):
         pass
 
 
-_MAGIC = b"SITATOR-RCCL-ID1"
+_MAGIC = b"SITATOR-CTL1"
 
 
-def _serve_unique_id(uid, world, addr, port0, timeout):
-    """Rank 0: hand the id to the world - 1 other ranks.  Binds the first free port of port0 .. port0 + 15."""
-    srv = None
-    for port in range(port0, port0 + 16):
-        try:
-            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            s.bind((addr, port))
-            s.listen(world)
-            srv = s
-            break
-        except OSError:
-            s.close()
-    if srv is None:
-        raise RuntimeError("no free port in %d..%d for the RCCL id exchange" % (port0, port0 + 15))
-    srv.settimeout(timeout)
-    served = 0
-    try:
-        while served < world - 1:
-            conn, _ = srv.accept()
-            with conn:
-                conn.settimeout(10.0)
+def _send_msg(sock, payload):
+    sock.sendall(struct.pack("<q", len(payload)) + payload)
+
+
+def _recv_exact(sock, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("control connection closed")
+        buf += chunk
+    return buf
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack("<q", _recv_exact(sock, 8))
+    return _recv_exact(sock, n)
+
+
+class Control(object):
+    """The set-up channel of a multi-rank run: every rank keeps one TCP connection to rank 0 (which binds the first
+    free port of port0 .. port0 + 15); ``allgather`` returns every rank's (small) bytes payload in rank order.  Used
+    before the communicator exists and to agree on its fate; the exchange steps of the analysis run on RCCL."""
+
+    def __init__(self, rank, size, addr, port0, timeout=300.0):
+        self.rank, self.size = int(rank), int(size)
+        self.peers = []                    # rank 0: sockets of ranks 1 .. size - 1, in rank order
+        self.sock = None                   # ranks > 0: the socket to rank 0
+        if self.size == 1:
+            return
+        if self.rank == 0:
+            srv = None
+            for port in range(port0, port0 + 16):
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                 try:
-                    hello = conn.recv(len(_MAGIC) + 4)
+                    s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    s.bind((addr, port))
+                    s.listen(self.size)
+                    srv = s
+                    break
                 except OSError:
-                    continue
-                if hello[:len(_MAGIC)] != _MAGIC:
-                    continue
-                conn.sendall(_MAGIC + uid)
-                served += 1
-    finally:
-        srv.close()
-
-
-def _fetch_unique_id(rank, addr, port0, timeout):
-    """Ranks > 0: ask rank 0 (which may not be listening yet, and on any of 16 ports) for the id."""
-    t_end = time.time() + timeout
-    while time.time() < t_end:
-        for port in range(port0, port0 + 16):
+                    s.close()
+            if srv is None:
+                raise RuntimeError("no free port in %d..%d for the control channel" % (port0, port0 + 15))
+            srv.settimeout(timeout)
+            got = {}
             try:
-                with socket.create_connection((addr, port), timeout=2.0) as s:
-                    s.sendall(_MAGIC + struct.pack("<i", rank))
-                    buf = b""
-                    while len(buf) < len(_MAGIC) + 128:
-                        chunk = s.recv(len(_MAGIC) + 128 - len(buf))
-                        if not chunk:
+                while len(got) < self.size - 1:
+                    conn, _ = srv.accept()
+                    conn.settimeout(timeout)
+                    try:
+                        hello = _recv_exact(conn, len(_MAGIC) + 4)
+                    except (OSError, ConnectionError):
+                        conn.close()
+                        continue
+                    r = struct.unpack("<i", hello[len(_MAGIC):])[0] if hello[:len(_MAGIC)] == _MAGIC else -1
+                    if r < 1 or r >= self.size or r in got:
+                        conn.close()
+                        continue
+                    conn.sendall(_MAGIC)
+                    got[r] = conn
+            except socket.timeout:
+                for c in got.values():
+                    c.close()
+                raise RuntimeError("rank 0: only %d of %d ranks connected within %.0f s" % (len(got) + 1, self.size, timeout))
+            finally:
+                srv.close()
+            self.peers = [got[r] for r in range(1, self.size)]
+        else:
+            t_end = time.time() + timeout
+            while self.sock is None and time.time() < t_end:
+                for port in range(port0, port0 + 16):
+                    try:
+                        s = socket.create_connection((addr, port), timeout=2.0)
+                        s.settimeout(10.0)
+                        s.sendall(_MAGIC + struct.pack("<i", self.rank))
+                        if _recv_exact(s, len(_MAGIC)) == _MAGIC:
+                            s.settimeout(timeout)
+                            self.sock = s
                             break
-                        buf += chunk
-                    if buf[:len(_MAGIC)] == _MAGIC and len(buf) == len(_MAGIC) + 128:
-                        return buf[len(_MAGIC):]
-            except OSError:
-                pass
-        time.sleep(0.05)
-    raise RuntimeError("rank %d: no RCCL unique id from rank 0 at %s:%d..%d within %.0f s" % (rank, addr, port0, port0 + 15, timeout))
+                        s.close()
+                    except (OSError, ConnectionError):
+                        pass
+                if self.sock is None:
+                    time.sleep(0.05)
+            if self.sock is None:
+                raise RuntimeError("rank %d: no control channel to rank 0 at %s:%d..%d within %.0f s"
+                                   % (self.rank, addr, port0, port0 + 15, timeout))
+
+    @classmethod
+    def from_env(cls, timeout=300.0):
+        rank = int(os.environ.get("RANK", "0"))
+        size = int(os.environ.get("WORLD_SIZE", "1"))
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        port0 = int(os.environ.get("SITATOR_COMM_PORT", str(int(os.environ.get("MASTER_PORT", "29500")) + 1)))
+        return cls(rank, size, addr, port0, timeout)
+
+    def allgather(self, payload):
+        """[size] list of every rank's bytes."""
+        payload = bytes(payload)
+        if self.size == 1:
+            return [payload]
+        if self.rank == 0:
+            parts = [payload] + [_recv_msg(c) for c in self.peers]
+            blob = json.dumps([p.hex() for p in parts]).encode()
+            for c in self.peers:
+                _send_msg(c, blob)
+            return parts
+        _send_msg(self.sock, payload)
+        return [bytes.fromhex(h) for h in json.loads(_recv_msg(self.sock).decode())]
+
+    def agree(self, ok, why=""):
+        """Every rank says whether it is fine; returns (all fine, the reasons of those that are not)."""
+        msgs = self.allgather(json.dumps({"ok": bool(ok), "why": str(why)}).encode())
+        recs = [json.loads(m.decode()) for m in msgs]
+        return all(r["ok"] for r in recs), ["rank %d: %s" % (i, r["why"]) for i, r in enumerate(recs) if not r["ok"]]
+
+    def close(self):
+        for c in self.peers:
+            c.close()
+        if self.sock is not None:
+            self.sock.close()
+        self.peers, self.sock = [], None
+
+
+class TcpComm(Comm):
+    """The ``Comm`` interface on the control channel alone (every operation is a gather at rank 0 and a broadcast).
+    For rehearsing the multi-rank path where RCCL cannot form a communicator - several ranks sharing one GPU on a
+    development box - never the exchange of a real run: payloads cross the host."""
+
+    def __init__(self, control):
+        self.ctl = control
+        self.rank, self.size = control.rank, control.size
+
+    @classmethod
+    def from_env(cls, timeout=300.0):
+        return cls(Control.from_env(timeout))
+
+    def allgather(self, arr):
+        arr = np.ascontiguousarray(arr)
+        parts = self.ctl.allgather(arr.tobytes())
+        return np.stack([np.frombuffer(p, dtype=arr.dtype).reshape(arr.shape) for p in parts])
+
+    def allreduce_sum(self, arr):
+        arr = np.asarray(arr)
+        with np.errstate(over="ignore"):
+            return self.allgather(arr).sum(axis=0, dtype=arr.dtype).reshape(arr.shape)
+
+    def allreduce_max(self, arr):
+        return self.allgather(np.asarray(arr)).max(axis=0)
+
+    def bcast(self, arr, root=0):
+        arr = np.ascontiguousarray(arr)
+        hdr = json.dumps({"shape": list(arr.shape), "dtype": str(arr.dtype)}).encode() if self.rank == root else b""
+        meta = json.loads(self.ctl.allgather(hdr)[root].decode())
+        data = self.ctl.allgather(arr.tobytes() if self.rank == root else b"")[root]
+        return np.frombuffer(data, dtype=np.dtype(meta["dtype"])).reshape(meta["shape"]).copy()
+
+    def barrier(self):
+        self.ctl.allgather(b"")
+
+    def close(self):
+        self.ctl.close()
 
 
 class RcclComm(Comm):
@@ -106,23 +219,59 @@ class RcclComm(Comm):
         self.ctx.comm_create(unique_id, self.rank, self.size)
 
     @classmethod
-    def from_env(cls, device=None, timeout=300.0):
+    def from_env(cls, device=None, timeout=300.0, init_timeout=None):
         """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as torchrun (or bench.py's own launcher) sets
-        them; ``device`` defaults to LOCAL_RANK."""
+        them; ``device`` defaults to LOCAL_RANK.  The ranks first agree over the control channel that every one of them
+        has a GPU and the id (``ncclCommInitRank`` is a collective: nobody enters it unless everybody will), run it
+        under a watchdog (``SITATOR_RCCL_INIT_TIMEOUT``, 120 s), and agree again that everybody came out with a
+        communicator.  Any rank's failure raises RuntimeError on EVERY rank (a launcher then exits non-zero)."""
         from . import _lib
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
-        rank = int(os.environ.get("RANK", "0"))
-        size = int(os.environ.get("WORLD_SIZE", "1"))
-        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-        port0 = int(os.environ.get("SITATOR_COMM_PORT", str(int(os.environ.get("MASTER_PORT", "29500")) + 1)))
-        if rank == 0:
-            uid = _lib.comm_unique_id()
-            if size > 1:
-                _serve_unique_id(uid, size, addr, port0, timeout)
-        else:
-            uid = _fetch_unique_id(rank, addr, port0, timeout)
-        return cls(device, rank, size, uid)
+        if init_timeout is None:
+            init_timeout = float(os.environ.get("SITATOR_RCCL_INIT_TIMEOUT", "120"))
+        ctl = Control.from_env(timeout)
+        rank, size = ctl.rank, ctl.size
+        why, uid = "", b""
+        try:
+            ndev = _lib.device_count()
+            if int(device) >= ndev:
+                why = "device %d requested but %d GPU(s) visible" % (int(device), ndev)
+            elif rank == 0:
+                uid = _lib.comm_unique_id()
+        except Exception as e:      # noqa: BLE001 - reported to every rank
+            why = "%s: %s" % (type(e).__name__, e)
+        try:
+            ids = ctl.allgather(uid)
+            uid = ids[0]
+            if not why and len(uid) != 128:
+                why = "no unique id from rank 0"
+            fine, reasons = ctl.agree(not why, why)
+            if not fine:
+                raise RuntimeError("RCCL communicator not created: " + "; ".join(reasons))
+            box = {}
+
+            def _init():
+                try:
+                    box["comm"] = cls(device, rank, size, uid)
+                except Exception as e:      # noqa: BLE001
+                    box["why"] = "%s: %s" % (type(e).__name__, e)
+
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(init_timeout)
+            stuck = th.is_alive()
+            why = "ncclCommInitRank did not return within %.0f s" % init_timeout if stuck else box.get("why", "")
+            fine, reasons = ctl.agree(not why, why)
+            if not fine:
+                if box.get("comm") is not None and not stuck:
+                    box["comm"].close()
+                err = RuntimeError("RCCL communicator not created: " + "; ".join(reasons))
+                err.stuck_in_rccl = stuck       # interpreter shutdown would wait on the thread RCCL still holds
+                raise err
+            return box["comm"]
+        finally:
+            ctl.close()
 
     def allreduce_sum(self, arr):
         arr = np.asarray(arr)
@@ -157,59 +306,6 @@ class RcclComm(Comm):
     def close(self):
         self.ctx.comm_destroy()
         self.ctx.close()
-
-
-class TorchComm(Comm):
-    def __init__(self, device=None):
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            raise RuntimeError("torch.distributed is not initialised")
-        self._torch = torch
-        self._dist = dist
-        self.rank = dist.get_rank()
-        self.size = dist.get_world_size()
-        if device is None:
-            device = "cuda" if dist.get_backend() == "nccl" else "cpu"
-        self.device = device
-
-    def _to(self, arr):
-        t = self._torch.from_numpy(np.ascontiguousarray(arr))
-        return t.to(self.device) if self.device != "cpu" else t.clone()
-
-    def allreduce_sum(self, arr):
-        arr = np.asarray(arr)
-        t = self._to(arr)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
-        return t.cpu().numpy().reshape(arr.shape)
-
-    def allgather(self, arr):
-        arr = np.asarray(arr)
-        t = self._to(arr)
-        outs = [self._torch.empty_like(t) for _ in range(self.size)]
-        self._dist.all_gather(outs, t)
-        return np.stack([o.cpu().numpy() for o in outs]).reshape((self.size,) + arr.shape)
-
-    def bcast(self, arr, root=0):
-        arr = np.asarray(arr)
-        # shapes may differ per rank (fit state): send the shape first
-        shp = np.zeros(4, dtype=np.int64)
-        if self.rank == root:
-            shp[0] = arr.ndim
-            shp[1:1 + arr.ndim] = arr.shape
-        ts = self._to(shp)
-        self._dist.broadcast(ts, src=root)
-        shp = ts.cpu().numpy()
-        shape = tuple(int(x) for x in shp[1:1 + int(shp[0])])
-        if self.rank != root:
-            arr = np.zeros(shape, dtype=arr.dtype)
-        t = self._to(arr)
-        if t.numel():
-            self._dist.broadcast(t, src=root)
-        return t.cpu().numpy().reshape(shape)
-
-    def barrier(self):
-        self._dist.barrier()
 
 
 def exact_sum_across(comm, hi, lo):

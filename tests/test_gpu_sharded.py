@@ -22,7 +22,8 @@ def _worker(rank, world, port, case_name, tag, outdir):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure
-    from sitator_amd.sharding import TorchComm, shard_frames
+    from sitator_amd.sharding import shard_frames
+    from tests.torch_comm import TorchComm
     c = G.Case(case_name)
     sn = SiteNetwork(Structure(c.ref_positions, c.cell), c.static_mask, c.mobile_mask)
     sn.centers = c.centers

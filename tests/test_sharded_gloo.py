@@ -35,7 +35,8 @@ def _worker(rank, world, port, case_name, tag, outdir):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from sitator_amd import _lib, errors, LandmarkAnalysis, SiteNetwork, Structure
-    from sitator_amd.sharding import TorchComm, shard_frames
+    from sitator_amd.sharding import shard_frames
+    from tests.torch_comm import TorchComm
     from tests.fake_ctx import FakeContext
     _lib.HipContext = FakeContext                      # no GPU here: oracle-backed test double
     c = G.Case(case_name)
