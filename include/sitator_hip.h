@@ -275,6 +275,12 @@ int sit_comm_allreduce(sit_ctx *ctx, void *buf, int64_t count, int dtype, int op
 int sit_comm_allgather(sit_ctx *ctx, const void *send, void *recv, int64_t nbytes);
 int sit_comm_broadcast(sit_ctx *ctx, void *buf, int64_t nbytes, int root);
 int sit_comm_barrier(sit_ctx *ctx);
+/* The communicator of `comm_ctx` (same device) reduces `ctx`'s mcl statistics where they are: after this call
+ * sit_gram / sit_gram_limbs / sit_weighted_row_sums(_limbs) of `ctx` return the sums over all ranks (the exact
+ * 128-bit accumulators are split into three int64 words on the device, all-reduced with one ncclAllReduce on
+ * `ctx`'s stream and joined with their carries: the same bits for any number of ranks, no host round trip).
+ * comm_ctx = NULL detaches.  (landmark/cluster/mcl.py:53-59,114-122 in a frame-sharded run.)              */
+int sit_comm_attach(sit_ctx *ctx, sit_ctx *comm_ctx);
 
 /* ---- measurement --------------------------------------------------------------------- */
 
@@ -288,7 +294,7 @@ int sit_timers(sit_ctx *ctx, double *ms, int n);
  * delta, [6..8] loose grid, [9..11] tight grid, [12] frames per workgroup of the last fill,
  * [13] steps (speculate / walk / verify / commit) / [14] rows applied one at a time (cluster-founding rows and the
  * rows at a cut) / [15] steps cut short by a wrong speculation, summed over the speculative fits of the context,
- * [16] generation of the fill kernel the last sit_fill launched (1, 2 or 3), [17] survivor slots per wave and
+ * [16] generation of the fill kernel the last sit_fill launched (1 or 3), [17] survivor slots per wave and
  * [18] waves per workgroup of that launch, [19] capacity bits that ended a speculative fit (0: none) and
  * [20] the row it stopped at, [24..27] work census of a SITATOR_DEBUG_STOP=9 fill.                         */
 int sit_info(sit_ctx *ctx, double *out, int n);

@@ -89,6 +89,7 @@ SIGNATURES = {
     "sit_comm_allgather": (C.c_int, [_vp, C.c_void_p, C.c_void_p, i64]),
     "sit_comm_broadcast": (C.c_int, [_vp, C.c_void_p, i64, C.c_int]),
     "sit_comm_barrier": (C.c_int, [_vp]),
+    "sit_comm_attach": (C.c_int, [_vp, _vp]),
     "sit_timers": (C.c_int, [_vp, _dp, C.c_int]),
     "sit_info": (C.c_int, [_vp, _dp, C.c_int]),
     "sit_synchronize": (C.c_int, [_vp]),
@@ -548,6 +549,11 @@ class HipContext(object):
 
     def comm_barrier(self):
         self._check(self.lib.sit_comm_barrier(self._h))
+
+    def comm_attach(self, comm_ctx):
+        """``gram`` / ``weighted_row_sums`` (and their limbs) of this context return the sums over all ranks of
+        ``comm_ctx``'s communicator, reduced on the device (``sit_comm_attach``); ``None`` detaches."""
+        self._check(self.lib.sit_comm_attach(self._h, comm_ctx._h if comm_ctx is not None else None))
 
     def timers(self):
         t = np.zeros(8)

@@ -82,7 +82,14 @@ def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, ver
     n_lmk = X.shape[1]
 
     n_rows = X.shape[0]
-    if comm.size > 1 and hasattr(X.ctx, "gram_limbs"):
+    # RCCL: the exact accumulators are all-reduced where they are (sit_comm_attach); other Comm implementations (the
+    # tests' gloo double) sum the limbs on the host - the same integers either way
+    on_device = comm.size > 1 and hasattr(comm, "ctx") and hasattr(X.ctx, "comm_attach")
+    if on_device:
+        X.ctx.comm_attach(comm.ctx)
+        gram, seen_ntimes = X.ctx.gram()                               # :54-55, summed over the ranks
+        n_rows = int(comm.allreduce_sum(np.array([n_rows], dtype=np.int64))[0])
+    elif comm.size > 1 and hasattr(X.ctx, "gram_limbs"):
         # exact integer accumulators add up across ranks without rounding: same bits for any number of GPUs
         from ..sharding import exact_sum_across
         hi, lo, seen_ntimes = X.ctx.gram_limbs()                       # :54-55
@@ -91,7 +98,7 @@ def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, ver
         gram, seen_ntimes = X.ctx.gram()                               # :54-55
         if comm.size > 1:
             gram = comm.allreduce_sum(gram)
-    if comm.size > 1:
+    if comm.size > 1 and not on_device:
         seen_ntimes = comm.allreduce_sum(seen_ntimes)
         n_rows = int(comm.allreduce_sum(np.array([n_rows], dtype=np.int64))[0])
     cov = gram / n_rows
@@ -152,7 +159,10 @@ def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, ver
 
     # representative landmark vector of each site: confidence-weighted mean of its rows (:114-122)
     weighted = params.get("weighted_representative_landmarks", True)
-    if comm.size > 1 and hasattr(X.ctx, "weighted_row_sums_limbs"):
+    if on_device:
+        sums, wsum = X.ctx.weighted_row_sums(len(groups), weighted=weighted)      # summed over the ranks on the device
+        X.ctx.comm_attach(None)
+    elif comm.size > 1 and hasattr(X.ctx, "weighted_row_sums_limbs"):
         from ..sharding import exact_sum_across
         K = len(groups)
         hi, lo = X.ctx.weighted_row_sums_limbs(K, weighted=weighted)

@@ -842,7 +842,9 @@ extern "C" int sit_fit_push_dense_rows(sit_ctx *c, const double *rows, const i64
 
 // ---- mcl plugin reductions (landmark/cluster/mcl.py:53-59, :80-83, :114-122) ----------------
 
-// G = X^T X accumulated exactly (exact_add, sit_internal.h): the same bits every run
+// G = X^T X accumulated exactly (exact_add, sit_internal.h): the same bits every run.  Only the upper triangle is
+// accumulated (a row's entries ascend in landmark id, so e2 >= e1 is d2 >= d1; v1 * v2 == v2 * v1 bit for bit) and
+// k_gram_mirror copies it below the diagonal: half the integer atomics.
 __global__ void k_gram(const i32 *nnz, const i32 *idx, const double *val, i64 N, i64 D, u64 *Ghi, u64 *Glo, u64 *seen)
 {
     const i64 row = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -852,11 +854,19 @@ __global__ void k_gram(const i32 *nnz, const i32 *idx, const double *val, i64 N,
         const i32 d1 = idx[(i64)e1 * N + row];
         const double v1 = val[(i64)e1 * N + row];
         atomicAdd(&seen[d1], 1ull);
-        for (int e2 = 0; e2 < n; e2++) {
+        for (int e2 = e1; e2 < n; e2++) {
             const i64 q = (i64)d1 * D + idx[(i64)e2 * N + row];
             exact_add(&Ghi[q], &Glo[q], v1 * val[(i64)e2 * N + row]);
         }
     }
+}
+
+__global__ void k_gram_mirror(u64 *hi, u64 *lo, i64 D)
+{
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= D * D) return;
+    const i64 i = q / D, j = q - i * D;
+    if (i > j) { hi[q] = hi[j * D + i]; lo[q] = lo[j * D + i]; }
 }
 
 __global__ void k_limbs_to_double(const u64 *hi, const u64 *lo, i64 n, double *out)
@@ -871,16 +881,19 @@ static int gram_impl(sit_ctx *c, double *G, u64 *hi, u64 *lo, i64 *seen)
     SIT_REQUIRE(c, c->rows_valid, "sit_gram: no landmark rows on the device");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 D = c->D, DD = D * D;
-    int rc = ensure_scratch(c, DD * 24 + D * 8);
+    int rc = ensure_scratch(c, DD * 24 + D * 8 + (c->comm_peer ? DD * 24 : 0));
     if (rc) return rc;
     u64 *dhi = (u64 *)c->d_scratch, *dlo = dhi + DD, *ds = dlo + DD;
     double *dG = (double *)(ds + D);
+    u64 *work = (u64 *)(dG + DD);
     HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(DD * 16 + D * 8), c->stream));
     StageTimer t(c, T_GRAM);
     if (c->N > 0) {
         k_gram<<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dhi, dlo, ds);
+        k_gram_mirror<<<dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, c->stream>>>(dhi, dlo, D);
         HIP_TRY(c, hipGetLastError());
     }
+    if (c->comm_peer && (rc = comm_allreduce_limbs_device(c, dhi, dlo, DD, ds, D, work))) return rc;   // sums over all ranks
     if (G) k_limbs_to_double<<<dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, c->stream>>>(dhi, dlo, DD, dG);
     t.stop();
     if (G) HIP_TRY(c, hipMemcpyAsync(G, dG, (size_t)DD * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1095,16 +1108,18 @@ static int weighted_row_sums_impl(sit_ctx *c, int weighted, i64 K, double *sums,
     SIT_REQUIRE(c, c->rows_valid && c->assign_valid && K > 0, "sit_weighted_row_sums: rows and assignments needed");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 D = c->D, n = K * D + K;
-    int rc = ensure_scratch(c, n * 24);
+    int rc = ensure_scratch(c, n * 24 + (c->comm_peer ? n * 24 : 0));
     if (rc) return rc;
     u64 *dhi = (u64 *)c->d_scratch, *dlo = dhi + n;
     double *dout = (double *)(dlo + n);
+    u64 *work = (u64 *)(dout + n);
     HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(n * 16), c->stream));
     if (c->N > 0) {
         k_weighted_row_sums<<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(
             c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs, c->N, D, K, weighted, dhi, dlo);
         HIP_TRY(c, hipGetLastError());
     }
+    if (c->comm_peer && (rc = comm_allreduce_limbs_device(c, dhi, dlo, n, nullptr, 0, work))) return rc;   // sums over all ranks
     if (sums) {
         k_limbs_to_double<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(dhi, dlo, n, dout);
         HIP_TRY(c, hipMemcpyAsync(sums, dout, (size_t)(K * D) * 8, hipMemcpyDeviceToHost, c->stream));

@@ -168,3 +168,51 @@ extern "C" int sit_comm_barrier(sit_ctx *c)
     int64_t one = 1;
     return sit_comm_allreduce(c, &one, 1, 1, 0);
 }
+
+extern "C" int sit_comm_attach(sit_ctx *c, sit_ctx *comm_ctx)
+{
+    if (!c) return SIT_ERR_INVALID;
+    if (comm_ctx) {
+        SIT_REQUIRE(c, comm_ctx->comm != nullptr, "sit_comm_attach: the other context has no communicator");
+        SIT_REQUIRE(c, comm_ctx->device == c->device, "sit_comm_attach: both contexts must be on one device");
+    }
+    c->comm_peer = comm_ctx;
+    return SIT_OK;
+}
+
+// (hi, lo) -> three int64 words whose sums over <= 2^31 ranks cannot wrap: hi, lo & 0xffffffff, lo >> 32
+__global__ void k_limbs_split(const u64 *hi, const u64 *lo, i64 n, u64 *w)
+{
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const u64 l = lo[q];
+    w[q] = hi[q]; w[n + q] = l & 0xffffffffull; w[2 * n + q] = l >> 32;
+}
+
+// ... and back, the carries of the low word going up (sharding.exact_sum_across does the same on the host)
+__global__ void k_limbs_join(const u64 *w, i64 n, u64 *hi, u64 *lo)
+{
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const u64 s_hi = w[q], s_l0 = w[n + q], s_l1 = w[2 * n + q];
+    const u64 mid = s_l1 + (s_l0 >> 32);
+    lo[q] = (s_l0 & 0xffffffffull) | ((mid & 0xffffffffull) << 32);
+    hi[q] = s_hi + (mid >> 32);
+}
+
+int comm_allreduce_limbs_device(sit_ctx *c, u64 *dhi, u64 *dlo, i64 n, u64 *dseen, i64 nseen, u64 *work)
+{
+    sit_ctx *pc = c->comm_peer;
+    RcclApi *api = rccl();
+    if (!api->err.empty()) { c->msg = api->err; return SIT_ERR_HIP; }
+    SIT_REQUIRE(c, pc && pc->comm, "no communicator attached");
+    if (n > 0) {
+        const unsigned g = (unsigned)((n + 255) / 256);
+        k_limbs_split<<<dim3(g), dim3(256), 0, c->stream>>>(dhi, dlo, n, work);
+        RCCL_TRY(c, api, api->AllReduce(work, work, (size_t)(3 * n), ncclInt64, ncclSum, (ncclComm_t)pc->comm, c->stream));
+        k_limbs_join<<<dim3(g), dim3(256), 0, c->stream>>>(work, n, dhi, dlo);
+        HIP_TRY(c, hipGetLastError());
+    }
+    if (nseen > 0) RCCL_TRY(c, api, api->AllReduce(dseen, dseen, (size_t)nseen, ncclUint64, ncclSum, (ncclComm_t)pc->comm, c->stream));
+    return SIT_OK;
+}

@@ -123,6 +123,7 @@ struct sit_ctx {
     // RCCL communicator of the frame-sharded path (comm.hip); opaque here
     void *comm = nullptr;
     int comm_rank = 0, comm_size = 1;
+    sit_ctx *comm_peer = nullptr;     // sit_comm_attach: the context whose communicator reduces this one's statistics
 
     // scalars on device
     u64 *d_err = nullptr;             // packed first-offender key (atomicMin)
@@ -331,6 +332,9 @@ bool fill3_eligible(sit_ctx *c);
 int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo = 0, i64 f_hi = -1);   // frames [f_lo, f_hi)
 int download_staged(sit_ctx *c, hipStream_t stream, void *dst, const void *src, size_t bytes);   // fill.hip: large read-backs
 int reset_fill_words(sit_ctx *c);                                  // ctx.hip: error key and counters in one launch
+// comm.hip: n exact accumulators (hi, lo) and nseen counters summed over the ranks of c->comm_peer, on c->stream;
+// work = 3 n words of device scratch
+int comm_allreduce_limbs_device(sit_ctx *c, u64 *dhi, u64 *dlo, i64 n, u64 *dseen, i64 nseen, u64 *work);
 int reset_predict_words(sit_ctx *c, bool counts, unsigned *wcount, int nseg); // label counts and wide-row segment lengths in one launch
 int fill3_prepare(sit_ctx *c);     // the allocations of fill3_launch, ahead of time
 int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S, const i64 *mobile_idx, i64 M, i64 frame0);   // ctx.hip

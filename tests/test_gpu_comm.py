@@ -56,17 +56,57 @@ def test_landmark_analysis_on_an_rccl_comm_matches_the_plain_run():
     assert base[3] == got[3]
 
 
-def test_unique_id_exchange_over_the_loopback_socket():
-    """The only bytes that travel outside RCCL: rank 0 serves the ncclUniqueId, the others fetch it (no GPU needed for
-    the sockets themselves; kept here because the id comes from librccl.so)."""
+def test_unique_id_travels_over_the_control_channel():
+    """The set-up bytes outside RCCL: rank 0's ncclUniqueId reaches every rank through `sharding.Control` (kept here
+    because the id comes from librccl.so; the channel itself is tested on CPU in tests/test_control_plane.py)."""
     import threading
     from sitator_amd import _lib, sharding
     uid = _lib.comm_unique_id()
     port0 = 43000 + (os.getpid() % 2000)
     got = {}
-    th = threading.Thread(target=sharding._serve_unique_id, args=(uid, 3, "127.0.0.1", port0, 30.0))
-    th.start()
-    for r in (1, 2):
-        got[r] = sharding._fetch_unique_id(r, "127.0.0.1", port0, 30.0)
-    th.join()
-    assert got[1] == uid and got[2] == uid
+
+    def rank(r):
+        ctl = sharding.Control(r, 3, "127.0.0.1", port0, timeout=30.0)
+        got[r] = ctl.allgather(uid if r == 0 else b"")[0]
+        ctl.close()
+
+    ths = [threading.Thread(target=rank, args=(r,)) for r in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert got[0] == uid and got[1] == uid and got[2] == uid
+
+
+def test_statistics_reduced_on_the_device_keep_their_bits():
+    """`sit_comm_attach`: the mcl plugin's exact accumulators (Gram matrix, weighted row sums) are split into int64
+    words, all-reduced with ncclAllReduce on the analysis context's stream and joined again, all on the device.  On a
+    communicator of one rank the sums must come back bit for bit (split / join and the carries are exercised; more
+    ranks add integers, which commute)."""
+    from sitator_amd import _lib, sharding, synth
+    from tests.test_gpu_kernels import _setup
+    host = synth.config_host("C5")
+    ctx, frames, sm, mm, ref = _setup(host, 160, 60, seed=21)
+    assert ctx.fill(check_for_zeros=False)[0] == 0
+    G0, seen0 = ctx.gram()
+    hi0, lo0, _ = ctx.gram_limbs()
+    X = ctx.rows_dense()
+    K = 7
+    rng = np.random.default_rng(1)
+    cen = rng.uniform(0, 1, size=(K, X.shape[1]))
+    ctx.set_centers(cen / np.linalg.norm(cen, axis=1)[:, None], True)
+    ctx.predict(0.0, fetch=False)
+    s0, w0 = ctx.weighted_row_sums(K, weighted=True)
+    comm = sharding.RcclComm(0, 0, 1, _lib.comm_unique_id())
+    try:
+        ctx.comm_attach(comm.ctx)
+        G1, seen1 = ctx.gram()
+        hi1, lo1, _ = ctx.gram_limbs()
+        s1, w1 = ctx.weighted_row_sums(K, weighted=True)
+        ctx.comm_attach(None)
+    finally:
+        comm.close()
+    assert np.array_equal(G0, G1) and np.array_equal(seen0, seen1)
+    assert np.array_equal(hi0, hi1) and np.array_equal(lo0, lo1)
+    assert np.array_equal(s0, s1) and np.array_equal(w0, w1)
+    assert np.array_equal(G0, G0.T) and np.count_nonzero(G0) > 0
