@@ -250,14 +250,19 @@ int sit_assign_last_known(sit_ctx *ctx, int64_t frame_threshold, const int64_t *
                           const int64_t *time_unknown_in, int64_t *labels_out, int32_t *frame_max,
                           int64_t *stats3, int64_t *last_known_out, int64_t *time_unknown_out);
 
-/* running_windowed_mode (dynamics/SmoothSiteTrajectory.pyx:79-111) of the device labels -> out[F*M].   */
+/* running_windowed_mode (dynamics/SmoothSiteTrajectory.pyx:79-111) of the device labels -> out[F*M]; counts
+ * (optional, [K]) = np.bincount of the smoothed labels >= 0: which sites are left occupied
+ * (dynamics/RemoveUnoccupiedSites.py:31-38 looks for the others).                                        */
 int sit_running_mode(sit_ctx *ctx, int64_t wleft, int64_t wright, int64_t threshold,
-                     int replace_no_winner_unknown, int64_t *out);
+                     int replace_no_winner_unknown, int64_t *out, int64_t K, int64_t *counts);
 
 /* recenter_traj_array (util/RecenterTrajectory.pyx:66-100) IN PLACE on a host array [F,A,3]:
  * x -= sum_j (factor_j*mass_j / sum(factor*mass)) x_j per frame, then += add3 (NULL = 0).              */
 int sit_recenter(sit_ctx *ctx, double *arr, int64_t F, int64_t A, const double *masses,
                  const double *factors, const double *add3);
+/* The same on the frames resident after sit_set_frames, in place on the device (the caller's array stays as it is):
+ * the recentring as a pre-pass of the landmark analysis without a PCIe round trip of the trajectory.      */
+int sit_recenter_resident(sit_ctx *ctx, const double *masses, const double *factors, const double *add3);
 
 /* ---- frame sharding across GPUs ------------------------------------ */
 

@@ -80,7 +80,8 @@ SIGNATURES = {
     "sit_jump_list": (C.c_int, [_vp, C.c_int, _ip, i64, _ip, _ip, _ip]),
     "sit_jump_analysis": (C.c_int, [_vp, i64, _ip, _ip, _dp, _dp, _ip, _ip, _ip, _ip, _ip]),
     "sit_assign_last_known": (C.c_int, [_vp, i64, _ip, _ip, _ip, _i32p, _ip, _ip, _ip]),
-    "sit_running_mode": (C.c_int, [_vp, i64, i64, i64, C.c_int, _ip]),
+    "sit_running_mode": (C.c_int, [_vp, i64, i64, i64, C.c_int, _ip, i64, _ip]),
+    "sit_recenter_resident": (C.c_int, [_vp, _dp, _dp, _dp]),
     "sit_recenter": (C.c_int, [_vp, _dp, i64, i64, _dp, _dp, _dp]),
     "sit_comm_unique_id": (C.c_int, [_u8p]),
     "sit_comm_create": (C.c_int, [_vp, _u8p, C.c_int, C.c_int]),
@@ -172,6 +173,10 @@ class HipContext(object):
             raise RuntimeError("sit_create failed on device %d: %s (is a GPU visible?)" % (device, msg))
         self.D = self.S = self.M = self.F = self.N = self.K = 0
         self.frame0 = 0
+        # who may trust the resident labels (site_trajectory.py): a counter of their rewrites and, when somebody has
+        # looked, (version, content digest) of what is there
+        self.labels_version = 0
+        self.labels_digest = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -287,6 +292,9 @@ class HipContext(object):
                        int(store_rows), int(assign), 1, float(predict_threshold))
         nz = i64(0)
         err = SitError()
+        if assign:
+            self.labels_version += 1
+            self.labels_digest = None
         rc = self.lib.sit_fill(self._h, C.byref(p), C.byref(nz), C.byref(err))
         return rc, nz.value, err
 
@@ -349,6 +357,8 @@ class HipContext(object):
         self._check(self.lib.sit_set_centers(self._h, _d(matrix), self.K, int(bool(normed))))
 
     def predict(self, threshold, fetch=True):
+        self.labels_version += 1
+        self.labels_digest = None
         counts = np.zeros(self.K, dtype=np.int64)
         if fetch:
             labels = np.empty(self.N, dtype=np.int64)
@@ -444,6 +454,8 @@ class HipContext(object):
         return rc, a.value, b.value, c.value, err
 
     def set_assignments(self, labels, confs=None, frame0=0):
+        self.labels_version += 1
+        self.labels_digest = None
         labels = _i64(labels)
         F, M = labels.shape
         c = None if confs is None else _f64(confs)
@@ -494,8 +506,12 @@ class HipContext(object):
                                                C.byref(nprob), _i(lout), _i(tout)))
         return n_ij, tsum, tn, total, nprob.value, lout, tout
 
-    def assign_last_known(self, frame_threshold, last_known_in=None, time_unknown_in=None):
-        labels = np.empty((self.F, self.M), dtype=np.int64)
+    def assign_last_known(self, frame_threshold, last_known_in=None, time_unknown_in=None, out=None):
+        """``out``: a C-contiguous int64 [F, M] array that receives the new labels (else a fresh one)."""
+        labels = np.empty((self.F, self.M), dtype=np.int64) if out is None else out
+        assert labels.dtype == np.int64 and labels.flags.c_contiguous and labels.shape == (self.F, self.M)
+        self.labels_version += 1            # the kernel rewrites the resident labels in place
+        self.labels_digest = None
         fmax = np.zeros(max(self.F, 1), dtype=np.int32)
         st = np.zeros(3, dtype=np.int64)
         lout = np.empty(self.M, dtype=np.int64); tout = np.empty(self.M, dtype=np.int64)
@@ -506,10 +522,13 @@ class HipContext(object):
                                                    fmax.ctypes.data_as(_i32p), _i(st), _i(lout), _i(tout)))
         return labels, fmax[:self.F], st, lout, tout
 
-    def running_mode(self, wleft, wright, threshold, replace_unknown):
+    def running_mode(self, wleft, wright, threshold, replace_unknown, n_sites=0):
+        """The smoothed labels, and (``n_sites`` > 0) how often every site occurs among them."""
         out = np.empty((self.F, self.M), dtype=np.int64)
-        self._check(self.lib.sit_running_mode(self._h, int(wleft), int(wright), int(threshold), int(replace_unknown), _i(out)))
-        return out
+        counts = np.zeros(int(n_sites), dtype=np.int64) if n_sites > 0 else None
+        self._check(self.lib.sit_running_mode(self._h, int(wleft), int(wright), int(threshold), int(replace_unknown), _i(out),
+                                              int(n_sites), None if counts is None else _i(counts)))
+        return (out, counts) if counts is not None else out
 
     def recenter(self, arr, masses, factors, add3=None):
         assert arr.dtype == np.float64 and arr.flags.c_contiguous and arr.ndim == 3 and arr.shape[2] == 3
@@ -517,6 +536,13 @@ class HipContext(object):
         a3 = None if add3 is None else _f64(add3)
         self._check(self.lib.sit_recenter(self._h, _d(arr), arr.shape[0], arr.shape[1], _d(masses), _d(factors),
                                           None if a3 is None else _d(a3)))
+
+    def recenter_resident(self, masses, factors, add3=None):
+        """Recentre the frames resident after ``set_frames`` in place on the device (``sit_recenter_resident``)."""
+        masses = _f64(masses); factors = _f64(factors)
+        assert len(masses) == self.A and len(factors) == self.A
+        a3 = None if add3 is None else _f64(add3)
+        self._check(self.lib.sit_recenter_resident(self._h, _d(masses), _d(factors), None if a3 is None else _d(a3)))
 
     # ---- RCCL exchange of the frame-sharded path (csrc/comm.hip) ----
     def comm_create(self, unique_id, rank, world):

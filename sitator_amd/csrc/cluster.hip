@@ -845,19 +845,32 @@ extern "C" int sit_fit_push_dense_rows(sit_ctx *c, const double *rows, const i64
 // G = X^T X accumulated exactly (exact_add, sit_internal.h): the same bits every run.  Only the upper triangle is
 // accumulated (a row's entries ascend in landmark id, so e2 >= e1 is d2 >= d1; v1 * v2 == v2 * v1 bit for bit) and
 // k_gram_mirror copies it below the diagonal: half the integer atomics.
-__global__ void k_gram(const i32 *nnz, const i32 *idx, const double *val, i64 N, i64 D, u64 *Ghi, u64 *Glo, u64 *seen)
+// `seen` (how many rows hold a landmark) is counted per workgroup in LDS when D fits (LSEEN), else with global atomics
+template <bool LSEEN>
+__global__ __launch_bounds__(256) void k_gram(const i32 *nnz, const i32 *idx, const double *val, i64 N, i64 D, u64 *Ghi, u64 *Glo, u64 *seen)
 {
+    extern __shared__ __attribute__((aligned(16))) char kg_smem[];
+    unsigned *sseen = (unsigned *)kg_smem;
+    if (LSEEN) {
+        for (i64 q = threadIdx.x; q < D; q += 256) sseen[q] = 0u;
+        __syncthreads();
+    }
     const i64 row = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= N) return;
-    const int n = nnz[row];
-    for (int e1 = 0; e1 < n; e1++) {
-        const i32 d1 = idx[(i64)e1 * N + row];
-        const double v1 = val[(i64)e1 * N + row];
-        atomicAdd(&seen[d1], 1ull);
-        for (int e2 = e1; e2 < n; e2++) {
-            const i64 q = (i64)d1 * D + idx[(i64)e2 * N + row];
-            exact_add(&Ghi[q], &Glo[q], v1 * val[(i64)e2 * N + row]);
+    if (row < N) {
+        const int n = nnz[row];
+        for (int e1 = 0; e1 < n; e1++) {
+            const i32 d1 = idx[(i64)e1 * N + row];
+            const double v1 = val[(i64)e1 * N + row];
+            if (LSEEN) atomicAdd(&sseen[d1], 1u); else atomicAdd(&seen[d1], 1ull);
+            for (int e2 = e1; e2 < n; e2++) {
+                const i64 q = (i64)d1 * D + idx[(i64)e2 * N + row];
+                exact_add(&Ghi[q], &Glo[q], v1 * val[(i64)e2 * N + row]);
+            }
         }
+    }
+    if (LSEEN) {
+        __syncthreads();
+        for (i64 q = threadIdx.x; q < D; q += 256) { const unsigned v = sseen[q]; if (v) atomicAdd(&seen[q], (u64)v); }
     }
 }
 
@@ -889,7 +902,10 @@ static int gram_impl(sit_ctx *c, double *G, u64 *hi, u64 *lo, i64 *seen)
     HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(DD * 16 + D * 8), c->stream));
     StageTimer t(c, T_GRAM);
     if (c->N > 0) {
-        k_gram<<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dhi, dlo, ds);
+        if (D * 4 <= 48 * 1024)
+            k_gram<true><<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), (size_t)D * 4, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dhi, dlo, ds);
+        else
+            k_gram<false><<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dhi, dlo, ds);
         k_gram_mirror<<<dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, c->stream>>>(dhi, dlo, D);
         HIP_TRY(c, hipGetLastError());
     }

@@ -304,7 +304,11 @@ __global__ void k_running_mode(const i64 *traj, i64 *out, i64 F, i64 M, i64 wlef
     out[o] = best >= threshold ? winner : (replace_unknown ? -1 : traj[o]);
 }
 
-extern "C" int sit_running_mode(sit_ctx *c, i64 wleft, i64 wright, i64 threshold, int replace_unknown, i64 *out)
+// labels_hist: np.bincount(labels[labels >= 0], minlength = K) of a device label array (fill.hip)
+int label_counts_of(sit_ctx *c, const i64 *d_labels, i64 N, i64 K, i64 *counts_host);
+
+extern "C" int sit_running_mode(sit_ctx *c, i64 wleft, i64 wright, i64 threshold, int replace_unknown, i64 *out, i64 K,
+                                i64 *counts)
 {
     if (!c || !out) return SIT_ERR_INVALID;
     SIT_REQUIRE(c, c->assign_valid && wleft >= 0 && wright >= 0, "sit_running_mode: assignments needed");
@@ -317,6 +321,7 @@ extern "C" int sit_running_mode(sit_ctx *c, i64 wleft, i64 wright, i64 threshold
         c->d_labels, (i64 *)c->d_scratch, c->F, c->M, wleft, wright, threshold, replace_unknown);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (counts && K > 0) return label_counts_of(c, (const i64 *)c->d_scratch, N, K, counts);   // (synchronises)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SIT_OK;
 }
@@ -369,5 +374,31 @@ extern "C" int sit_recenter(sit_ctx *c, double *arr, i64 F, i64 A, const double 
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(arr, d, (size_t)(F * A) * 24, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SIT_OK;
+}
+
+// The same subtraction on the frames ALREADY RESIDENT for the landmark analysis (sit_set_frames), in place on the
+// device: the pre-processing step of util/RecenterTrajectory.pyx:66-100 without the round trip of the trajectory over
+// PCIe.  The caller's host array is not touched.
+extern "C" int sit_recenter_resident(sit_ctx *c, const double *masses, const double *factors, const double *add3)
+{
+    if (!c || !masses || !factors) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, c->d_frames && c->frames_owned && c->A > 0, "sit_recenter_resident: no resident frames (sit_set_frames first)");
+    if (c->F == 0) return SIT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const i64 A = c->A;
+    double tot = 0.0;                                       // :83-92, left to right
+    for (i64 j = 0; j < A; j++) tot += factors[j] * masses[j];
+    const double tmi = 1.0 / tot;
+    std::vector<double> coef((size_t)A);
+    for (i64 j = 0; j < A; j++) coef[(size_t)j] = tmi * factors[j] * masses[j];
+    int rc = ensure_scratch(c, A * 8);
+    if (rc) return rc;
+    double *dc = (double *)c->d_scratch;
+    HIP_TRY(c, hipMemcpyAsync(dc, coef.data(), (size_t)A * 8, hipMemcpyHostToDevice, c->stream));
+    k_recenter<<<dim3((unsigned)c->F), dim3(256), 0, c->stream>>>(c->d_frames, A, dc, add3 ? add3[0] : 0.0, add3 ? add3[1] : 0.0, add3 ? add3[2] : 0.0);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));         // coef lives on this stack frame
+    c->rows_valid = false; c->assign_valid = false; c->map_valid = false; c->tight_valid = false;
     return SIT_OK;
 }

@@ -350,6 +350,29 @@ int sit_label_counts(sit_ctx *c)
     return SIT_OK;
 }
 
+// np.bincount(labels[labels >= 0], minlength=K) of a label array on the device, read back (the histogram sits behind the
+// caller's label array in the scratch buffer when that is where the labels are)
+int label_counts_of(sit_ctx *c, const i64 *d_labels, i64 N, i64 K, i64 *counts_host)
+{
+    SIT_REQUIRE(c, K * 4 <= 150 * 1024, "too many sites for the LDS label histogram");
+    u64 *d_cnt = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&d_cnt, (size_t)K * 8));
+    hipError_t e = hipMemsetAsync(d_cnt, 0, (size_t)K * 8, c->stream);
+    if (e == hipSuccess && N > 0) {
+        const size_t lds = (size_t)K * 4 + 16;
+        e = hipFuncSetAttribute((const void *)k_label_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) {
+            k_label_hist<<<dim3((unsigned)((N + 8191) / 8192)), dim3(256), lds, c->stream>>>(d_labels, N, K, d_cnt);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(counts_host, d_cnt, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_cnt);
+    HIP_TRY(c, e);
+    return SIT_OK;
+}
+
 // np.bincount(traj[traj >= 0], minlength=K) of the device-resident labels (SiteTrajectory.compute_site_occupancies,
 // SiteTrajectory.py:187-202, divides it by the number of frames)
 extern "C" int sit_site_counts(sit_ctx *c, i64 K, i64 *counts)

@@ -102,16 +102,19 @@ class SmoothSiteTrajectory(object):
     def run(self, st, threshold):
         window = self.window_threshold_factor * threshold
         wleft, wright = int(np.floor(window / 2)), int(np.ceil(window / 2))
-        out = st._device().running_mode(wleft, wright, threshold, self.set_unassigned_under_threshold)
-        new = st.copy()
-        new._traj = out
-        new._invalidate_device()
+        n_sites = int(st.site_network.n_sites)
+        res = st._device().running_mode(wleft, wright, threshold, self.set_unassigned_under_threshold, n_sites=n_sites)
+        out, counts = res if n_sites > 0 else (res, np.zeros(0, dtype=np.int64))
+        # a new trajectory around the smoothed labels (adopted, not copied: nothing else holds them), the confidences
+        # shared as the reference's st.copy() shares them (SiteTrajectory.py:31-38 copies the assignments only)
+        new = type(st)(st.site_network.copy(), out, confidences=st._confs, _adopt=True)
+        if st._real_traj is not None:
+            new.set_real_traj(st._real_traj)
         if self.remove_unoccupied_sites:
             # sites left without any assignment are dropped and the rest renumbered in order
-            # (what the reference delegates to dynamics.RemoveUnoccupiedSites)
+            # (what the reference delegates to dynamics.RemoveUnoccupiedSites); which are left comes with the labels
             sn = new.site_network
-            seen = np.zeros(sn.n_sites, dtype=bool)
-            seen[np.unique(out[out >= 0])] = True
+            seen = counts > 0
             if not np.all(seen):
                 n_new = int(np.sum(seen))
                 if n_new < sn.n_mobile:                      # dynamics/RemoveUnoccupiedSites.py:42-47

@@ -57,7 +57,7 @@ class LandmarkAnalysis(object):
                  site_centers_method=SITE_CENTERS_REAL_WEIGHTED, check_for_zero_landmarks=True,
                  static_movement_threshold=1.0, dynamic_lattice_mapping=False,
                  relaxed_lattice_checks=False, max_mobile_per_site=1, force_no_memmap=False,
-                 verbose=True, comm=None, device=None):
+                 verbose=True, comm=None, device=None, recenter_masses=None):
         self._cutoff_midpoint = cutoff_midpoint
         self._cutoff_steepness = cutoff_steepness
         self._minimum_site_occupancy = minimum_site_occupancy
@@ -73,6 +73,12 @@ class LandmarkAnalysis(object):
         self.force_no_memmap = force_no_memmap
         self._comm = comm if comm is not None else Comm()
         self._device = device
+        # Not in the reference (default None = its behaviour): per-atom masses; the frames are recentred on the static
+        # sub-lattice's centre of mass ON THE DEVICE before the analysis - what RecenterTrajectory.run (the step the
+        # reference's own error message recommends, util/RecenterTrajectory.pyx:66-100) does to the host array, without
+        # sending the trajectory over PCIe twice.  The caller's frames (and the real_trajectory of the result) stay as
+        # they are.
+        self._recenter_masses = None if recenter_masses is None else np.asarray(recenter_masses, dtype=np.float64)
         # upload, fill and first fit pass as one pipelined call where that applies (SITATOR_PIPELINE=0: the separate calls)
         self._pipeline = os.environ.get("SITATOR_PIPELINE", "1") != "0"
         self._landmark_vectors = None
@@ -149,7 +155,7 @@ class LandmarkAnalysis(object):
         prefit = None
         self._pipelined = False
         if (comm.size == 1 and self._cluster_algo == "dotprod" and not self.dynamic_lattice_mapping and self._pipeline
-                and hasattr(ctx, "upload_fill_fit")):
+                and self._recenter_masses is None and hasattr(ctx, "upload_fill_fit")):
             # one process, the ordered dotprod clustering: upload, fill and the first pass of fit_centers as one
             # pipelined call (the fit starts on the first frames while the last ones are still being uploaded)
             from .cluster import dotprod as _dp
@@ -163,6 +169,8 @@ class LandmarkAnalysis(object):
             lap("upload")
         else:
             ctx.set_frames(frames, static_idx, mobile_idx, frame0=frame0)
+            if self._recenter_masses is not None:
+                ctx.recenter_resident(self._recenter_masses, np.asarray(sn.static_mask, dtype=np.float64), ctx.cell_centroid)
             lap("upload")
             logger.info("  - computing landmark vectors -")
             rc, n_zero, err = ctx.fill(self.dynamic_lattice_mapping, self.relaxed_lattice_checks,
@@ -218,9 +226,8 @@ class LandmarkAnalysis(object):
         out_st = SiteTrajectory(out_sn, lmk_lbls, lmk_confs, _ctx=ctx, _comm=comm, _adopt=True)
         self.n_multiple_assignments, self.avg_mobile_per_site = out_st.check_multiple_occupancy(
             max_mobile_per_site=self.max_mobile_per_site)
-        # the context is shared with this object (predict() through landmark_vectors rewrites its labels): from here
-        # on the trajectory uploads its own labels before every device-backed operation
-        out_st._labels_shared = True
+        # the context is shared with this object (predict() through landmark_vectors rewrites its labels and bumps
+        # ctx.labels_version): the trajectory re-validates its labels only if that, or an edit of its array, happens
         out_st.set_real_traj(frames)
         lap("occupancy")
         self.timings = ctx.timers()

@@ -9,6 +9,21 @@ import numpy as np
 
 from . import _lib, errors
 
+try:
+    import xxhash as _xxhash
+except ImportError:             # the package is optional: a weaker (but still content-based) digest without it
+    _xxhash = None
+
+
+def _digest(arr):
+    """Content digest of a label array (5 ms per 50 MB): what decides whether the device copy is still current."""
+    a = np.ascontiguousarray(arr)
+    if _xxhash is not None:
+        return (a.shape, _xxhash.xxh3_128_intdigest(memoryview(a).cast("B")))
+    v = a.reshape(-1).view(np.uint64)
+    with np.errstate(over="ignore"):
+        return (a.shape, int(v.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(v * (np.arange(len(v), dtype=np.uint64) | np.uint64(1)))))
+
 
 class SiteTrajectory(object):
     """Site assignment of every mobile particle in every frame."""
@@ -28,9 +43,13 @@ class SiteTrajectory(object):
         self._traj = particle_assignments if _adopt else particle_assignments.copy()
         self._confs = confidences
         self._real_traj = None
-        # device context whose resident assignments equal self._traj (set by LandmarkAnalysis)
+        # Device context that holds (or held) these assignments; it may be shared (with the LandmarkAnalysis that made
+        # it, with copies of this object).  `ctx.labels_version` counts the rewrites of its labels; `_synced_version` is
+        # the version at which they were known to equal `_traj`.  Once the array has been handed out (`_host_shared`) or
+        # the version has moved, the two are compared by content (`_device`).
         self._ctx = _ctx
-        self._labels_shared = False      # see traj / _device
+        self._synced_version = _ctx.labels_version if _ctx is not None else -1
+        self._host_shared = False
         self._comm = _comm
 
     # -- container protocol ---------------------------------------------------------------
@@ -41,6 +60,10 @@ class SiteTrajectory(object):
         st = type(self)(self._sn, self._traj[key], confidences=None if self._confs is None else self._confs[key])
         if self._real_traj is not None:
             st.set_real_traj(self._real_traj[key])
+        if isinstance(key, slice) and key == slice(None) and self._ctx is not None:
+            # a full copy starts with the same labels: it shares the device context (no upload while nothing moves)
+            st._ctx, st._comm = self._ctx, self._comm
+            st._synced_version = -1 if self._host_shared else self._synced_version
         return st
 
     def __getstate__(self):
@@ -54,9 +77,9 @@ class SiteTrajectory(object):
     @property
     def traj(self):
         """The site-assignment array itself, writable as in the reference (editing it in place is normal use there).
-        Once it has been handed out the device copy can no longer be trusted: every device-backed operation
-        uploads the labels again from then on (N * 8 bytes)."""
-        self._labels_shared = True
+        Once it has been handed out the device copy is trusted only after a content comparison (a digest of the array,
+        ~5 ms per 50 MB; an upload only when it differs)."""
+        self._host_shared = True
         return self._traj
 
     @property
@@ -111,7 +134,7 @@ class SiteTrajectory(object):
     def trajectory_for_particle(self, i, return_confidences=False):
         if return_confidences and self._confs is None:
             raise ValueError("This SiteTrajectory has no confidences")
-        self._labels_shared = True              # a view of the label array leaves
+        self._host_shared = True                # a view of the label array leaves
         if return_confidences:
             return self._traj[:, i], self._confs[:, i]
         return self._traj[:, i]
@@ -150,16 +173,23 @@ class SiteTrajectory(object):
         """A context holding this trajectory's CURRENT labels: a fresh upload if there is no context yet, and again
         whenever the label array may have been edited by the caller (``traj`` hands out the array itself; a context
         shared with LandmarkAnalysis may also have been re-predicted)."""
-        if self._ctx is None:
+        ctx = self._ctx
+        if ctx is None:
             cell = self._sn.structure.cell
-            self._ctx = _lib.HipContext(np.asarray(cell, dtype=np.float64))
-            self._ctx.set_assignments(self._traj, self._confs)
-        elif getattr(self, "_labels_shared", True):
-            self._ctx.set_assignments(self._traj, self._confs, frame0=self._ctx.frame0)
-        return self._ctx
+            ctx = self._ctx = _lib.HipContext(np.asarray(cell, dtype=np.float64))
+            ctx.set_assignments(self._traj, self._confs)
+            ctx.labels_digest = (ctx.labels_version, _digest(self._traj)) if self._host_shared else None
+        elif self._host_shared or ctx.labels_version != self._synced_version:
+            d = (ctx.labels_version, _digest(self._traj))
+            if ctx.labels_digest != d:             # the device holds something else, or nobody knows what it holds
+                ctx.set_assignments(self._traj, self._confs, frame0=ctx.frame0)
+                ctx.labels_digest = (ctx.labels_version, d[1])
+        self._synced_version = ctx.labels_version
+        return ctx
 
     def _invalidate_device(self):
         self._ctx = None
+        self._synced_version = -1
 
     def check_multiple_occupancy(self, max_mobile_per_site=1):
         """Count frames x sites holding more than one mobile atom; raise past the allowed maximum.
@@ -213,16 +243,22 @@ class SiteTrajectory(object):
                 if comm.rank == r + 1:
                     lin, tin = halo[0], halo[1]
             labels, fmax, st3 = res[0], res[1], comm.allreduce_sum(res[2])
+            self._traj[...] = labels
             over = np.nonzero(fmax > frame_threshold)[0]
             pair = np.array([ctx.frame0 + over[-1], fmax[over[-1]]] if len(over) else [-1, 0], dtype=np.int64)
             pairs = comm.allgather(pair)
             best = pairs[int(np.argmax(pairs[:, 0]))]
             max_time_unknown = int(best[1]) if best[0] >= 0 else 0
         else:
-            labels, fmax, st3, _, _ = ctx.assign_last_known(frame_threshold)
+            direct = self._traj.flags.c_contiguous and self._traj.dtype == np.int64
+            labels, fmax, st3, _, _ = ctx.assign_last_known(frame_threshold, out=self._traj if direct else None)
+            if not direct:
+                self._traj[...] = labels
             over = np.nonzero(fmax > frame_threshold)[0]
             max_time_unknown = int(fmax[over[-1]]) if len(over) else 0      # the reference keeps the LAST such frame's maximum
-        self._traj[...] = labels
+        # the kernel rewrote the context's labels in place (version bumped): they are this object's new labels
+        self._synced_version = ctx.labels_version
+        ctx.labels_digest = None
         if st3[1] > 0:
             avg = float(st3[0]) / float(st3[1])
             logger.info("  Maximum # of frames any mobile particle spent unassigned: %i" % max_time_unknown)

@@ -35,6 +35,8 @@ class FakeContext(object):
         self.frame0 = 0
         self._fit = (np.zeros((0, 0)), np.zeros(0, dtype=np.int64))
         self._labels = None
+        self.labels_version = 0          # as the real context: rewrites of the resident labels (site_trajectory.py)
+        self.labels_digest = None
 
     def close(self):
         pass
@@ -174,6 +176,8 @@ class FakeContext(object):
         return len(z), (int(z[0]) if len(z) else -1)
 
     def predict(self, threshold, fetch=True):
+        self.labels_version += 1
+        self.labels_digest = None
         X = self.X
         labels = np.full(len(X), -1, dtype=np.int64)
         confs = np.zeros(len(X))
@@ -199,6 +203,8 @@ class FakeContext(object):
         return self._labels.copy(), self._confs.copy(), self._counts.copy()
 
     def set_assignments(self, labels, confs=None, frame0=0):
+        self.labels_version += 1
+        self.labels_digest = None
         labels = np.asarray(labels, dtype=np.int64)
         self.F, self.M = labels.shape
         self.N = self.F * self.M

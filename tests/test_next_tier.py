@@ -197,6 +197,82 @@ def oracle_jumps(traj):
 
 
 @pytest.mark.gpu
+def test_device_labels_are_reused_until_something_changes(oracle):
+    """The labels stay on the device between the operators: no upload while neither the array nor the context moved, one
+    upload after an edit, copies share the context, and an operator that rewrites the resident labels
+    (assign_to_last_known_site on a copy) does not leak into the original."""
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth, _lib
+    host = synth.config_host("C1")
+    frames, sm, mm, ref = synth.make_trajectory(host, 4, 600, seed=23, p_hop=1.0 / 40)
+    sn = SiteNetwork(Structure(ref, host.cell), sm, mm)
+    sn.centers = host.centers
+    sn.vertices = host.vertices
+    st = LandmarkAnalysis(verbose=False).run(sn, frames)
+    uploads = []
+    real = _lib.HipContext.set_assignments
+
+    def counting(self, *a, **k):
+        uploads.append(1)
+        return real(self, *a, **k)
+
+    _lib.HipContext.set_assignments = counting
+    try:
+        base = list(st.jumps())
+        occ = st.compute_site_occupancies()
+        assert list(st.jumps()) == base and len(uploads) == 0, "untouched labels must not be uploaded again"
+        t = st.traj                                           # the array leaves: content decides from here on
+        assert list(st.jumps()) == base and len(uploads) <= 1
+        n = len(uploads)
+        assert list(st.jumps()) == base and len(uploads) == n, "unchanged content must not be uploaded again"
+        st2 = st.copy()                                       # shares the context
+        assert st2._ctx is st._ctx
+        st2.assign_to_last_known_site(frame_threshold=3)      # rewrites the resident labels in place
+        exp2, _ = oracle.assign_to_last_known_site(np.asarray(t), 3)
+        assert np.array_equal(st2.traj, exp2)
+        assert list(st.jumps()) == base, "the original's operators must see the original's labels"
+        assert list(st2.jumps()) == oracle.jumps(exp2)
+        t[50:80, 1] = -1
+        assert list(st.jumps()) == oracle.jumps(np.asarray(t))
+        assert np.array_equal(st.compute_site_occupancies(), np.true_divide(np.bincount(t[t >= 0], minlength=len(occ)), len(t)))
+    finally:
+        _lib.HipContext.set_assignments = real
+
+
+@pytest.mark.gpu
+def test_recentring_as_a_device_pre_pass_equals_recenter_then_run():
+    """LandmarkAnalysis(recenter_masses=...) recentres the resident frames on the device; the result is that of
+    RecenterTrajectory.run on a copy of the frames followed by the plain run, and the caller's frames stay untouched."""
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth, RecenterTrajectory
+    host = synth.config_host("C1b")
+    frames, sm, mm, ref = synth.make_trajectory(host, 4, 400, seed=31, p_hop=1.0 / 50)
+    drift = np.cumsum(np.random.default_rng(3).normal(scale=0.002, size=(len(frames), 1, 3)), axis=0)
+    frames = frames + drift                                   # the whole cell drifts: what recentring removes
+    masses = np.random.default_rng(4).uniform(1.0, 40.0, size=frames.shape[1])
+
+    # the basis is recentred the same way (the static centre of mass goes to the cell centroid): a constant shift
+    ref_rec = ref[None].copy()
+    RecenterTrajectory().run(Structure(ref, host.cell), sm, ref_rec, masses=masses)
+    shift = ref_rec[0, 0] - ref[0]
+
+    def sn_():
+        sn = SiteNetwork(Structure(ref_rec[0], host.cell), sm, mm)
+        sn.centers = np.asarray(host.centers) + shift
+        sn.vertices = host.vertices
+        return sn
+
+    keep = frames.copy()
+    st_a = LandmarkAnalysis(verbose=False, recenter_masses=masses).run(sn_(), frames)
+    assert np.array_equal(frames, keep)
+    rec = frames.copy()
+    RecenterTrajectory().run(Structure(ref, host.cell), sm, rec, masses=masses)
+    # the reference recentres about the static centre of mass and moves it to the cell centroid; the basis must sit there too
+    st_b = LandmarkAnalysis(verbose=False).run(sn_(), rec)
+    assert np.array_equal(st_a.traj, st_b.traj)
+    assert np.array_equal(st_a.confidences, st_b.confidences)
+    np.testing.assert_allclose(np.asarray(st_a.site_network.centers), np.asarray(st_b.site_network.centers), rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
 def test_predict_reports_zero_rows_like_the_reference():
     """All-zero rows: label -1 and a warning; with ignore_zeros=False the reference raises naming the first one."""
     from sitator_amd import DotProdClassifier
