@@ -411,6 +411,7 @@ static int run_predict(sit_ctx *c, double threshold)
     a.col_ptr = c->d_col_ptr; a.col_k = c->d_col_k; a.col_val = c->d_col_val; a.dense = c->d_cen_dense;
     a.labels = c->d_labels; a.confs = c->d_confs;
     a.N = c->rows_N; a.K = c->K; a.D = c->D; a.normed = c->centers_normed; a.threshold = threshold;
+    SIT_REQUIRE(c, c->N < (1LL << 31), "sit_predict: more than 2^31 rows per context (the wide-row list holds 32-bit row numbers)");
     const unsigned grid = (unsigned)((c->N + PRED_BLOCK - 1) / PRED_BLOCK);
     if (c->num_cu <= 0) {
         int v = 0;

@@ -338,34 +338,45 @@ __global__ __launch_bounds__(256) void k_label_hist(const i64 *labels, i64 N, i6
     for (i64 q = threadIdx.x; q < K; q += 256) if (h[q]) atomicAdd(&counts[q], (u64)h[q]);
 }
 
+// more sites than an LDS histogram holds (38 400): straight global atomics
+__global__ __launch_bounds__(256) void k_label_hist_global(const i64 *labels, i64 N, i64 K, u64 *counts)
+{
+    for (i64 r = (i64)blockIdx.x * 256 + threadIdx.x; r < N; r += (i64)gridDim.x * 256) {
+        const i64 l = labels[r];
+        if (l >= 0 && l < K) atomicAdd(&counts[l], 1ull);
+    }
+}
+
+// counts[K] += histogram of labels (the caller zeroes counts)
+static int launch_label_hist(sit_ctx *c, const i64 *d_labels, i64 N, i64 K, u64 *d_counts)
+{
+    if (N <= 0) return SIT_OK;
+    if (K * 4 <= 150 * 1024) {
+        const size_t lds = (size_t)K * 4 + 16;
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_label_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_label_hist<<<dim3((unsigned)((N + 8191) / 8192)), dim3(256), lds, c->stream>>>(d_labels, N, K, d_counts);
+    } else {
+        const i64 blocks = (N + 255) / 256;
+        k_label_hist_global<<<dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, c->stream>>>(d_labels, N, K, d_counts);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return SIT_OK;
+}
+
 int sit_label_counts(sit_ctx *c)
 {
     HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
-    if (c->N == 0) return SIT_OK;
-    SIT_REQUIRE(c, c->K * 4 <= 150 * 1024, "too many sites for the LDS label histogram");
-    const size_t lds = (size_t)c->K * 4 + 16;
-    HIP_TRY(c, hipFuncSetAttribute((const void *)k_label_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_label_hist<<<dim3((unsigned)((c->N + 8191) / 8192)), dim3(256), lds, c->stream>>>(c->d_labels, c->N, c->K, (u64 *)c->d_counts);
-    HIP_TRY(c, hipGetLastError());
-    return SIT_OK;
+    return launch_label_hist(c, c->d_labels, c->N, c->K, (u64 *)c->d_counts);
 }
 
 // np.bincount(labels[labels >= 0], minlength=K) of a label array on the device, read back (the histogram sits behind the
 // caller's label array in the scratch buffer when that is where the labels are)
 int label_counts_of(sit_ctx *c, const i64 *d_labels, i64 N, i64 K, i64 *counts_host)
 {
-    SIT_REQUIRE(c, K * 4 <= 150 * 1024, "too many sites for the LDS label histogram");
     u64 *d_cnt = nullptr;
     HIP_TRY(c, hipMalloc((void **)&d_cnt, (size_t)K * 8));
     hipError_t e = hipMemsetAsync(d_cnt, 0, (size_t)K * 8, c->stream);
-    if (e == hipSuccess && N > 0) {
-        const size_t lds = (size_t)K * 4 + 16;
-        e = hipFuncSetAttribute((const void *)k_label_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) {
-            k_label_hist<<<dim3((unsigned)((N + 8191) / 8192)), dim3(256), lds, c->stream>>>(d_labels, N, K, d_cnt);
-            e = hipGetLastError();
-        }
-    }
+    if (e == hipSuccess && launch_label_hist(c, d_labels, N, K, d_cnt) != SIT_OK) e = hipErrorUnknown;
     if (e == hipSuccess) e = hipMemcpyAsync(counts_host, d_cnt, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_cnt);
@@ -379,17 +390,11 @@ extern "C" int sit_site_counts(sit_ctx *c, i64 K, i64 *counts)
 {
     if (!c || !counts) return SIT_ERR_INVALID;
     SIT_REQUIRE(c, c->assign_valid && K > 0, "sit_site_counts: no assignments on the device");
-    SIT_REQUIRE(c, K * 4 <= 150 * 1024, "too many sites for the LDS label histogram");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = ensure_scratch(c, K * 8);
     if (rc) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)K * 8, c->stream));
-    if (c->N > 0) {
-        const size_t lds = (size_t)K * 4 + 16;
-        HIP_TRY(c, hipFuncSetAttribute((const void *)k_label_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_label_hist<<<dim3((unsigned)((c->N + 8191) / 8192)), dim3(256), lds, c->stream>>>(c->d_labels, c->N, K, (u64 *)c->d_scratch);
-        HIP_TRY(c, hipGetLastError());
-    }
+    if ((rc = launch_label_hist(c, c->d_labels, c->N, K, (u64 *)c->d_scratch))) return rc;
     HIP_TRY(c, hipMemcpyAsync(counts, c->d_scratch, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SIT_OK;
@@ -625,10 +630,20 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
     int nch = (int)(F / chunk_frames_min);
     nch = nch > 16 ? 16 : (nch < 2 ? 2 : nch);
     const i64 cf = (F + nch - 1) / nch;
-    std::vector<hipEvent_t> ev((size_t)nch, nullptr);
-    for (int i = 0; i < nch; i++) HIP_TRY(c, hipEventCreateWithFlags(&ev[(size_t)i], hipEventDisableTiming));
-    hipEvent_t slot_ev[RING_SLOTS] = {};
-    for (int i = 0; i < RING_SLOTS; i++) HIP_TRY(c, hipEventCreateWithFlags(&slot_ev[i], hipEventDisableTiming));
+    // events of the chunks and of the ring slots: destroyed on every way out of this function
+    struct Events {
+        std::vector<hipEvent_t> ev;
+        ~Events() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+        int make(sit_ctx *c, size_t n) {
+            ev.assign(n, nullptr);
+            for (size_t i = 0; i < n; i++) HIP_TRY(c, hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+            return SIT_OK;
+        }
+    } chunk_events, slot_events;
+    if ((rc = chunk_events.make(c, (size_t)nch))) return rc;
+    if ((rc = slot_events.make(c, RING_SLOTS))) return rc;
+    std::vector<hipEvent_t> &ev = chunk_events.ev;
+    hipEvent_t *slot_ev = slot_events.ev.data();
     std::atomic<int> issued(0), failed(0);
     const bool merge = !(getenv("SITATOR_PIPE_MERGE") && getenv("SITATOR_PIPE_MERGE")[0] == '0');
     if (dbgpipe) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "  buffers and tables ready at %.1f ms\n", since()); }
@@ -645,10 +660,9 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
         }
     });
     auto finish = [&](int code) {
+        if (code != SIT_OK) failed.store(1);        // the upload thread skips the chunks it has not started
         up.join();
         (void)hipStreamSynchronize(c->copy_stream);
-        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : slot_ev) if (e) (void)hipEventDestroy(e);
         return code;
     };
     auto wait_chunk = [&](int i) -> int {
@@ -681,7 +695,8 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
         }
         if ((rc = fill3_launch(c, p, true, lo, hi))) return finish(rc);
         if (dbgpipe) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "  chunks %d..%d filled at %.1f ms\n", i, j, since()); }
-        if ((rc = fit_stream_rows(c, lo * M, (hi - lo) * M, fit_threshold))) return finish(rc);
+        { StageTimer tf(c, T_FIT); rc = fit_stream_rows(c, lo * M, (hi - lo) * M, fit_threshold); tf.stop(); }
+        if (rc) return finish(rc);
         i = j + 1;
     }
     timer.stop();

@@ -1287,7 +1287,9 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         bool fits;
         f->ready = false;
         if ((rc = ff_from_dense(c, f, cen.data(), cnt.data(), Kd, &fits))) return rc;
-        if (!fits) { f->valid = false; break; }
+        // a state that was sparse always fits again; if it ever did not, the arena is empty now and carrying on would
+        // continue the fit from nothing: stop instead
+        if (!fits) { f->valid = false; c->msg = "fit: the clustering state did not fit the regrown arena (internal error)"; return SIT_ERR_CAPACITY; }
         f->valid = true;                      // ff_alloc marked the new arena as empty: it now holds the state again
         if (base >= nrows) break;
     }
