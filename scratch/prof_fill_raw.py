@@ -11,4 +11,6 @@ ts = []
 for i in range(int(os.environ.get("F_REPS", "4"))):
     rc, nz, err = ctx.fill(check_for_zeros=False)
     ts.append(ctx.timers()["fill"])
-print("stop", os.environ.get("SITATOR_DEBUG_STOP", "0"), cfg, "F", F, "rc", rc, "fill ms", [round(t, 4) for t in ts], "fpb", ctx.info()["frames_per_workgroup"], "kernel", ctx.info()["fill_kernel"])
+if len(ts) > 12:
+    print("steady fill ms %.4f (median of the last 8 of %d)" % (float(np.median(ts[-8:])), len(ts)))
+print("stop", os.environ.get("SITATOR_DEBUG_STOP", "0"), cfg, "F", F, "rc", rc, "fill ms", [round(t, 4) for t in ts[:6]], "fpb", ctx.info()["frames_per_workgroup"], "kernel", ctx.info()["fill_kernel"])

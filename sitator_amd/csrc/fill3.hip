@@ -886,10 +886,27 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
         return (size_t)f3_layout(fpbv, (int)(S + M), (int)M, nwv, rcapv, iwv, tt, mcap_for(iwv), fpbv == 1 ? 1 : 0).total + 32;
     };
     if (nw != 4 && nw != 8 && nw != 16) {
-        // small frames: 4 waves and several workgroups per CU; a frame that leaves room for one workgroup only: 16
+        // Waves per workgroup: the count that keeps the most waves on a CU (workgroups are admitted by their LDS: the
+        // frame is shared by a workgroup's waves) among those that leave a wave a window of >= 32 ions (or what four
+        // waves would get, if that is less): C2 4 waves x 7 workgroups, C3 8 x 2 (12 % faster than 4 x 3), C4 8 x 2,
+        // C5 4 x 6.
         while (fpb > 1 && lds_bytes(4, fpb, rcap) > 53 * 1024) fpb--;
-        const size_t b4 = lds_bytes(4, fpb, rcap);
-        nw = b4 <= 53 * 1024 ? 4 : (b4 <= 72 * 1024 ? 8 : 16);
+        auto per_wave = [&](int nwv) { const i64 v = ((i64)(nwv == 4 ? fpb : 1) * M + nwv - 1) / nwv; return v > 64 ? (i64)64 : v; };
+        const i64 want = std::min<i64>(32, per_wave(4));
+        int best = 4;
+        i64 best_waves = -1;
+        for (int nwv : {4, 8, 16}) {
+            const size_t b = (lds_bytes(nwv, nwv == 4 ? fpb : 1, rcap) + 1535) / 1024 * 1024;
+            if (b > 160 * 1024) continue;
+            i64 wgs = (i64)((160 * 1024) / b);
+            if (wgs > 8) wgs = 8;
+            i64 waves = wgs * nwv;
+            if (waves > 32) waves = 32;
+            if (per_wave(nwv) < want && nwv != 4) continue;
+            if (waves > best_waves) { best_waves = waves; best = nwv; }
+        }
+        if (best_waves < 0) best = 16;                              // not even one workgroup of four or eight waves fits
+        nw = best;
     }
     if (nw != 4) fpb = 1;                                       // several frames per workgroup only with four waves
     if (rcap_auto) {
