@@ -111,6 +111,7 @@ class SiteTrajectory(object):
         assert np.all(value.mobile_mask == self._sn.mobile_mask)
         assert np.all(value.static_mask == self._sn.static_mask)
         self._sn = value
+        self._host_shared = True         # another network may have fewer sites: consumers look at the labels again
 
     @property
     def real_trajectory(self):
@@ -118,7 +119,7 @@ class SiteTrajectory(object):
 
     def copy(self):
         st = self[:]
-        st.site_network = st.site_network.copy()
+        st._sn = st._sn.copy()           # (not through the setter: the same sites, the labels need no second look)
         return st
 
     def set_real_traj(self, real_traj):
