@@ -23,7 +23,16 @@ size_t pool_env_mb(const char *name, size_t dflt)
     return x < 0 ? dflt : (size_t)x;
 }
 size_t pool_min_bytes() { static const size_t v = pool_env_mb("SITATOR_POOL_MIN_MB", 64) << 20; return v; }
-size_t pool_cap_bytes() { static const size_t v = pool_env_mb("SITATOR_POOL_GB", 64) << 30; return v; }
+// idle buffers kept: SITATOR_POOL_GB if given, else as much as the contexts of this process have held at once (the
+// high-water mark of the pooled buffers in use: one context's worth for a process that analyses one trajectory at a time)
+size_t g_live = 0, g_live_peak = 0;
+bool pool_enabled() { static const bool on = pool_env_mb("SITATOR_POOL_GB", 1) > 0; return on; }
+size_t pool_cap_bytes()
+{
+    static const size_t fixed = pool_env_mb("SITATOR_POOL_GB", (size_t)-1);
+    return fixed != (size_t)-1 ? fixed << 30 : g_live_peak;
+}
+void pool_live(long long delta) { g_live = (size_t)((long long)g_live + delta); if (g_live > g_live_peak) g_live_peak = g_live; }
 
 // idle buffers beyond the cap go back to the driver, least recently used first (call with the lock held)
 void pool_trim(size_t cap)
@@ -51,7 +60,7 @@ hipError_t sit_dmalloc(sit_ctx *c, void **p, size_t bytes)
 {
     *p = nullptr;
     if (bytes == 0) bytes = 8;
-    const bool pooled = bytes >= pool_min_bytes() && pool_cap_bytes() > 0;
+    const bool pooled = bytes >= pool_min_bytes() && pool_enabled();
     if (pooled) {
         std::lock_guard<std::mutex> lock(g_pool_mu);
         int best = -1;
@@ -60,7 +69,7 @@ hipError_t sit_dmalloc(sit_ctx *c, void **p, size_t bytes)
             if (!e.idle || e.device != c->device || e.bytes < bytes || e.bytes > bytes + bytes / 4 + (1 << 20)) continue;
             if (best < 0 || e.bytes < g_pool[(size_t)best].bytes) best = i;
         }
-        if (best >= 0) { g_pool[(size_t)best].idle = false; *p = g_pool[(size_t)best].p; return hipSuccess; }
+        if (best >= 0) { g_pool[(size_t)best].idle = false; pool_live((long long)g_pool[(size_t)best].bytes); *p = g_pool[(size_t)best].p; return hipSuccess; }
     }
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) {
@@ -74,6 +83,7 @@ hipError_t sit_dmalloc(sit_ctx *c, void **p, size_t bytes)
         std::lock_guard<std::mutex> lock(g_pool_mu);
         for (size_t i = 0; i < g_pool.size();) { if (g_pool[i].p == *p) g_pool.erase(g_pool.begin() + (long)i); else i++; }
         g_pool.push_back({*p, bytes, c->device, false, 0ull});
+        pool_live((long long)bytes);
     }
     return hipSuccess;
 }
@@ -90,6 +100,7 @@ void sit_dfree(sit_ctx *c, void *p)
                 if (c && c->stream) (void)hipStreamSynchronize(c->stream);
                 if (c && c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
                 e.idle = true; e.stamp = ++g_pool_clock;
+                pool_live(-(long long)e.bytes);
                 pool_trim(pool_cap_bytes());
                 return;
             }
@@ -421,7 +432,7 @@ int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S, const
     for (i64 i = 1; i < M; i++) if (m32[(size_t)i] != m32[0] + (i32)i) c->idx_contig = false;
     c->idx_s0 = s32[0]; c->idx_m0 = m32[0];
     c->F = F; c->A = A; c->M = M; c->frame0 = frame0; c->N = F * M;
-    c->rows_valid = false; c->assign_valid = false; c->map_valid = false; c->tight_valid = false;
+    c->rows_valid = false; c->assign_valid = false; c->map_valid = false; c->tight_valid = false; c->rows_overflowed = false;
     return SIT_OK;
 }
 

@@ -400,19 +400,77 @@ extern "C" int sit_site_counts(sit_ctx *c, i64 K, i64 *counts)
     return SIT_OK;
 }
 
+// Slots per landmark row.  The loose table's longest list (c->W) bounds a row rigorously but is several times what
+// rows hold (C2: 10 slots for rows of <= 3 entries, C3: 12 B x 10 x 1.1e8 rows = 13 GB).  The width is measured
+// instead: the leading frames are filled into scratch buffers, width = their longest row + 2 (at least 4); a longer row
+// later raises the kernel's capacity flag and the fill is repeated at the rigorous width.  Rows already allocated for
+// this trajectory length keep their width.  SITATOR_ROW_WIDTH=loose: always c->W; =<n>: n slots (tests).
+__global__ __launch_bounds__(256) void k_max_nnz(const i32 *nnz, i64 n, i32 *out)
+{
+    i32 m = 0;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) m = nnz[i] > m ? nnz[i] : m;
+    for (int off = 32; off > 0; off >>= 1) { const i32 o = __shfl_down(m, off); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+
+static int measured_row_width(sit_ctx *c, const sit_fill_params *p, i64 *W_out)
+{
+    *W_out = c->W;
+    if (c->d_row_nnz && c->rows_N == c->N && c->rows_W > 0 && c->rows_W <= c->W && !c->rows_overflowed) { *W_out = c->rows_W; return SIT_OK; }
+    const char *mode = getenv("SITATOR_ROW_WIDTH");
+    if (mode && mode[0] >= '1' && mode[0] <= '9' && !c->rows_overflowed) {      // a given width (tests of the overflow path)
+        const i64 w = atoll(mode);
+        *W_out = w < c->W ? w : c->W;
+        return SIT_OK;
+    }
+    if ((mode && mode[0] == 'l') || c->rows_overflowed || c->W <= 4 || c->F == 0 || p->dynamic_lattice_mapping || !fill3_eligible(c)) return SIT_OK;
+    i64 Fs = (1 << 16) / c->M;
+    Fs = Fs < 16 ? 16 : Fs;
+    if (Fs > c->F) Fs = c->F;
+    const i64 Ns = Fs * c->M, W = c->W;
+    int rc = ensure_scratch(c, Ns * (4 + 12 * W) + 64);
+    if (rc) return rc;
+    i32 *s_nnz = (i32 *)c->d_scratch, *s_idx = s_nnz + Ns, *s_max = s_idx + Ns * W;
+    double *s_val = (double *)(((uintptr_t)(s_max + 2) + 15) & ~(uintptr_t)15);
+    // the context points at the scratch rows while the leading frames are filled
+    i32 *k_nnz = c->d_row_nnz, *k_idx = c->d_row_idx;
+    double *k_val = c->d_row_val;
+    const i64 k_N = c->N, k_W = c->rows_W;
+    const double k_delta = c->tight_delta;
+    c->d_row_nnz = s_nnz; c->d_row_idx = s_idx; c->d_row_val = s_val; c->N = Ns; c->rows_W = W;
+    c->tight_delta = -1.0;                        // the loose table will do (the rows are the same): no table is built for this
+    hipError_t e = hipMemsetAsync(s_max, 0, 4, c->stream);
+    if (e == hipSuccess && (rc = reset_fill_words(c)) == SIT_OK) rc = fill3_launch(c, p, true, 0, Fs);
+    c->d_row_nnz = k_nnz; c->d_row_idx = k_idx; c->d_row_val = k_val; c->N = k_N; c->rows_W = k_W;
+    c->tight_delta = k_delta;
+    HIP_TRY(c, e);
+    if (rc) return rc;
+    k_max_nnz<<<dim3((unsigned)((Ns + 255) / 256 > 256 ? 256 : (Ns + 255) / 256)), dim3(256), 0, c->stream>>>(s_nnz, Ns, s_max);
+    HIP_TRY(c, hipGetLastError());
+    i32 mx = 0;
+    HIP_TRY(c, hipMemcpyAsync(&mx, s_max, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    i64 w = (i64)mx + 2;
+    if (w < 4) w = 4;
+    *W_out = w < W ? w : W;
+    return SIT_OK;
+}
+
 extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, sit_error *err)
 {
     if (!c || !p) return SIT_ERR_INVALID;
     SIT_REQUIRE(c, c->D > 0 && c->d_frames && c->M > 0, "sit_fill: basis and frames must be set first");
     HIP_TRY(c, hipSetDevice(c->device));
     if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
-    const i64 N = c->N, W = c->W;
+    const i64 N = c->N;
+    i64 W = c->W;
     const bool v3 = c->fill_kernel == 3 && fill3_eligible(c);
     bool assign = p->assign != 0;
     bool store = true;   // the assignment is a second kernel that reads the stored rows
     if (assign) SIT_REQUIRE(c, c->K > 0 && c->d_col_ptr, "sit_fill: assign requested but no centres set");
     int rc;
     for (int attempt = 0; attempt < 2; attempt++) {
+        if (store && v3 && (rc = measured_row_width(c, p, &W))) return rc;
         if (store && (c->rows_W != W || c->rows_N != N || !c->d_row_nnz)) {
             c->rows_valid = false;
             if ((rc = dev_alloc(c, &c->d_row_nnz, N))) return rc;
@@ -456,7 +514,12 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         c->fallback_frames = (i64)hs[2];
         const int kind = decode_error(c, hkey, err);
         if (kind != SIT_OK) { c->assign_valid = false; return kind; }
-        if (v3 && hs[3]) { c->assign_valid = false; c->msg = "landmark row wider than the pruning bound (internal error)"; return SIT_ERR_CAPACITY; }
+        if (v3 && hs[3]) {
+            c->assign_valid = false; c->rows_valid = false;
+            if (c->rows_W < c->W && attempt == 0) { c->rows_overflowed = true; continue; }     // a row beyond the measured width: once more at the rigorous one
+            c->msg = "landmark row wider than the pruning bound (internal error)";
+            return SIT_ERR_CAPACITY;
+        }
         return SIT_OK;
     }
     return SIT_ERR_CAPACITY;
@@ -610,7 +673,16 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
     }
     if (dbgpipe) fprintf(stderr, "  frame buffer at %.1f ms\n", since());
     // every allocation first: hipMalloc / hipFree stall the other thread's copies
-    const i64 N = c->N, W = c->W;
+    const i64 N = c->N;
+    i64 W = c->W;
+    if (!(c->d_row_nnz && c->rows_N == N && c->rows_W > 0 && c->rows_W <= c->W) && !c->rows_overflowed) {
+        // the row width is measured on the leading frames (measured_row_width): they go up ahead of the pipeline
+        i64 Fs = (1 << 16) / M;
+        Fs = Fs < 16 ? 16 : (Fs > F ? F : Fs);
+        HIP_TRY(c, hipMemcpyAsync(c->d_frames, frames, (size_t)(Fs * A * 24), hipMemcpyHostToDevice, c->stream));
+        if ((rc = fill3_prepare(c))) return rc;
+        if ((rc = measured_row_width(c, p, &W))) return rc;
+    } else if (c->d_row_nnz && c->rows_N == N && c->rows_W > 0 && c->rows_W <= c->W && !c->rows_overflowed) W = c->rows_W;
     if (c->rows_W != W || c->rows_N != N || !c->d_row_nnz) {
         c->rows_valid = false;
         if ((rc = dev_alloc(c, &c->d_row_nnz, N))) return rc;
@@ -714,7 +786,16 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
     c->fallback_frames = (i64)hs[2];
     const int kind = decode_error(c, hkey, err);
     if (kind != SIT_OK) return kind;
-    if (hs[3]) { c->msg = "landmark row wider than the pruning bound (internal error)"; return SIT_ERR_CAPACITY; }
+    if (hs[3]) {
+        if (c->rows_W < c->W) {
+            // a row beyond the measured width: the separate calls at the rigorous width (the fit starts again with them)
+            c->rows_overflowed = true; c->rows_valid = false;
+            if ((rc = sit_fit_reset(c))) return rc;
+            return sit_fill(c, p, n_all_zero, err);
+        }
+        c->msg = "landmark row wider than the pruning bound (internal error)";
+        return SIT_ERR_CAPACITY;
+    }
     *fitted = 1;
     return SIT_OK;
 }

@@ -92,6 +92,7 @@ struct sit_ctx {
     i32 *d_row_nnz = nullptr, *d_row_idx = nullptr;
     double *d_row_val = nullptr;
     bool rows_valid = false;
+    bool rows_overflowed = false;     // a row was longer than the measured width: this context keeps the rigorous width
 
     // assignment
     i64 *d_labels = nullptr;

@@ -121,6 +121,37 @@ def test_third_generation_launch_shapes_agree(waves, fpb, rcap, iw, contig, tcap
     assert np.array_equal(base, got)
 
 
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_rows_wider_than_the_measured_width_are_filled_again_at_the_rigorous_width(pipeline, monkeypatch):
+    """The rows get as many slots as the leading frames need (+2), not the loose table's longest list; a later row that
+    needs more raises the kernel's capacity flag and the fill is repeated at the rigorous width.  Forced here with a
+    width of 3 on the ragged C5 host (rows hold up to 13 entries): same labels and vectors as with the rigorous width,
+    through the separate calls and through the pipelined call."""
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth
+    host = synth.config_host("C5")
+    gen = synth.TrajectoryGenerator(host, 160, seed=12)
+    frames = gen.generate(96)
+    monkeypatch.setenv("SITATOR_PIPELINE", "1" if pipeline else "0")
+    monkeypatch.setenv("SITATOR_PIPE_CHUNK_FRAMES", "16")
+
+    def run(width):
+        monkeypatch.setenv("SITATOR_ROW_WIDTH", width)
+        sn = SiteNetwork(Structure(gen.reference_positions(), host.cell), gen.static_mask, gen.mobile_mask)
+        sn.centers = host.centers
+        sn.vertices = host.vertices
+        la = LandmarkAnalysis(verbose=False)
+        st = la.run(sn, frames)
+        return st.traj.copy(), st.confidences.copy(), np.asarray(la.landmark_vectors).copy(), la._ctx.row_width()
+
+    t_a, c_a, x_a, w_a = run("loose")
+    t_b, c_b, x_b, w_b = run("3")
+    t_c, c_c, x_c, w_c = run("measure")
+    assert (x_a != 0).sum(axis=1).max() > 3, "the case must overflow a width of 3"
+    assert w_b == w_a and w_c <= w_a and w_c >= (x_a != 0).sum(axis=1).max()
+    for t, c, x in ((t_b, c_b, x_b), (t_c, c_c, x_c)):
+        assert np.array_equal(t_a, t) and np.array_equal(c_a, c) and np.array_equal(x_a, x)
+
+
 def test_fused_assign_equals_fill_then_predict(oracle):
     from sitator_amd import synth
     host = synth.config_host("C2")
