@@ -19,3 +19,12 @@ print("timers(ms)", {k: round(v, 2) for k, v in la.timings.items()})
 print("wall(s)", {k: round(v, 3) for k, v in la.wall_timings.items()})
 print("info", la._ctx.info())
 t = time.time(); nj = sum(1 for _ in st.jumps()); print("jumps", nj, "%.2fs" % (time.time() - t))
+try:                                                        # device memory held by this process (contexts + idle pool)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+    print("device memory in use %.2f GB; rows %d slots x %d rows" % ((total.value - free.value) / 1e9, la._ctx.row_width(), la._ctx.N))
+except Exception as e:
+    print("hipMemGetInfo unavailable:", e)
+t = time.time(); st2 = LandmarkAnalysis(clustering_algorithm=algo, verbose=False).run(sn, frames); print("second run %.3fs" % (time.time() - t))
