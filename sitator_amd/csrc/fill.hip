@@ -45,7 +45,9 @@ __device__ __forceinline__ u64 err_key(i64 frame, i64 S, i64 M, i64 slot)
     return (u64)frame * (u64)(S + 1 + M) + (u64)slot;
 }
 
-template <bool DYN>
+// BIG: a frame's atoms do not fit in LDS (more than ~6 000 atoms): nothing is staged, every vertex position is read
+// from the frame and wrapped where it is used - slow, but any system size runs.
+template <bool DYN, bool BIG>
 __global__ __launch_bounds__(256) void k_fill_rows(FillArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,15 +70,16 @@ __global__ __launch_bounds__(256) void k_fill_rows(FillArgs a)
         const i64 atom = r < S ? a.static_idx[r] : a.mobile_idx[r - S];
         const double *p = a.frames + ((f0 + fl) * a.A + atom) * 3;
         double x = p[0], y = p[1], z = p[2];
+        if (BIG && r >= S) continue;
         wrap3(P, x, y, z);
         if (r < S) {
-            sx[fl * S + r] = x; sy[fl * S + r] = y; sz[fl * S + r] = z;
+            if (!BIG) { sx[fl * S + r] = x; sy[fl * S + r] = y; sz[fl * S + r] = z; }
             if (!DYN) {
                 const double *rp = a.ref_static + 3 * r;
                 const double d = dist_sw(P, rp[0], rp[1], rp[2], x, y, z);
                 if (d > a.static_thr) atomicMin(a.err, err_key(a.frame0 + f0 + fl, S, M, r));
             }
-        } else {
+        } else if (!BIG) {
             mx[fl * M + (r - S)] = x; my[fl * M + (r - S)] = y; mz[fl * M + (r - S)] = z;
         }
     }
@@ -86,7 +89,12 @@ __global__ __launch_bounds__(256) void k_fill_rows(FillArgs a)
     for (i64 t = threadIdx.x; t < (i64)nf * M; t += blockDim.x) {
         const int fl = (int)(t / M);
         const i64 j = t - (i64)fl * M;
-        const double px = mx[fl * M + j], py = my[fl * M + j], pz = mz[fl * M + j];
+        double px, py, pz;
+        if (BIG) {
+            const double *mp = a.frames + ((f0 + fl) * a.A + a.mobile_idx[j]) * 3;
+            px = mp[0]; py = mp[1]; pz = mp[2];
+            wrap3(P, px, py, pz);                                                   // Step 0 (LandmarkAnalysis.py:182-189)
+        } else { px = mx[fl * M + j]; py = my[fl * M + j]; pz = mz[fl * M + j]; }
         const double ox = P.cen[0] - px, oy = P.cen[1] - py, oz = P.cen[2] - pz;   // helpers.pyx:100
         // bin of the (wrapped) ion in fractional coordinates
         double fb0 = (P.ci[0] * px + P.ci[1] * py + P.ci[2] * pz); fb0 -= floor(fb0);
@@ -113,7 +121,13 @@ __global__ __launch_bounds__(256) void k_fill_rows(FillArgs a)
                 if (v < 0) break;
                 nv++;
                 if (DYN) v = lmap[v];
-                double qx = fsx[v] + ox, qy = fsy[v] + oy, qz = fsz[v] + oz;
+                double vx, vy, vz;
+                if (BIG) {
+                    const double *vp = a.frames + ((f0 + fl) * a.A + a.static_idx[v]) * 3;
+                    vx = vp[0]; vy = vp[1]; vz = vp[2];
+                    wrap3(P, vx, vy, vz);
+                } else { vx = fsx[v]; vy = fsy[v]; vz = fsz[v]; }
+                double qx = vx + ox, qy = vy + oy, qz = vz + oz;
                 wrap3(P, qx, qy, qz);                                             // helpers.pyx:103
                 const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
                 const double dist = sqrt((dx * dx + dy * dy) + dz * dz);          // :176
@@ -243,19 +257,20 @@ static int launch_fill_v1(sit_ctx *c, const sit_fill_params *p)
     a.midpoint = c->midpoint; a.steepness = c->steepness; a.rz = c->rz; a.static_thr = c->static_thr;
     // frames per workgroup: aim at ~256 ions per workgroup within the LDS budget
     const i64 per_frame = (S + M) * 24;
-    SIT_REQUIRE(c, per_frame <= 150 * 1024, "sit_fill: one frame's atoms do not fit in LDS");
+    const bool big = per_frame > 150 * 1024;          // a frame's atoms do not fit in LDS: read in place
     i64 fpb = 256 / M; if (fpb < 1) fpb = 1; if (fpb > 16) fpb = 16;
     while (fpb > 1 && fpb * per_frame > 64 * 1024) fpb--;
     a.fpb = (int)fpb;
-    const size_t lds = (size_t)(fpb * per_frame);
+    const size_t lds = big ? 16 : (size_t)(fpb * per_frame);
     const unsigned grid = (unsigned)((c->F + fpb - 1) / fpb);
-    if (p->dynamic_lattice_mapping) {
-        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_fill_rows<true><<<dim3(grid), dim3(256), lds, c->stream>>>(a);
-    } else {
-        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_fill_rows<false><<<dim3(grid), dim3(256), lds, c->stream>>>(a);
-    }
+#define V1_LAUNCH(DY, BG)                                                                                                  \
+    do {                                                                                                               \
+        HIP_TRY(c, hipFuncSetAttribute((const void *)k_fill_rows<DY, BG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        k_fill_rows<DY, BG><<<dim3(grid), dim3(256), lds, c->stream>>>(a);                                             \
+    } while (0)
+    if (p->dynamic_lattice_mapping) { if (big) V1_LAUNCH(true, true); else V1_LAUNCH(true, false); }
+    else { if (big) V1_LAUNCH(false, true); else V1_LAUNCH(false, false); }
+#undef V1_LAUNCH
     HIP_TRY(c, hipGetLastError());
     return SIT_OK;
 }

@@ -749,6 +749,7 @@ bool fill3_eligible(sit_ctx *c)
     if (c->fill_kernel != 3) return false;
     if (c->Vp > 16) return false;
     if (c->D >= (1LL << 22) || c->M > 30000 || c->W > 255) return false;
+    if ((c->S + c->M) * 24 + c->M * 8 > 132 * 1024) return false;      // the frame must leave room for four waves' tables in LDS
     return true;
 }
 

@@ -121,6 +121,28 @@ def test_third_generation_launch_shapes_agree(waves, fpb, rcap, iw, contig, tcap
     assert np.array_equal(base, got)
 
 
+def test_frames_too_large_for_lds_take_the_general_kernel(oracle):
+    """6 859 static atoms + 8 ions = 165 KB per frame: more than a workgroup's LDS holds.  The first-generation kernel
+    then reads every vertex from the frame where it uses it; rows, zero count and the static-lattice error are the
+    oracle's (the reference has no size limit)."""
+    from sitator_amd import synth, _lib
+    host = synth.sc_grid((19, 19, 19), cell=np.diag([76.0, 77.9, 79.8]))
+    ctx, frames, sm, mm, ref = _setup(host, 8, 3, seed=5)
+    rc, nz, err = ctx.fill(check_for_zeros=False)
+    assert rc == 0 and ctx.info()["fill_kernel"] == 1
+    verts, vcd = oracle.site_vertex_distances(host.cell, host.centers, host.vertices, ref[sm])
+    sidx, midx = np.where(sm)[0], np.where(mm)[0]
+    exp, nz_exp = oracle.fill(host.cell, oracle.wrap_points(host.cell, frames), sidx, midx, ref[sm], verts, vcd, check_for_zeros=False)
+    got = ctx.rows_dense()
+    assert nz == nz_exp and np.array_equal(got != 0, exp != 0)
+    np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
+    bad = frames.copy()
+    bad[1, sidx[4321]] += np.array([0.9, 0.7, 0.0])                  # 1.14 A: beyond static_movement_threshold
+    ctx.set_frames(bad, sidx, midx)
+    rc, nz, err = ctx.fill(check_for_zeros=False)
+    assert rc == _lib.E_STATIC_THRESHOLD and (err.frame, err.index) == (1, 4321)
+
+
 @pytest.mark.parametrize("pipeline", [False, True])
 def test_rows_wider_than_the_measured_width_are_filled_again_at_the_rigorous_width(pipeline, monkeypatch):
     """The rows get as many slots as the leading frames need (+2), not the loose table's longest list; a later row that
