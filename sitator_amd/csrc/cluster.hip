@@ -314,7 +314,7 @@ __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_wide(PredArgs a, co
 
 // The wide rows with the CSC arrays in LDS: one persistent workgroup per CU (the wide merge's registers allow three
 // waves per SIMD anyway, so up to ~150 KB of LDS cost no occupancy).  C5: 645 centres x ~12 landmarks = 93 KB.
-#define PRED_WIDE_LDS_BLOCK 768
+#define PRED_WIDE_LDS_BLOCK 1024
 __global__ __launch_bounds__(PRED_WIDE_LDS_BLOCK) void k_predict_rows_wide_lds(PredArgs a, const i32 *wide_list, const unsigned *wide_count,
                                                                               i64 seg_cap, int nseg, int nnzc, u64 *counts)
 {
