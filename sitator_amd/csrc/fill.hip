@@ -712,7 +712,6 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
     if (dbgpipe) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "  row buffers at %.1f ms\n", since()); }
     if ((rc = sit_fit_reset(c))) return rc;
     if ((rc = fill3_prepare(c))) return rc;
-    if (!c->copy_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     // chunks of whole frames: 8 to 16 of them, at least 4096 frames each
     int nch = (int)(F / chunk_frames_min);
     nch = nch > 16 ? 16 : (nch < 2 ? 2 : nch);
