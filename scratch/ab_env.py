@@ -30,7 +30,8 @@ for r in range(R + 1):
         if r: ts[mode].append(dt)
         info = la._ctx.info()
         print(cfg, VAR, mode, "run %.4f s" % dt, "steps", info["fit_batches"], "rewalks", info["fit_rewalks"], "serial rows", info["fit_serial_rows"],
-              "sites", st.site_network.n_sites, flush=True)
+              "sites", st.site_network.n_sites,
+              {k: round(v * 1e3, 1) for k, v in la.wall_timings.items()}, flush=True)
 for mode in ts:
     print(VAR, mode, "median %.4f min %.4f" % (float(np.median(ts[mode])), min(ts[mode])))
 if trace:

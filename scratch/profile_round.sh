@@ -20,5 +20,5 @@ $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/e2e_c5 -o run -- p
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/dyn -o run -- python3 $R/scratch/time_dynamics.py > $O/dyn.log 2>&1 || exit 1
 sha256sum $R/sitator_amd/lib/libsitator_hip.so | cut -c1-16 > $O/lib_sha16
 find $O -name "*.db" -delete
-tail -3 $O/e2e_c2.log $O/e2e_c5.log $O/dyn.log
+tail -n 3 $O/e2e_c2.log $O/e2e_c5.log $O/dyn.log
 echo profile set $tag done
