@@ -291,7 +291,9 @@ int sit_comm_attach(sit_ctx *ctx, sit_ctx *comm_ctx);
 
 /* Device time (ms, HIP events on the library's stream) of the last call of each stage:
  * [0] fill (+assign)  [1] fit  [2] predict  [3] gram  [4] site centres  [5] occupancy
- * [6] H2D of frames.                                                                      */
+ * [6] H2D of frames, [7] unused.  With n = 24: [8, 16) the sums over all calls of each
+ * stage so far and [16, 24) their numbers - a caller that times a loop reads them before
+ * and after instead of once per pass.                                                     */
 int sit_timers(sit_ctx *ctx, double *ms, int n);
 /* Diagnostics of the pruning tables and the last fill: [0] row width (loose table), [1] mean
  * candidates per bin (loose), [2] longest tight list, [3] mean candidates per bin (tight),

@@ -586,6 +586,13 @@ class HipContext(object):
         self.lib.sit_timers(self._h, _d(t), 8)
         return dict(zip(["fill", "fit", "predict", "gram", "site_centers", "occupancy", "h2d"], t))
 
+    def timer_totals(self):
+        """(sum of all laps in ms, number of laps) per stage since the context was made."""
+        t = np.zeros(24)
+        self.lib.sit_timers(self._h, _d(t), 24)
+        names = ["fill", "fit", "predict", "gram", "site_centers", "occupancy", "h2d"]
+        return {k: (float(t[8 + i]), int(t[16 + i])) for i, k in enumerate(names)}
+
     def info(self):
         v = np.zeros(28)
         self.lib.sit_info(self._h, _d(v), 28)

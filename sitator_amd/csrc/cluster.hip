@@ -391,7 +391,60 @@ extern "C" int sit_set_centers(sit_ctx *c, const double *centers, i64 K, int nor
     return SIT_OK;
 }
 
-static int run_predict(sit_ctx *c, double threshold)
+// Launch shape of the assignment pass and its counters in the scratch buffer (the label counts, one length word per
+// segment of the wide-row list).
+struct PredPlan {
+    bool narrow_lds, wide_lds;
+    int nt, per_cu, nseg;
+    i64 seg_cap;
+    size_t lds, csc;
+    unsigned *wcount;
+    i32 *wlist;
+};
+
+static int predict_plan(sit_ctx *c, PredPlan &p)
+{
+    if (c->num_cu <= 0) {
+        int v = 0;
+        c->num_cu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0 ? v : 256;
+    }
+    const int ncu = c->num_cu;
+    p.csc = (size_t)c->csc_nnz * 12 + (size_t)(c->D + 1) * 4 + 16;
+    p.lds = p.csc + (size_t)c->K * 4;
+    const char *pl = getenv("SITATOR_PREDICT_LDS");                 // "0": keep the centres in global memory (A/B, tests)
+    const bool no_lds = pl && pl[0] == '0';
+    p.narrow_lds = p.lds <= 150 * 1024 && !no_lds;
+    p.wide_lds = p.csc <= 150 * 1024 && !no_lds;
+    // the listing kernel: persistent workgroups, each with its own segment of the wide-row list
+    // LDS: three or four workgroups of 512 threads per CU; larger centre sets (C3: 1 044 centres, 109 KB) leave room
+    // for two or one, of 1024 threads (from global memory C3's assignment took 2.1 ms per 4.5e7 rows)
+    p.nt = !p.narrow_lds ? PRED_BLOCK : (p.lds <= 52 * 1024 ? PRED_LDS_BLOCK : 1024);
+    p.per_cu = !p.narrow_lds ? 8 : (p.lds <= 36 * 1024 ? 4 : (p.lds <= 52 * 1024 ? 3 : (p.lds <= 78 * 1024 ? 2 : 1)));
+    const i64 blocks = (c->N + p.nt - 1) / p.nt;
+    p.nseg = (int)std::min<i64>(blocks, (i64)ncu * p.per_cu);
+    p.seg_cap = (blocks + p.nseg - 1) / p.nseg * p.nt;             // rows a workgroup can meet
+    int rc = ensure_scratch(c, ((i64)p.nseg * p.seg_cap + p.nseg + 64) * 4);
+    if (rc) return rc;
+    p.wcount = (unsigned *)c->d_scratch;
+    p.wlist = (i32 *)c->d_scratch + ((p.nseg + 63) / 64 * 64);
+    return SIT_OK;
+}
+
+// sit_fill with assign = 1: the words of the fill and of the assignment behind it in ONE launch, ahead of the fill
+// kernel (a launch costs ~6 us of a 1 ms step).  *done = false: the assignment resets its own (dense fall-back, no rows).
+int predict_reset_with_fill(sit_ctx *c, bool *done)
+{
+    *done = false;
+    if (c->N <= 0 || c->K <= 0 || c->max_col > PRED_MAXCOL) return reset_fill_words(c);
+    PredPlan pp;
+    int rc = predict_plan(c, pp);
+    if (rc) return rc;
+    if ((rc = reset_step_words(c, pp.narrow_lds, pp.wcount, pp.nseg))) return rc;
+    *done = true;
+    return SIT_OK;
+}
+
+static int run_predict(sit_ctx *c, double threshold, bool words_reset = false)
 {
     SIT_REQUIRE(c, c->rows_valid, "predict: no landmark rows on the device (run sit_fill with store_rows)");
     SIT_REQUIRE(c, c->K > 0 && c->d_col_ptr, "predict: no centres set");
@@ -421,24 +474,18 @@ static int run_predict(sit_ctx *c, double threshold)
     StageTimer t(c, T_PREDICT);
     bool counted = false;
     if (c->max_col <= PRED_MAXCOL) {
-        const size_t csc = (size_t)c->csc_nnz * 12 + (size_t)(c->D + 1) * 4 + 16, lds = csc + (size_t)c->K * 4;
-        const char *pl = getenv("SITATOR_PREDICT_LDS");                 // "0": keep the centres in global memory (A/B, tests)
-        const bool no_lds = pl && pl[0] == '0';
-        const bool narrow_lds = lds <= 150 * 1024 && !no_lds, wide_lds = csc <= 150 * 1024 && !no_lds;
-        // the listing kernel: persistent workgroups, each with its own segment of the wide-row list
-        // LDS: three or four workgroups of 512 threads per CU; larger centre sets (C3: 1 044 centres, 109 KB) leave room
-        // for two or one, of 1024 threads (from global memory C3's assignment took 2.1 ms per 4.5e7 rows)
-        const int nt = !narrow_lds ? PRED_BLOCK : (lds <= 52 * 1024 ? PRED_LDS_BLOCK : 1024);
-        const int per_cu = !narrow_lds ? 8 : (lds <= 36 * 1024 ? 4 : (lds <= 52 * 1024 ? 3 : (lds <= 78 * 1024 ? 2 : 1)));
-        const i64 blocks = (c->N + nt - 1) / nt;
-        const int nseg = (int)std::min<i64>(blocks, (i64)ncu * per_cu);
-        const i64 seg_cap = (blocks + nseg - 1) / nseg * nt;           // rows a workgroup can meet
-        if ((rc = ensure_scratch(c, ((i64)nseg * seg_cap + nseg + 64) * 4))) return rc;
-        unsigned *wcount = (unsigned *)c->d_scratch;
-        i32 *wlist = (i32 *)c->d_scratch + ((nseg + 63) / 64 * 64);
-        if (getenv("SITATOR_DEBUG_SHAPE")) fprintf(stderr, "predict: lds %zu nt %d per_cu %d nseg %d seg_cap %lld narrow_lds %d wide_lds %d rows_W %lld\n", lds, nt, per_cu, nseg, (long long)seg_cap, (int)narrow_lds, (int)wide_lds, (long long)c->rows_W);
+        PredPlan pp;
+        if ((rc = predict_plan(c, pp))) return rc;
+        const bool narrow_lds = pp.narrow_lds, wide_lds = pp.wide_lds;
+        const int nt = pp.nt, nseg = pp.nseg;
+        const i64 seg_cap = pp.seg_cap;
+        const size_t lds = pp.lds, csc = pp.csc;
+        unsigned *wcount = pp.wcount;
+        i32 *wlist = pp.wlist;
+        if (getenv("SITATOR_DEBUG_SHAPE")) fprintf(stderr, "predict: lds %zu nt %d per_cu %d nseg %d seg_cap %lld narrow_lds %d wide_lds %d rows_W %lld\n", lds, nt, pp.per_cu, nseg, (long long)seg_cap, (int)narrow_lds, (int)wide_lds, (long long)c->rows_W);
         u64 *cnt = narrow_lds ? (u64 *)c->d_counts : nullptr;            // the LDS kernel counts the labels on the way
-        if ((rc = reset_predict_words(c, narrow_lds, wcount, nseg))) return rc;
+        // sit_fill with assign = 1 has reset these words together with its own, ahead of the fill kernel
+        if (!words_reset && (rc = reset_predict_words(c, narrow_lds, wcount, nseg))) return rc;
         if (narrow_lds) {
             if (nt == PRED_LDS_BLOCK) {
                 HIP_TRY(c, lds_limit((const void *)k_predict_rows_lds<PRED_LDS_BLOCK>, lds, c->device));
@@ -465,7 +512,7 @@ static int run_predict(sit_ctx *c, double threshold)
     return SIT_OK;
 }
 
-int sit_predict_internal(sit_ctx *c, double threshold) { return run_predict(c, threshold); }
+int sit_predict_internal(sit_ctx *c, double threshold, bool words_reset) { return run_predict(c, threshold, words_reset); }
 
 extern "C" int sit_get_assignments(sit_ctx *c, i64 *labels, double *confs, i64 *counts)
 {

@@ -124,6 +124,23 @@ __global__ void k_reset_predict_words(u64 *counts, i64 K, unsigned *wcount, int 
     if (i < nseg) wcount[i] = 0u;
 }
 
+__global__ void k_reset_step_words(u64 *err_block, u64 *counts, i64 K, unsigned *wcount, int nseg)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) err_block[0] = ~0ull;
+    else if (i <= 16) err_block[i] = 0ull;
+    if (i < K) counts[i] = 0ull;
+    if (i < nseg) wcount[i] = 0u;
+}
+
+int reset_step_words(sit_ctx *c, bool counts, unsigned *wcount, int nseg)
+{
+    const i64 K = counts ? c->K : 0, n = std::max<i64>(std::max<i64>(K, nseg), 17);
+    k_reset_step_words<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_err, (u64 *)c->d_counts, K, wcount, nseg);
+    HIP_TRY(c, hipGetLastError());
+    return SIT_OK;
+}
+
 int reset_fill_words(sit_ctx *c)
 {
     k_reset_fill_words<<<dim3(1), dim3(64), 0, c->stream>>>(c->d_err);
@@ -239,7 +256,8 @@ extern "C" int sit_timers(sit_ctx *c, double *ms, int n)
     if (!c || !ms) return SIT_ERR_INVALID;
     (void)hipSetDevice(c->device);
     for (int i = 0; i < T_N; i++) stage_timer_resolve(c, i);
-    for (int i = 0; i < n; i++) ms[i] = i < T_N ? c->timers[i] : 0.0;
+    // [0, T_N): the last lap of every stage; [T_N, 2 T_N): the sum of all its laps; [2 T_N, 3 T_N): their number
+    for (int i = 0; i < n; i++) ms[i] = i < T_N ? c->timers[i] : (i < 2 * T_N ? c->timer_sum[i - T_N] : (i < 3 * T_N ? c->timer_cnt[i - 2 * T_N] : 0.0));
     return SIT_OK;
 }
 

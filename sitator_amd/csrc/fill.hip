@@ -502,7 +502,9 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
             c->assign_N = N;
         }
         if (v3 && c->F > 0 && (rc = ensure_tight_table(c))) return rc;
-        if ((rc = reset_fill_words(c))) return rc;
+        bool pred_reset = false;
+        // (the lattice-mapping pass keeps its flags in the scratch buffer the assignment's counters live in)
+        if ((rc = assign && !p->dynamic_lattice_mapping ? predict_reset_with_fill(c, &pred_reset) : reset_fill_words(c))) return rc;
         if (c->F == 0) {
             if (n_all_zero) *n_all_zero = 0;
             c->rows_valid = store; c->assign_valid = assign;
@@ -519,7 +521,7 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         // synchronisation per call (if the fill did report an error the assignment is simply discarded)
         c->rows_valid = store;
         c->assign_valid = false;
-        if (assign && (rc = sit_predict_internal(c, p->predict_threshold))) return rc;
+        if (assign && (rc = sit_predict_internal(c, p->predict_threshold, pred_reset))) return rc;
         u64 *hb = (u64 *)c->h_pinned;          // [0] error key, [1..4] scalars
         HIP_TRY(c, hipMemcpyAsync(hb, c->d_err, 72, hipMemcpyDeviceToHost, c->stream));      // d_scal follows d_err
         HIP_TRY(c, hipStreamSynchronize(c->stream));

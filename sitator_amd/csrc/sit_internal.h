@@ -36,6 +36,8 @@ struct sit_ctx {
     void *h_pinned = nullptr;                                  // small pinned read-back buffer (256 bytes)
     std::string msg;
     double timers[T_N] = {0};
+    double timer_sum[T_N] = {0};                               // all resolved laps of a stage, and how many (sit_timers)
+    double timer_cnt[T_N] = {0};
     Pbc pbc;
 
     // basis (sit_set_basis)
@@ -213,6 +215,7 @@ static inline void stage_timer_resolve(sit_ctx *c, int slot)
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->tev0[slot], c->tev1[slot]);
     c->timers[slot] = ms;
+    c->timer_sum[slot] += ms; c->timer_cnt[slot] += 1.0;
     c->tpending[slot] = false;
 }
 
@@ -317,7 +320,8 @@ __host__ __device__ inline double exact_value(u64 hi, u64 lo)
 }
 
 // host-side pieces implemented in other translation units
-int sit_predict_internal(sit_ctx *c, double threshold);
+int sit_predict_internal(sit_ctx *c, double threshold, bool words_reset = false);   // words_reset: predict_reset_with_fill did it
+int predict_reset_with_fill(sit_ctx *c, bool *done);                // cluster.hip: the fill's and the assignment's words in one launch
 int sit_label_counts(sit_ctx *c);
 void fitfast_free(sit_ctx *c);
 bool fitfast_valid(sit_ctx *c);
@@ -336,6 +340,7 @@ int reset_fill_words(sit_ctx *c);                                  // ctx.hip: e
 // comm.hip: n exact accumulators (hi, lo) and nseen counters summed over the ranks of c->comm_peer, on c->stream;
 // work = 3 n words of device scratch
 int comm_allreduce_limbs_device(sit_ctx *c, u64 *dhi, u64 *dlo, i64 n, u64 *dseen, i64 nseen, u64 *work);
+int reset_step_words(sit_ctx *c, bool counts, unsigned *wcount, int nseg);  // both sets in one launch
 int reset_predict_words(sit_ctx *c, bool counts, unsigned *wcount, int nseg); // label counts and wide-row segment lengths in one launch
 int fill3_prepare(sit_ctx *c);     // the allocations of fill3_launch, ahead of time
 int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S, const i64 *mobile_idx, i64 M, i64 frame0);   // ctx.hip
