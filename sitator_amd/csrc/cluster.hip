@@ -218,22 +218,34 @@ __device__ __forceinline__ bool predict_row_head(const PredArgs &a, i64 row, int
 // The list is kept in SEGMENTS, one per workgroup of the listing kernel (workgroup b walks the row blocks b, b + G, ...
 // and appends to wide_list[b * seg_cap ...], wide_count[b] = its length, zeroed before the launch): where most rows
 // are wide (C5) a single counter took a quarter of a million contended atomics per pass.
-__device__ __forceinline__ void list_wide_rows(bool wide, i64 row, i32 *seg, unsigned *seg_count, int lane)
+// A segment holds TWO lists: rows of 5-8 entries from its start upwards (length seg_count[0]), rows of 9 and more from
+// its end downwards (seg_count[1]); the merge of a row is a compile-time width, and a wave whose rows need different
+// widths runs them one after the other - sorted by class the waves of k_predict_rows_wide* are uniform (C5: 25 % of
+// the rows hold 5-8 entries, 29 % hold 9; mixed, every wave paid an 8-wide and a 16-wide merge).
+__device__ __forceinline__ void list_wide_rows(int n, bool live, i64 row, i32 *seg, unsigned *seg_count, i64 seg_cap, int lane)
 {
-    const unsigned long long wm = __ballot(wide);
-    if (wm) {                                                      // one atomic per wave, on the workgroup's own counter
-        const int leader = __ffsll((long long)wm) - 1;
+    const bool ca = live && n > 4 && n <= 8, cb = live && n > 8;
+    const unsigned long long ma = __ballot(ca), mb = __ballot(cb);
+    if (ma) {                                                      // one atomic per wave and class, on the workgroup's own counter
+        const int leader = __ffsll((long long)ma) - 1;
         unsigned base = 0;
-        if (lane == leader) base = atomicAdd(seg_count, (unsigned)__popcll(wm));
+        if (lane == leader) base = atomicAdd(seg_count, (unsigned)__popcll(ma));
         base = __shfl(base, leader);
-        if (wide) seg[base + __popcll(wm & ((1ull << lane) - 1ull))] = (i32)row;
+        if (ca) seg[base + __popcll(ma & ((1ull << lane) - 1ull))] = (i32)row;
+    }
+    if (mb) {
+        const int leader = __ffsll((long long)mb) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(seg_count + 1, (unsigned)__popcll(mb));
+        base = __shfl(base, leader);
+        if (cb) seg[seg_cap - 1 - (i64)(base + __popcll(mb & ((1ull << lane) - 1ull)))] = (i32)row;
     }
 }
 
 __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a, i32 *wide_list, unsigned *wide_count, i64 seg_cap)
 {
     i32 *seg = wide_list + (i64)blockIdx.x * seg_cap;
-    unsigned *seg_count = wide_count + blockIdx.x;
+    unsigned *seg_count = wide_count + 2 * blockIdx.x;
     const int lane = threadIdx.x & 63;
     for (i64 r0 = (i64)blockIdx.x * PRED_BLOCK; r0 < a.N; r0 += (i64)gridDim.x * PRED_BLOCK) {
         const i64 row = r0 + threadIdx.x;
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a, i32 *wi
         double xn = 0.0;
         const bool live = row < a.N && predict_row_head(a, row, n, xn);
         const bool wide = live && n > 4;
-        list_wide_rows(wide, row, seg, seg_count, lane);
+        list_wide_rows(n, live, row, seg, seg_count, seg_cap, lane);
         if (live && !wide) predict_row_merge(a, row, n, xn, a.col_ptr, a.col_k, a.col_val);
     }
 }
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(NTMAX) void k_predict_rows_lds(PredArgs a, i32 *wid
     for (int q = threadIdx.x; q <= (int)a.D; q += NT) l_ptr[q] = a.col_ptr[q];
     __syncthreads();
     i32 *seg = wide_list + (i64)blockIdx.x * seg_cap;
-    unsigned *seg_count = wide_count + blockIdx.x;
+    unsigned *seg_count = wide_count + 2 * blockIdx.x;
     const int lane = threadIdx.x & 63;
     for (i64 r0 = (i64)blockIdx.x * NT; r0 < a.N; r0 += (i64)gridDim.x * NT) {
         const i64 row = r0 + threadIdx.x;
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(NTMAX) void k_predict_rows_lds(PredArgs a, i32 *wid
         double xn = 0.0;
         const bool live = row < a.N && predict_row_head(a, row, n, xn);
         const bool wide = live && n > 4;
-        list_wide_rows(wide, row, seg, seg_count, lane);
+        list_wide_rows(n, live, row, seg, seg_count, seg_cap, lane);
         if (live && !wide) {
             const i64 to = predict_row_merge(a, row, n, xn, l_ptr, l_k, l_val);
             if (hist_K > 0 && to >= 0) atomicAdd(&hist[to], 1u);
@@ -296,6 +308,7 @@ __device__ __forceinline__ void predict_wide_row(const PredArgs &a, i64 row, con
     if (!predict_row_head(a, row, n, xn)) return;
     i64 to;
     if (n <= 8) to = predict_row_merge_wide<8>(a, row, n, xn, col_ptr, col_k, col_val);
+    else if (n <= 10) to = predict_row_merge_wide<10>(a, row, n, xn, col_ptr, col_k, col_val);
     else if (n <= 16) to = predict_row_merge_wide<16>(a, row, n, xn, col_ptr, col_k, col_val);
     else to = predict_row_generic(a, row, n, xn);
     if (counts && to >= 0) atomicAdd(&counts[to], 1ull);           // the narrow rows were counted by k_predict_rows_lds
@@ -306,9 +319,10 @@ __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_wide(PredArgs a, co
                                                                   int nseg, u64 *counts)
 {
     for (int sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
-        const i64 nw = (i64)wide_count[sg];
+        const i64 na = (i64)wide_count[2 * sg], nb = (i64)wide_count[2 * sg + 1];
         const i32 *seg = wide_list + (i64)sg * seg_cap;
-        for (i64 q = threadIdx.x; q < nw; q += PRED_BLOCK) predict_wide_row(a, seg[q], a.col_ptr, a.col_k, a.col_val, counts);
+        for (i64 q = threadIdx.x; q < na; q += PRED_BLOCK) predict_wide_row(a, seg[q], a.col_ptr, a.col_k, a.col_val, counts);
+        for (i64 q = threadIdx.x; q < nb; q += PRED_BLOCK) predict_wide_row(a, seg[seg_cap - 1 - q], a.col_ptr, a.col_k, a.col_val, counts);
     }
 }
 
@@ -326,16 +340,17 @@ __global__ __launch_bounds__(PRED_WIDE_LDS_BLOCK) void k_predict_rows_wide_lds(P
     if (threadIdx.x == 0) any = 0u;
     __syncthreads();
     for (int sg = blockIdx.x + threadIdx.x * gridDim.x; sg < nseg; sg += gridDim.x * PRED_WIDE_LDS_BLOCK)
-        if (wide_count[sg]) any = 1u;
+        if (wide_count[2 * sg] | wide_count[2 * sg + 1]) any = 1u;
     __syncthreads();
     if (!any) return;                                              // nothing for this workgroup: skip the staging
     for (int q = threadIdx.x; q < nnzc; q += PRED_WIDE_LDS_BLOCK) { l_val[q] = a.col_val[q]; l_k[q] = a.col_k[q]; }
     for (int q = threadIdx.x; q <= (int)a.D; q += PRED_WIDE_LDS_BLOCK) l_ptr[q] = a.col_ptr[q];
     __syncthreads();
     for (int sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
-        const i64 nw = (i64)wide_count[sg];
+        const i64 na = (i64)wide_count[2 * sg], nb = (i64)wide_count[2 * sg + 1];
         const i32 *seg = wide_list + (i64)sg * seg_cap;
-        for (i64 q = threadIdx.x; q < nw; q += PRED_WIDE_LDS_BLOCK) predict_wide_row(a, seg[q], l_ptr, l_k, l_val, counts);
+        for (i64 q = threadIdx.x; q < na; q += PRED_WIDE_LDS_BLOCK) predict_wide_row(a, seg[q], l_ptr, l_k, l_val, counts);
+        for (i64 q = threadIdx.x; q < nb; q += PRED_WIDE_LDS_BLOCK) predict_wide_row(a, seg[seg_cap - 1 - q], l_ptr, l_k, l_val, counts);
     }
 }
 
@@ -423,10 +438,10 @@ static int predict_plan(sit_ctx *c, PredPlan &p)
     const i64 blocks = (c->N + p.nt - 1) / p.nt;
     p.nseg = (int)std::min<i64>(blocks, (i64)ncu * p.per_cu);
     p.seg_cap = (blocks + p.nseg - 1) / p.nseg * p.nt;             // rows a workgroup can meet
-    int rc = ensure_scratch(c, ((i64)p.nseg * p.seg_cap + p.nseg + 64) * 4);
+    int rc = ensure_scratch(c, ((i64)p.nseg * p.seg_cap + 2 * p.nseg + 64) * 4);
     if (rc) return rc;
     p.wcount = (unsigned *)c->d_scratch;
-    p.wlist = (i32 *)c->d_scratch + ((p.nseg + 63) / 64 * 64);
+    p.wlist = (i32 *)c->d_scratch + ((2 * p.nseg + 63) / 64 * 64);    // two length words per segment
     return SIT_OK;
 }
 
@@ -439,7 +454,7 @@ int predict_reset_with_fill(sit_ctx *c, bool *done)
     PredPlan pp;
     int rc = predict_plan(c, pp);
     if (rc) return rc;
-    if ((rc = reset_step_words(c, pp.narrow_lds, pp.wcount, pp.nseg))) return rc;
+    if ((rc = reset_step_words(c, pp.narrow_lds, pp.wcount, 2 * pp.nseg))) return rc;
     *done = true;
     return SIT_OK;
 }
@@ -485,7 +500,7 @@ static int run_predict(sit_ctx *c, double threshold, bool words_reset = false)
         if (getenv("SITATOR_DEBUG_SHAPE")) fprintf(stderr, "predict: lds %zu nt %d per_cu %d nseg %d seg_cap %lld narrow_lds %d wide_lds %d rows_W %lld\n", lds, nt, pp.per_cu, nseg, (long long)seg_cap, (int)narrow_lds, (int)wide_lds, (long long)c->rows_W);
         u64 *cnt = narrow_lds ? (u64 *)c->d_counts : nullptr;            // the LDS kernel counts the labels on the way
         // sit_fill with assign = 1 has reset these words together with its own, ahead of the fill kernel
-        if (!words_reset && (rc = reset_predict_words(c, narrow_lds, wcount, nseg))) return rc;
+        if (!words_reset && (rc = reset_predict_words(c, narrow_lds, wcount, 2 * nseg))) return rc;
         if (narrow_lds) {
             if (nt == PRED_LDS_BLOCK) {
                 HIP_TRY(c, lds_limit((const void *)k_predict_rows_lds<PRED_LDS_BLOCK>, lds, c->device));
