@@ -63,8 +63,8 @@ int sit_device_count(int *count);
 int sit_create(const double *cell, const double *cell_inv, int device, sit_ctx **out);
 void sit_destroy(sit_ctx *ctx);
 const char *sit_last_message(sit_ctx *ctx);
-/* Device buffers of 64 MB and more (the trajectory, the landmark rows, labels) are kept by the process when a
- * context lets go of them, up to 64 GB in all, and handed to the next context that asks for a similar size: a process
+/* Device buffers of 1 MB and more (the trajectory, the landmark rows, labels, the fit's arena) are kept by the process
+ * when a context lets go of them, up to as much as its contexts have held at once, and handed to the next context that asks for a similar size: a process
  * that analyses one trajectory after another (the reference allocates its landmark matrix anew per run,
  * landmark/LandmarkAnalysis.py:211-218) does not pay the driver's free-then-allocate stall per run.
  * SITATOR_POOL_MIN_MB / SITATOR_POOL_GB change the two limits (SITATOR_POOL_GB=0: no pool); this call returns every

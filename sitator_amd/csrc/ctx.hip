@@ -22,7 +22,7 @@ size_t pool_env_mb(const char *name, size_t dflt)
     const long long x = atoll(v);
     return x < 0 ? dflt : (size_t)x;
 }
-size_t pool_min_bytes() { static const size_t v = pool_env_mb("SITATOR_POOL_MIN_MB", 64) << 20; return v; }
+size_t pool_min_bytes() { static const size_t v = pool_env_mb("SITATOR_POOL_MIN_MB", 1) << 20; return v; }
 // idle buffers kept: SITATOR_POOL_GB if given, else as much as the contexts of this process have held at once (the
 // high-water mark of the pooled buffers in use: one context's worth for a process that analyses one trajectory at a time)
 size_t g_live = 0, g_live_peak = 0;

@@ -1050,7 +1050,7 @@ void fitfast_free(sit_ctx *c)
 {
     if (!c->fitfast) return;
     FitFast *f = (FitFast *)c->fitfast;
-    if (f->blob) (void)hipFree(f->blob);
+    if (f->blob) sit_dfree(c, f->blob);                       // the arena is 85 MB and more: recycled between contexts
     if (f->d_trace) (void)hipFree(f->d_trace);
     if (f->h_ctl) (void)hipHostFree(f->h_ctl);
     delete f;
@@ -1066,11 +1066,11 @@ static char *carve(char *&p, size_t bytes)
 
 static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
 {
-    if (f->blob) { (void)hipFree(f->blob); f->blob = nullptr; }
+    if (f->blob) { sit_dfree(c, f->blob); f->blob = nullptr; }
     const i64 D = c->D;
     const size_t total = (size_t)Kcap * (4 + FS_CS * 12 + 16 + FS_W0 * 8 + FS_W1 * 8) + (size_t)D * (4 + FS_DC * 4)
                        + (size_t)FS_BMAX * (4 + 4 + 4 + FS_OC * 4 + 8 + FS_CS * 16) + (size_t)FS_LOG * 12 + 65536;
-    HIP_TRY(c, hipMalloc(&f->blob, total));
+    HIP_TRY(c, sit_dmalloc(c, &f->blob, total));
     if (!f->h_ctl) HIP_TRY(c, hipHostMalloc((void **)&f->h_ctl, sizeof(FSCtl)));
     HIP_TRY(c, hipMemsetAsync(f->blob, 0, total, c->stream));
     char *p = (char *)f->blob;

@@ -224,12 +224,12 @@ def test_c2_cut_against_oracle(oracle):
 
 def test_c4_shaped_cut_against_oracle(oracle):
     from sitator_amd import synth
-    _oracle_vs_gpu(oracle, synth.config_host("C4"), 256, 12, seed=404)
+    _oracle_vs_gpu(oracle, synth.config_host("C4"), 256, 48, seed=404)
 
 
 def test_c3_shaped_cut_against_oracle(oracle):
     from sitator_amd import synth
-    _oracle_vs_gpu(oracle, synth.config_host("C3"), 448, 10, seed=303)
+    _oracle_vs_gpu(oracle, synth.config_host("C3"), 448, 40, seed=303)
 
 
 def test_triclinic_mcl_against_oracle(oracle):
