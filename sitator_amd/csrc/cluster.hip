@@ -879,25 +879,32 @@ extern "C" int sit_fit_push_dense_rows(sit_ctx *c, const double *rows, const i64
     if (nrows == 0) return SIT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 D = c->D;
-    // sparse, slot-major with stride nrows and width D (zeros dropped: x + 0 == x)
-    std::vector<i32> nnz((size_t)nrows, 0), idx((size_t)(nrows * D), 0);
-    std::vector<double> val((size_t)(nrows * D), 0.0);
+    // sparse, slot-major with stride nrows, as wide as the fullest row (zeros dropped: x + 0 == x)
+    std::vector<i32> nnz((size_t)nrows, 0);
+    i64 Wd = 1;
+    for (i64 r = 0; r < nrows; r++) {
+        int n = 0;
+        for (i64 d = 0; d < D; d++) n += rows[r * D + d] != 0.0;
+        nnz[(size_t)r] = n;
+        if (n > Wd) Wd = n;
+    }
+    std::vector<i32> idx((size_t)(nrows * Wd), 0);
+    std::vector<double> val((size_t)(nrows * Wd), 0.0);
     for (i64 r = 0; r < nrows; r++) {
         int n = 0;
         for (i64 d = 0; d < D; d++) {
             const double v = rows[r * D + d];
             if (v != 0.0) { idx[(size_t)((i64)n * nrows + r)] = (i32)d; val[(size_t)((i64)n * nrows + r)] = v; n++; }
         }
-        nnz[(size_t)r] = n;
     }
     i32 *dn = nullptr, *di = nullptr; double *dv = nullptr; i64 *dw = nullptr;
     int rc;
     if ((rc = dev_upload(c, &dn, nnz.data(), nrows))) return rc;
-    if ((rc = dev_upload(c, &di, idx.data(), nrows * D))) return rc;
-    if ((rc = dev_upload(c, &dv, val.data(), nrows * D))) return rc;
+    if ((rc = dev_upload(c, &di, idx.data(), nrows * Wd))) return rc;
+    if ((rc = dev_upload(c, &dv, val.data(), nrows * Wd))) return rc;
     if (weights && (rc = dev_upload(c, &dw, weights, nrows))) return rc;
     StageTimer t(c, T_FIT);
-    rc = fit_stream(c, dn, di, dv, dw, nrows, (int)D, nrows, threshold);
+    rc = fit_stream(c, dn, di, dv, dw, nrows, (int)Wd, nrows, threshold);
     t.stop();
     sit_dfree(c, dn); sit_dfree(c, di); sit_dfree(c, dv); if (dw) sit_dfree(c, dw);
     return rc;

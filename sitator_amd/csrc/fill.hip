@@ -692,11 +692,13 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
     // every allocation first: hipMalloc / hipFree stall the other thread's copies
     const i64 N = c->N;
     i64 W = c->W;
+    i64 F_head = 0;                                           // leading frames already on the device
     if (!(c->d_row_nnz && c->rows_N == N && c->rows_W > 0 && c->rows_W <= c->W) && !c->rows_overflowed) {
         // the row width is measured on the leading frames (measured_row_width): they go up ahead of the pipeline
         i64 Fs = (1 << 16) / M;
         Fs = Fs < 16 ? 16 : (Fs > F ? F : Fs);
         HIP_TRY(c, hipMemcpyAsync(c->d_frames, frames, (size_t)(Fs * A * 24), hipMemcpyHostToDevice, c->stream));
+        F_head = Fs;
         if ((rc = fill3_prepare(c))) return rc;
         if ((rc = measured_row_width(c, p, &W))) return rc;
     } else if (c->d_row_nnz && c->rows_N == N && c->rows_W > 0 && c->rows_W <= c->W && !c->rows_overflowed) W = c->rows_W;
@@ -760,6 +762,15 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
         return SIT_OK;
     };
     StageTimer timer(c, T_FILL);
+    if (F_head >= 256 && !c->tight_valid) {
+        // the tight pruning table from the static displacements of the leading frames, which are on the device
+        // already, while chunk 0 is on the link (a frame beyond its bound takes the loose table: exact either way)
+        c->F = F_head;
+        rc = ensure_tight_table(c);
+        c->F = F;
+        if (rc) return finish(rc);
+        if (dbgpipe) fprintf(stderr, "  tight table (leading %lld frames) at %.1f ms\n", (long long)F_head, since());
+    }
     for (int i = 0; i < nch;) {
         if (i * cf >= F) break;
         if (dbgpipe) fprintf(stderr, "  main waits for chunk %d at %.1f ms\n", i, since());
@@ -773,8 +784,7 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
         const i64 lo = i * cf, hi = std::min<i64>(F, (j + 1) * cf);
         if (dbgpipe) fprintf(stderr, "  main has chunks %d..%d at %.1f ms\n", i, j, since());
         if (i == 0) {
-            // the tight pruning table from the static displacements of the first chunk (a frame beyond it takes the
-            // loose table: exact either way)
+            // no leading frames were sent ahead: the tight pruning table from the static displacements of the first chunk
             c->F = hi;
             rc = ensure_tight_table(c);
             c->F = F;

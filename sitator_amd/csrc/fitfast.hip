@@ -46,7 +46,7 @@
 #define FS_BMW 256                // words of a row's bitmap of centres already listed (speculation)
 #define FS_NP 16                  // row entries staged per joining row
 #define FS_LCAP 8192              // joining rows listed at a time by a walking wave
-#define FS_TAIL 32                // rows the commit may apply one at a time
+#define FS_TAIL 64                // rows the commit may apply one at a time
 #define FS_NEW (-1)
 #define FS_BREAK (-2)             // row must go the serial way (zero row, capacity)
 #define FS_CHUNK 64               // steps enqueued between two looks at the control block
@@ -505,12 +505,12 @@ struct Walker {
     // unchanged (the walk is void from jj on / the stream stops before this row).
     template <bool LOGGED>
     __device__ __forceinline__ bool join_general(const FS &s, const FSRows &r, FSCtl *ctl, i64 row, int jj, int n,
-                                                 double fo, double fn, const i32 *ri, const double *rv)
+                                                 double fo, double fn, const i32 *ri, const double *rv, int rs = 1)
     {
         int extra = 0;                                          // capacity first: how many dimensions are new?
         bool dcfull = false;
         for (int e = 0; e < n; e++) {
-            const i32 d = e < FS_NP ? ri[e] : r.idx[(i64)e * r.stride + row];
+            const i32 d = e < FS_NP ? ri[e * rs] : r.idx[(i64)e * r.stride + row];
             if (!__ballot(idx == d)) { extra++; if (!LOGGED && s.dc_n[d] >= FS_DC) dcfull = true; }
         }
         int slot0 = 0;
@@ -529,8 +529,8 @@ struct Walker {
         }
         double t = val * fo;
         for (int e = 0; e < n; e++) {
-            const i32 d = e < FS_NP ? ri[e] : r.idx[(i64)e * r.stride + row];
-            const double v = e < FS_NP ? rv[e] : r.val[(i64)e * r.stride + row];
+            const i32 d = e < FS_NP ? ri[e * rs] : r.idx[(i64)e * r.stride + row];
+            const double v = e < FS_NP ? rv[e * rs] : r.val[(i64)e * r.stride + row];
             if (__ballot(idx == d)) { if (idx == d) t += v; continue; }
             // the centre gains dimension d (0 * fo + v): sorted insertion across the lanes
             if (lane == 0) {
@@ -584,8 +584,8 @@ struct WalkLds {
     unsigned short lst[FS_LCAP];     // joining rows (batch row numbers), ascending
     double addm[64 * FS_CS];         // [join][support slot]: what the joining row adds to the slot
     i32 supl[FS_CS];                 // the support, for the joins to look their dimensions up
-    i32 rowi[64 * FS_NP];            // first entries of the joining rows
-    double rowv[64 * FS_NP];
+    i32 rowi[64 * FS_NP];            // first entries of the joining rows, [entry][join]: a lane per join writes and reads
+    double rowv[64 * FS_NP];         // without bank conflicts ([join][entry] put all 64 lanes on one or two banks)
     double zero;
 };
 
@@ -678,7 +678,7 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
             const int n = J.n;
             const double wd = J.wd;
 #pragma unroll
-            for (int e = 0; e < FS_NP; e++) { rowi[lane * FS_NP + e] = J.i[e]; rowv[lane * FS_NP + e] = J.v[e]; }
+            for (int e = 0; e < FS_NP; e++) if (e < r.width) { rowi[e * 64 + lane] = J.i[e]; rowv[e * 64 + lane] = J.v[e]; }
             const double fn = wk.cnt + wave_incl_scan(wd, lane), fo = fn - wd, fy = 1.0 / fn;
             // the next group's rows are on their way while this group is applied
             {
@@ -691,18 +691,18 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
             for (;;) {
                 // joins s0.. look their dimensions up in the support as it is now
                 FF_T(t_l0);
-                const int SW = wk.sn;
+                const int SW = wk.sn, SWP = SW | 1;            // odd row stride of the [join][slot] matrix: no bank conflicts
                 if (lane < SW) supl[lane] = wk.idx;
                 __builtin_amdgcn_wave_barrier();
                 bool grow = false;
                 if (isj && lane >= s0) {
-                    for (int i = 0; i < SW; i++) addm[lane * SW + i] = 0.0;
+                    for (int i = 0; i < SW; i++) addm[lane * SWP + i] = 0.0;
                     for (int e = 0; e < n; e++) {
-                        const i32 d = e < FS_NP ? rowi[lane * FS_NP + e] : r.idx[(i64)e * r.stride + row];
-                        const double v = e < FS_NP ? rowv[lane * FS_NP + e] : r.val[(i64)e * r.stride + row];
+                        const i32 d = e < FS_NP ? rowi[e * 64 + lane] : r.idx[(i64)e * r.stride + row];
+                        const double v = e < FS_NP ? rowv[e * 64 + lane] : r.val[(i64)e * r.stride + row];
                         int lo = 0, hi = SW;
                         while (lo < hi) { const int mid = (lo + hi) >> 1; if (supl[mid] < d) lo = mid + 1; else hi = mid; }
-                        if (lo < SW && supl[lo] == d) addm[lane * SW + lo] = v; else grow = true;
+                        if (lo < SW && supl[lo] == d) addm[lane * SWP + lo] = v; else grow = true;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -726,7 +726,7 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
                 }
                 const int u0 = __builtin_amdgcn_readfirstlane(s0), u1 = __builtin_amdgcn_readfirstlane(s1);
                 const double *col = lane < SW ? addm + lane : &L.zero;      // lanes outside the support add 0 to their 0
-                const int stp = lane < SW ? SW : 0;
+                const int stp = lane < SW ? SWP : 0;
                 double a0 = u0 < u1 ? col[u0 * stp] : 0.0, a1 = 0.0;
                 double qfo = bc_d(fo, u0 < 64 ? u0 : 0);
                 int q = u0;
@@ -745,7 +745,7 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
                 {
                     const int jj = bc_i(j, s1);
                     if (!wk.join_general<true>(s, r, ctl, pos + jj, jj, bc_i(n, s1), bc_d(fo, s1), bc_d(fn, s1),
-                                               rowi + s1 * FS_NP, rowv + s1 * FS_NP)) return;
+                                               rowi + s1, rowv + s1, 64)) return;
                     wk.publish(s, jj);
                 }
                 FF_ACC(4, clock64() - t_l2);
@@ -915,6 +915,61 @@ __device__ __forceinline__ bool fs_apply_row(const FS &s, const FSRows &r, FSCtl
     return ok;
 }
 
+// Rows 1 .. of a batch whose row 0 has just founded a cluster: bit q of the result = row q founds one too, given that
+// rows 1 .. q - 1 all do.  The speculation found such a row below the threshold against every centre of the batch
+// start (its decision is exact for that state, and no join has changed it: the batch was cut at row 0); what is left
+// is its score against the centres founded by rows 0 .. q - 1, which ARE those rows (:250-260) - a lane per row scores
+// it against the earlier rows of the run out of LDS, with the arithmetic of fs_decide (:238-240).  The centres of a
+// second fit pass (every row founds a cluster) and the first frame of a trajectory go this way instead of one
+// fs_decide per row, a chain of memory round trips each.  Conservative: a row that is not certainly a founding
+// row ends the run and is decided the general way.
+template <int NR, int NS>
+__device__ __forceinline__ u64 fs_founding_run(const FS &s, const FSRows &r, i64 pos, int nb, i64 left, double threshold,
+                                                i32 *t_ri, double *t_rv, int lane)
+{
+    int lim = nb < 64 ? nb : 64;
+    if (left < lim) lim = (int)left;
+    Row<NR> R;
+    R.n = 0;
+#pragma unroll
+    for (int e = 0; e < NR; e++) { R.i[e] = 0; R.v[e] = 0.0; }
+    double xn = 0.0;
+    bool cand = false;
+    if (lane < lim) {
+        row_load(R, r, pos + lane);
+        xn = s.xn[lane];
+        cand = (lane == 0 || s.dec[lane] == FS_NEW) && R.n >= 1 && R.n <= FS_NP && R.n <= FS_SMAX;
+    }
+    const u64 cm = __ballot(cand);
+    const int m = cm == ~0ull ? 64 : __ffsll((long long)~cm) - 1;     // rows [0, m) are the run
+    if (m <= 1) return 0ull;
+    if (lane < m)
+        for (int e = 0; e < FS_NP; e++) {
+            i32 di = 0;
+            double dv = 0.0;
+            if (e < R.n) { di = r.idx[(i64)e * r.stride + pos + lane]; dv = r.val[(i64)e * r.stride + pos + lane]; }
+            t_ri[lane * FS_NP + e] = di; t_rv[lane * FS_NP + e] = dv;
+        }
+    wave_mem_sync();
+    bool ok = lane >= 1 && lane < m;
+    for (int i = 0; i + 1 < m; i++) {
+        const int sn_i = bc_i(R.n, i);
+        const double nrm_i = bc_d(xn, i);
+        if (ok && i < lane) {
+            Sup<NS> S;
+            sup_load(S, t_ri + i * FS_NP, t_rv + i * FS_NP, sn_i);
+            int first;
+            double dot = row_dot(R, r, pos + lane, S, first);
+            dot /= nrm_i;                                           // :239 (the founded centre's norm is its row's)
+            dot /= xn;                                              // :240
+            if (!(dot < threshold)) ok = false;                     // joins (or NaN): the general way decides
+        }
+    }
+    const u64 bad = __ballot(!ok) & ~1ull & (m >= 64 ? ~0ull : (1ull << m) - 1ull);
+    const int f = bad ? __ffsll((long long)bad) - 1 : m;            // first row of the run that is not certainly founding
+    return ((f >= 64 ? ~0ull : (1ull << f) - 1ull)) & ~1ull;
+}
+
 template <int NR, int NS>
 __global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, double threshold)
 {
@@ -922,6 +977,8 @@ __global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, doubl
     __shared__ double rv[FS_NP];
     __shared__ i32 ovl[FS_OC];
     __shared__ unsigned seen[FS_BMW];
+    __shared__ __attribute__((aligned(16))) i32 t_ri[64 * FS_NP];      // the ending wave's run of founding rows
+    __shared__ __attribute__((aligned(16))) double t_rv[64 * FS_NP];
     FSCtl *ctl = s.ctl + par, *nxt = s.ctl + (par ^ 1);
     const int lane = threadIdx.x;
     if (ctl->halt) {
@@ -973,12 +1030,15 @@ __global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, doubl
         // a batch cut at its first row by a founding row: keep going one row at a time while rows found clusters
         if (applied && cut == 0 && single == FS_NEW) {
             const i64 left = ctl->nrows - pos;
+            const u64 founds = fs_founding_run<NR, NS>(s, r, pos, nb, left, threshold, t_ri, t_rv, lane);
             for (int q = 1; q < FS_TAIL && q < left; q++) {
                 wave_mem_sync();
                 if (Kn >= s.Kcap) break;
                 int nov;
                 double xn;
-                const int dec = fs_decide<NR, NS, 64>(s, r, pos + q, Kn, threshold, ovl, seen, lane, nov, xn);
+                int dec;
+                if ((founds >> q) & 1ull) { dec = FS_NEW; xn = s.xn[q]; }
+                else dec = fs_decide<NR, NS, 64>(s, r, pos + q, Kn, threshold, ovl, seen, lane, nov, xn);
                 if (dec == FS_BREAK) break;                       // the next step meets it at its own first row
                 if (!fs_apply_row(s, r, ctl, pos + q, q, dec, -1, xn, Kn, ri, rv, lane)) break;
                 applied++;
