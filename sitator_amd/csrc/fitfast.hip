@@ -1098,6 +1098,7 @@ struct FitFast {
     FSCtl *h_ctl = nullptr;   // pinned: read-back of a control block
     void *blob = nullptr;
     i64 *d_trace = nullptr;
+    int B_keep = 256;         // batch size the last chain ended with: the next stream over this state starts there
 };
 
 static FitFast *ff_of(sit_ctx *c)
@@ -1243,6 +1244,7 @@ int fitfast_set_state(sit_ctx *c, const double *cen, const i64 *cnt, i64 K)
     int rc = ff_from_dense(c, f, cen, cnt, K, &fits);
     if (rc) return rc;
     f->valid = fits;
+    f->B_keep = 256;
     return SIT_OK;
 }
 
@@ -1262,7 +1264,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
     const char *tp = getenv("SITATOR_FF_TRACE");              // diagnostics: one line per step
     if (tp && !f->d_trace) HIP_TRY(c, hipMalloc((void **)&f->d_trace, (size_t)FS_TRACE_CAP * 48));
     i64 base = 0;                                             // rows consumed before the current control chain
-    int B = 256;
+    int B = f->B_keep;                                        // (a pipelined run streams its rows in 4-16 calls: 8 doubling steps each)
     for (;;) {
         FS s = f->st;
         s.trace = tp ? f->d_trace : nullptr;
@@ -1330,6 +1332,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
             }
         }
         K = st.K; B = st.B;
+        f->B_keep = B;
         base += st.pos;
         // the next stream (and fitfast_to_dense) finds the centre count in control block 0
         FSCtl keep;
