@@ -762,7 +762,7 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
         return SIT_OK;
     };
     StageTimer timer(c, T_FILL);
-    if (F_head >= 256 && !c->tight_valid) {
+    if (F_head * S >= 100000 && !c->tight_valid) {              // enough displacements for a bound (C2: 1 024 frames x 512 atoms)
         // the tight pruning table from the static displacements of the leading frames, which are on the device
         // already, while chunk 0 is on the link (a frame beyond its bound takes the loose table: exact either way)
         c->F = F_head;
