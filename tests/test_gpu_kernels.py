@@ -446,6 +446,47 @@ def test_speculative_fit_on_random_sparse_rows(oracle, seed, D, N, maxnnz):
     np.testing.assert_allclose(clf.cluster_centers, exp, rtol=1e-12, atol=1e-300)
 
 
+@pytest.mark.parametrize("case", ["all_found", "repeat_in_run", "near_threshold", "wide_row", "short_stream", "weighted_pass"])
+def test_runs_of_founding_rows(oracle, case):
+    """Consecutive rows that each found a cluster (the second pass of fit_centers over its own centres, the first frame
+    of a trajectory) are verified by one pairwise pass of the step's ending wave instead of one decision each
+    (fitfast.hip fs_founding_run).  Directed streams: every row founds; a row inside the run repeats an earlier one
+    (it joins: the run ends there); pairs just below / above the threshold; a row wider than the staged entries; a
+    stream shorter than a run; the weighted second pass.  Centres must equal the oracle's ordered stream."""
+    from sitator_amd import DotProdClassifier
+    rng = np.random.default_rng(11)
+    D, thr = 300, 0.45
+    X = np.zeros((260, D))
+    for i in range(len(X)):                                      # pairwise dissimilar rows: one own dimension each + a weak shared one
+        X[i, i] = rng.uniform(0.5, 1.0)
+        X[i, 280 + i % 7] = rng.uniform(0.01, 0.05)
+    if case == "repeat_in_run":
+        for i in (5, 17, 40, 41, 100, 199):
+            X[i] = X[i - 3] * rng.uniform(0.9, 1.1)              # cosine 1 with an earlier row of the same run
+    elif case == "near_threshold":
+        for i in range(3, 250, 9):                               # cosine with row i - 2 just below / just above 0.45
+            c = thr + (1e-9 if (i // 9) % 2 else -1e-9)
+            X[i] = 0.0
+            X[i - 2, 280:] = 0.0                                  # the partner is its own dimension alone: the cosine is c
+            X[i, i - 2] = c * X[i - 2, i - 2]
+            X[i, i] = np.sqrt(max(0.0, 1.0 - c * c)) * X[i - 2, i - 2]
+    elif case == "wide_row":
+        X[30, 100:120] = rng.uniform(0.2, 0.4, size=20)           # 21 entries: more than the run stages
+        X[31, 100:118] = rng.uniform(0.2, 0.4, size=18)
+    elif case == "short_stream":
+        X = X[:37]
+    elif case == "weighted_pass":
+        # every row three times with a little noise: the first pass joins, the second pass (rows = centres, weights =
+        # their counts, :290-299) is one long run of founding rows with weights 3
+        X = np.repeat(X[:120], 3, axis=0) * rng.uniform(0.97, 1.03, size=(360, 1))
+    clf = DotProdClassifier(threshold=thr, min_samples=1)
+    clf.fit_centers(X)
+    got = clf.cluster_centers
+    exp = oracle.fit_centers(X, thr)
+    assert got.shape == exp.shape
+    np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-300)
+
+
 @pytest.mark.parametrize("seed,D,N,maxnnz,nproto,thr,dwell", [(1, 64, 20000, 13, 400, 0.9, 8), (2, 24, 70000, 4, 5, 0.9, 200),
                                                                (3, 1500, 20000, 13, 40, 0.6, 1), (4, 200, 70000, 2, 4000, 0.9, 1)])
 def test_speculative_fit_is_bit_identical_to_the_serial_stream(seed, D, N, maxnnz, nproto, thr, dwell):
