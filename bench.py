@@ -264,6 +264,7 @@ def main():
                          # what the counters say limits the kernel (profiles/pmc_valu.json, taken with this build)
                          "limiter": "valu-issue", "valu": measured_valu(kernel, args.config)},
             "clock_ramp_steps": ramp,
+            "fill_shape": {k: info.get(k) for k in ("waves_per_workgroup", "frames_per_workgroup", "survivors_per_wave", "task_table_per_wave")},
             "stages_ms": {"fill": fill_avg_ms, "predict": float(laps["predict"][0]), "h2d_frames": h2d_ms,
                           "generate_s": round(t_gen, 2)},
             "end_to_end_run": e2e,

@@ -632,6 +632,7 @@ class HipContext(object):
         out["fit_batches"], out["fit_serial_rows"], out["fit_rewalks"] = int(v[13]), int(v[14]), int(v[15])
         out["fill_kernel"], out["survivors_per_wave"], out["waves_per_workgroup"] = int(v[16]), int(v[17]), int(v[18])
         out["fit_capacity_hit"], out["fit_stop_row"] = int(v[19]), int(v[20])
+        out["task_table_per_wave"] = int(v[21])
         out["census"] = [float(x) for x in v[24:28]]
         return out
 

@@ -1010,7 +1010,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     h.rcap = rcap; h.tt = tt;
     if (f3_env_int("SITATOR_DEBUG_SHAPE", 0))
         fprintf(stderr, "k_fill3 shape: nw %d fpb %d rcap %d iw %d tt %d mcap %d, %zu bytes of LDS per workgroup\n", nw, fpb, rcap, iw, tt, h.mcap, lds);
-    c->last_fpb = fpb; c->last_kernel = 3; c->last_iw = rcap; c->last_nw = nw;
+    c->last_fpb = fpb; c->last_kernel = 3; c->last_iw = rcap; c->last_nw = nw; c->last_tt = tt;
     const unsigned grid = (unsigned)((f_hi - f_lo + fpb - 1) / fpb);
     if (f_hi <= f_lo) return SIT_OK;
     HIP_TRY(c, f3_dispatch(c, h, full, grid, lds, nw, vp, diag, dynmap));

@@ -77,7 +77,7 @@ struct sit_ctx {
     bool idx_contig = false;          // static_idx / mobile_idx are consecutive atom ranges
     i64 idx_s0 = 0, idx_m0 = 0;
     double hmin = 0;                  // smallest perpendicular height of the cell
-    int last_kernel = 0, last_iw = 0, last_nw = 0;
+    int last_kernel = 0, last_iw = 0, last_nw = 0, last_tt = 0;
     double census[4] = {0, 0, 0, 0};  // SITATOR_DEBUG_STOP=9: static tasks, landmark tasks, survivors, wave batches
 
     // trajectory (sit_set_frames)
