@@ -381,16 +381,21 @@ extern "C" int sit_set_centers(sit_ctx *c, const double *centers, i64 K, int nor
     SIT_REQUIRE(c, c->D > 0 && K > 0, "sit_set_centers: basis must be set and K > 0");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 D = c->D;
-    std::vector<i32> ptr((size_t)D + 1, 0), ks;
-    std::vector<double> vals;
-    for (i64 d = 0; d < D; d++) {
-        ptr[(size_t)d] = (i32)ks.size();
-        for (i64 k = 0; k < K; k++) {
-            const double v = centers[k * D + d];
-            if (v != 0.0) { ks.push_back((i32)k); vals.push_back(v); }   // NaN != 0 is kept
-        }
+    // CSC (per landmark the centres holding it, ascending centre id) in two row-major passes over the dense matrix:
+    // walking it column by column strides through K x D doubles (15 ms per call at C4: 1 585 x 2 048)
+    std::vector<i32> ptr((size_t)D + 1, 0);
+    for (i64 k = 0; k < K; k++) {
+        const double *row = centers + k * D;
+        for (i64 d = 0; d < D; d++) ptr[(size_t)d + 1] += row[d] != 0.0;              // NaN != 0 is kept
     }
-    ptr[(size_t)D] = (i32)ks.size();
+    for (i64 d = 0; d < D; d++) ptr[(size_t)d + 1] += ptr[(size_t)d];
+    std::vector<i32> ks((size_t)ptr[(size_t)D]), cur(ptr.begin(), ptr.end() - 1);
+    std::vector<double> vals((size_t)ptr[(size_t)D]);
+    for (i64 k = 0; k < K; k++) {
+        const double *row = centers + k * D;
+        for (i64 d = 0; d < D; d++)
+            if (row[d] != 0.0) { const i32 q = cur[(size_t)d]++; ks[(size_t)q] = (i32)k; vals[(size_t)q] = row[d]; }
+    }
     if (ks.empty()) { ks.push_back(0); vals.push_back(0.0); }
     int rc;
     if ((rc = dev_upload(c, &c->d_col_ptr, ptr.data(), D + 1))) return rc;
@@ -785,11 +790,10 @@ extern "C" int sit_fit_get_state(sit_ctx *c, double *centers, i64 *counts, i64 *
     HIP_TRY(c, hipSetDevice(c->device));
     if (fitfast_valid(c)) {
         std::vector<double> cen; std::vector<i64> cnt;
-        int rc = fitfast_to_dense(c, cen, cnt, K);
+        // no arrays: the count alone (the caller sizes them with it); else straight into the caller's arrays
+        int rc = !centers && !counts ? fitfast_count(c, K) : fitfast_to_dense(c, cen, cnt, K, centers, counts);
         if (rc) return rc;
         c->fit_K = *K;
-        if (centers && *K) memcpy(centers, cen.data(), cen.size() * 8);
-        if (counts && *K) memcpy(counts, cnt.data(), cnt.size() * 8);
         return SIT_OK;
     }
     *K = c->fit_K;

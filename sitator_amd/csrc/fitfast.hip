@@ -1212,25 +1212,40 @@ static int ff_read_K(sit_ctx *c, FitFast *f, i32 *K)
 }
 
 // sparse state -> dense host arrays (sit_fit_get_state, or hand-over to the serial dense kernel)
-int fitfast_to_dense(sit_ctx *c, std::vector<double> &cen, std::vector<i64> &cnt, i64 *Kout)
+// the centre count alone (the caller sizes its arrays with it)
+int fitfast_count(sit_ctx *c, i64 *Kout)
+{
+    i32 K32 = 0;
+    int rc = ff_read_K(c, ff_of(c), &K32);
+    *Kout = K32;
+    return rc;
+}
+
+// cen_out / cnt_out non-null: the dense state goes straight into the caller's arrays ([K, D] and [K], as many centres
+// as fitfast_count says) instead of the vectors
+int fitfast_to_dense(sit_ctx *c, std::vector<double> &cen_v, std::vector<i64> &cnt_v, i64 *Kout, double *cen_out, i64 *cnt_out)
 {
     FitFast *f = ff_of(c);
     i32 K32 = 0;
     { int rc = ff_read_K(c, f, &K32); if (rc) return rc; }
     const i64 K = K32, D = c->D;
     *Kout = K;
-    cen.assign((size_t)(K * D), 0.0); cnt.assign((size_t)K, 0);
+    double *cen = cen_out;
+    i64 *cnt = cnt_out;
+    if (!cen_out) { cen_v.assign((size_t)(K * D), 0.0); cen = cen_v.data(); }
+    else if (K) memset(cen_out, 0, (size_t)(K * D) * 8);
+    if (!cnt_out) { cnt_v.assign((size_t)K, 0); cnt = cnt_v.data(); }
     if (K == 0) return SIT_OK;
     std::vector<i32> cs_n((size_t)K), cs_idx((size_t)(K * FS_CS));
     std::vector<double> cs_val((size_t)(K * FS_CS));
     HIP_TRY(c, hipMemcpyAsync(cs_n.data(), f->st.cs_n, (size_t)K * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(cs_idx.data(), f->st.cs_idx, (size_t)K * FS_CS * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(cs_val.data(), f->st.cs_val, (size_t)K * FS_CS * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(cnt.data(), f->st.c_cnt, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(cnt, f->st.c_cnt, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (i64 k = 0; k < K; k++)
         for (int i = 0; i < cs_n[(size_t)k]; i++)
-            cen[(size_t)(k * D + cs_idx[(size_t)(k * FS_CS + i)])] = cs_val[(size_t)(k * FS_CS + i)];
+            cen[k * D + cs_idx[(size_t)(k * FS_CS + i)]] = cs_val[(size_t)(k * FS_CS + i)];
     return SIT_OK;
 }
 

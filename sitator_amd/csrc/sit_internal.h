@@ -327,7 +327,8 @@ void fitfast_free(sit_ctx *c);
 bool fitfast_valid(sit_ctx *c);
 void fitfast_invalidate(sit_ctx *c);
 int fitfast_set_state(sit_ctx *c, const double *cen, const i64 *cnt, i64 K);
-int fitfast_to_dense(sit_ctx *c, std::vector<double> &cen, std::vector<i64> &cnt, i64 *Kout);
+int fitfast_to_dense(sit_ctx *c, std::vector<double> &cen, std::vector<i64> &cnt, i64 *Kout, double *cen_out = nullptr, i64 *cnt_out = nullptr);
+int fitfast_count(sit_ctx *c, i64 *Kout);
 int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val, const i64 *weights, i64 stride,
                    int width, i64 nrows, double threshold, i64 *consumed);
 // pruning table for static displacements up to `displacement`, built and kept on the device (candidates.hip)
