@@ -748,3 +748,35 @@ def test_large_buffers_are_recycled_between_contexts_with_identical_results():
     ctx4, *_ = _setup(host, 64, F, seed=91)
     assert ctx4.fill(check_for_zeros=False)[0] == 0
     assert np.array_equal(ctx4.rows_dense(0, 64 * 300), a)
+
+
+def test_stage_timer_totals_and_prefaulted_read_back():
+    """Two small pieces of the measurement / read-back plumbing of round 3: `sit_timers` with n = 24 returns the summed
+    laps of every stage and their number (bench.py reads them before and after its timed loop instead of once per
+    pass); the label / confidence arrays that `prefault_assignments` prepares on a helper thread are the ones the next
+    fetching predict fills - once, and only if their length fits - with the same contents as fresh arrays."""
+    from sitator_amd import synth
+    host = synth.config_host("C2")
+    ctx, frames, sm, mm, ref = _setup(host, 64, 300, seed=77)
+    t0 = ctx.timer_totals()
+    for _ in range(3):
+        assert ctx.fill(check_for_zeros=False)[0] == 0
+    t1 = ctx.timer_totals()
+    assert t1["fill"][1] - t0["fill"][1] == 3
+    assert t1["fill"][0] - t0["fill"][0] >= ctx.timers()["fill"] > 0.0
+    assert t1["predict"] == t0["predict"]
+    rows = ctx.rows_dense()
+    centers = rows[:64] / np.linalg.norm(rows[:64], axis=1)[:, None]
+    ctx.set_centers(centers, True)
+    fresh = ctx.predict(0.8)
+    ctx.prefault_assignments(ctx.N)
+    th, box, n = ctx._prefault
+    th.join()
+    prepared = box["arrays"]
+    got = ctx.predict(0.8)
+    assert got[0] is prepared[0] and got[1] is prepared[1] and ctx._prefault is None
+    assert all(np.array_equal(a, b) for a, b in zip(got, fresh))
+    ctx.prefault_assignments(ctx.N + 5)                          # a length that does not fit is not used
+    again = ctx.predict(0.8)
+    assert len(again[0]) == ctx.N and all(np.array_equal(a, b) for a, b in zip(again, fresh))
+    ctx.close()
