@@ -491,13 +491,20 @@ struct Walker {
         if (lane < sn) { s.cs_idx[(i64)k * FS_CS + lane] = idx; s.cs_val[(i64)k * FS_CS + lane] = val; }
         if (lane == 0) { s.cs_n[k] = sn; s.c_cnt[k] = (i64)cnt; s.c_nrm[k] = sqrt(s2); }
     }
+    // Every lane stores (the slots beyond the support hold an out-of-range index and are not read: one instruction
+    // without an execution mask around it).
     __device__ __forceinline__ void publish(const FS &s, int jj)
     {
-        if (lane <= sn) {
-            VsEnt e;
-            e.idx = idx; e.sn = sn; e.val = lane == sn ? cnt : val;
-            (s.vs_ent + (size_t)jj * FS_CS)[lane] = e;           // jj is uniform: scalar base, lane offset
-        }
+        VsEnt e;
+        e.idx = idx; e.sn = sn; e.val = lane == sn ? cnt : val;
+        (s.vs_ent + (size_t)jj * FS_CS)[lane] = e;               // jj is uniform: scalar base, lane offset
+    }
+    // the same with the version's byte offset (jj * FS_CS * 16, below 2^32) in a register: scalar base + 32-bit offset
+    __device__ __forceinline__ void publish_at(const FS &s, unsigned off)
+    {
+        VsEnt e;
+        e.idx = idx; e.sn = sn; e.val = lane == sn ? cnt : val;
+        *(VsEnt *)((char *)s.vs_ent + (size_t)(off + 16u * (unsigned)lane)) = e;
     }
     // The general join (:283-288): batch row jj (n entries, the first FS_NP of them at ri / rv, weight fn - fo) joins
     // this centre and may add dimensions to its support.  LOGGED: growth goes to the walk's log (published at the
@@ -582,7 +589,9 @@ __device__ __forceinline__ double wave_incl_scan(double x, int lane)      // exa
 
 struct WalkLds {
     unsigned short lst[FS_LCAP];     // joining rows (batch row numbers), ascending
-    double addm[64 * FS_CS];         // [join][support slot]: what the joining row adds to the slot
+    double addm[66 * FS_CS];         // [join][support slot]: what the joining row adds to the slot (+2 rows: the chain reads ahead)
+    double2 fq[64];                  // per join of the group: sample count after it, its reciprocal
+    unsigned jo[64];                 // per join: byte offset of its version
     i32 supl[FS_CS];                 // the support, for the joins to look their dimensions up
     i32 rowi[64 * FS_NP];            // first entries of the joining rows, [entry][join]: a lane per join writes and reads
     double rowv[64 * FS_NP];         // without bank conflicts ([join][entry] put all 64 lanes on one or two banks)
@@ -680,6 +689,8 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
 #pragma unroll
             for (int e = 0; e < FS_NP; e++) if (e < r.width) { rowi[e * 64 + lane] = J.i[e]; rowv[e * 64 + lane] = J.v[e]; }
             const double fn = wk.cnt + wave_incl_scan(wd, lane), fo = fn - wd, fy = 1.0 / fn;
+            L.fq[lane] = make_double2(fn, fy);                      // the chain reads a join's constants as LDS broadcasts
+            L.jo[lane] = isj ? (unsigned)j * (unsigned)(FS_CS * sizeof(VsEnt)) : 0u;
             // the next group's rows are on their way while this group is applied
             {
                 const bool nj = g0 + 64 + lane < Ts;
@@ -715,14 +726,14 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
                 // its lane's registers; what it adds to my slot is read from LDS one join ahead.
 #define FS_JOIN_STEP(q, a)                                                                              \
                 {                                                                                               \
-                    const double qfn = bc_d(fn, q), qy = bc_d(fy, q);     /* fo of this join = fn of the one before */ \
-                    const int jj = bc_i(j, q);                                                                  \
+                    const double2 f_ = L.fq[q];                           /* fo of this join = fn of the one before */ \
+                    const unsigned off_ = L.jo[q];                                                              \
                     const double t = wk.val * qfo + (a);                                                        \
-                    const double q0 = t * qy;                                                                   \
-                    wk.val = __builtin_fma(__builtin_fma(-q0, qfn, t), qy, q0);                                 \
-                    wk.cnt = qfn;                                                                               \
-                    wk.publish(s, jj);                                                                          \
-                    qfo = qfn;                                                                                  \
+                    const double q0 = t * f_.y;                                                                 \
+                    wk.val = __builtin_fma(__builtin_fma(-q0, f_.x, t), f_.y, q0);                              \
+                    wk.cnt = f_.x;                                                                              \
+                    wk.publish_at(s, off_);                                                                     \
+                    qfo = f_.x;                                                                                 \
                 }
                 const int u0 = __builtin_amdgcn_readfirstlane(s0), u1 = __builtin_amdgcn_readfirstlane(s1);
                 const double *col = lane < SW ? addm + lane : &L.zero;      // lanes outside the support add 0 to their 0
@@ -733,7 +744,7 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
                 for (; q + 1 < u1; q += 2) {
                     a1 = col[(q + 1) * stp];
                     FS_JOIN_STEP(q, a0)
-                    a0 = q + 2 < u1 ? col[(q + 2) * stp] : 0.0;
+                    a0 = col[(q + 2) * stp];                               // (two rows of slack behind the last join)
                     FS_JOIN_STEP(q + 1, a1)
                 }
                 if (q < u1) FS_JOIN_STEP(q, a0)
