@@ -706,14 +706,36 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
                 if (lane < SW) supl[lane] = wk.idx;
                 __builtin_amdgcn_wave_barrier();
                 bool grow = false;
-                if (isj && lane >= s0) {
-                    for (int i = 0; i < SW; i++) addm[lane * SWP + i] = 0.0;
-                    for (int e = 0; e < n; e++) {
-                        const i32 d = e < FS_NP ? rowi[e * 64 + lane] : r.idx[(i64)e * r.stride + row];
-                        const double v = e < FS_NP ? rowv[e * 64 + lane] : r.val[(i64)e * r.stride + row];
-                        int lo = 0, hi = SW;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (supl[mid] < d) lo = mid + 1; else hi = mid; }
-                        if (lo < SW && supl[lo] == d) addm[lane * SWP + lo] = v; else grow = true;
+                {
+                    // The first four entries of a join's row against the support, which sits in the lanes' registers: one
+                    // readlane per support entry and a compare per row entry, no dependent LDS reads (the binary search
+                    // below cost 74 cycles per join, most of it the latency of its probes); further entries the slow way.
+                    const bool act = isj && lane >= s0;
+                    i32 d4[4];
+                    double v4[4];
+                    int sl[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        d4[e] = -1; v4[e] = 0.0; sl[e] = -1;
+                        if (act && e < n) { d4[e] = rowi[e * 64 + lane]; v4[e] = rowv[e * 64 + lane]; }
+                    }
+                    for (int i = 0; i < SW; i++) {
+                        const i32 si = bc_i(wk.idx, i);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) sl[e] = d4[e] == si ? i : sl[e];
+                    }
+                    if (act) {
+                        for (int i = 0; i < SW; i++) addm[lane * SWP + i] = 0.0;
+#pragma unroll
+                        for (int e = 0; e < 4; e++)
+                            if (e < n) { if (sl[e] >= 0) addm[lane * SWP + sl[e]] = v4[e]; else grow = true; }
+                        for (int e = 4; e < n; e++) {
+                            const i32 d = e < FS_NP ? rowi[e * 64 + lane] : r.idx[(i64)e * r.stride + row];
+                            const double v = e < FS_NP ? rowv[e * 64 + lane] : r.val[(i64)e * r.stride + row];
+                            int lo = 0, hi = SW;
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (supl[mid] < d) lo = mid + 1; else hi = mid; }
+                            if (lo < SW && supl[lo] == d) addm[lane * SWP + lo] = v; else grow = true;
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
