@@ -26,8 +26,8 @@ id, the ranks' agreement that every one of them got its communicator) is a TCP c
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_fill3 unless the tables force the general
 fallback) with the algorithmic bytes of SURVEY.md section 8(d): B = 24*A/M + 16 bytes per landmark vector;
-`roofline.frac_step` is the same for the whole step (fill + assignment); `roofline.limiter` / `roofline.valu` say what
-the counters say limits the kernel (vector-instruction issue, not HBM).  `cpu_baseline` = the oracle's C port of the
+`roofline.frac_step` is the same for the whole step (ms_per_step: fill + assignment + launch gaps); `roofline.limiter`
+/ `roofline.valu` say what the counters say keeps the kernel below that roofline.  `cpu_baseline` = the oracle's C port of the
 same pass on a bounded cut, one thread (the reference's execution model) and all host cores.
 """
 import argparse
@@ -195,12 +195,19 @@ def main():
         normed = fit_ctx_centers / np.linalg.norm(fit_ctx_centers, axis=1)[:, None]
     ctx.set_centers(normed, True)
 
-    def step():
-        rc, nz, err = ctx.fill(False, False, True, assign=True, predict_threshold=0.8)
+    def check(rc, err):
         if rc != 0:
             raise RuntimeError("fill failed rc=%d frame=%d index=%d: %s" % (rc, err.frame, err.index, ctx.message()))
 
+    def step():
+        # one pass, enqueued (sit_fill with defer = 1: no host synchronisation per pass; the error word of every pass is
+        # still read back and decoded - by a later call, or by fill_result() below)
+        rc, nz, err = ctx.fill(False, False, True, assign=True, predict_threshold=0.8, store_rows=False, defer=True)
+        check(rc, err)
+
     def sync_all():
+        rc, nz, err = ctx.fill_result()        # waits for the passes in flight; the first failure among them, if any
+        check(rc, err)
         ctx.synchronize()
         if comm is not None:
             comm.barrier()
@@ -245,9 +252,10 @@ def main():
         value = n_lvec / elapsed
         bytes_per_lvec = 24.0 * A / M + 16.0
         fill_avg_ms = float(laps["fill"][0])
-        step_ms = fill_avg_ms + float(laps["predict"][0])
+        step_ms = 1e3 * elapsed / args.steps
         achieved = (F * M * bytes_per_lvec) / (fill_avg_ms * 1e-3) / 1e9
         kernel = "k_fill%d" % info["fill_kernel"] if info["fill_kernel"] > 1 else "k_fill_rows"
+        valu = measured_valu(kernel, args.config)
         out = {
             "metric": "landmark-vectors/sec (frames x mobile atoms), fill + site assignment",
             "value": value, "unit": "lvec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -260,11 +268,14 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kernel),
                          "kernel": kernel, "kernel_ms": fill_avg_ms,
                          "algorithmic_bytes_per_lvec": bytes_per_lvec,
+                         # the whole step (fill + assignment + launch gaps = ms_per_step) against the same bytes
                          "frac_step": (F * M * bytes_per_lvec) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         # what the counters say limits the kernel (profiles/pmc_valu.json, taken with this build)
-                         "limiter": "valu-issue", "valu": measured_valu(kernel, args.config)},
+                         # `bound` names the roofline the kernel is priced against (its bytes are 1.09x the algorithmic
+                         # ones: no wasted traffic); what the counters say holds it below that roofline
+                         # (profiles/pmc_valu.json, taken with this build; null if the library has changed since):
+                         "limiter": limiter_of(valu), "valu": valu},
             "clock_ramp_steps": ramp,
-            "fill_shape": {k: info.get(k) for k in ("waves_per_workgroup", "frames_per_workgroup", "survivors_per_wave", "task_table_per_wave")},
+            "fill_shape": {k: info.get(k) for k in ("waves_per_workgroup", "frames_per_workgroup", "survivors_per_wave", "task_table_per_wave", "assignment_fused")},
             "stages_ms": {"fill": fill_avg_ms, "predict": float(laps["predict"][0]), "h2d_frames": h2d_ms,
                           "generate_s": round(t_gen, 2)},
             "end_to_end_run": e2e,
@@ -302,6 +313,17 @@ def measured_traffic(kernel):
     return None
 
 
+def limiter_of(valu):
+    """What the SQ counters say keeps the kernel below its HBM roofline: the SIMDs' vector-issue slots (issue_frac
+    >= 0.7), or the waves' waits (memory / LDS latency that the resident waves do not cover)."""
+    if not valu or "issue_frac" not in valu:
+        return None
+    if valu["issue_frac"] >= 0.7:
+        return "valu-issue (SIMDs issue a vector instruction in %.0f %% of the cycles)" % (100 * valu["issue_frac"])
+    return "latency (vector issue in %.0f %% of the cycles, waves waiting %.0f %% of their time)" % (
+        100 * valu["issue_frac"], 100 * valu.get("wait_frac", float("nan")))
+
+
 def measured_valu(kernel, config):
     """Vector-instruction counters of the fill kernel from the PMC passes kept under profiles/ (SURVEY.md section 8d:
     the FP64-VALU side of the roofline): wave instructions per landmark vector, the FP64 arithmetic among them (the
@@ -311,7 +333,7 @@ def measured_valu(kernel, config):
     try:
         rec = json.load(open(vpath))
         if rec.get("lib_sha16") == lib_sha() and rec.get("kernel") == kernel and rec.get("config") == config:
-            return {k: rec[k] for k in ("insts_per_ion", "floor_insts_per_ion", "issue_frac", "salu_per_ion") if k in rec}
+            return {k: rec[k] for k in ("insts_per_ion", "floor_insts_per_ion", "issue_frac", "wait_frac", "salu_per_ion") if k in rec}
     except Exception:
         pass
     return None

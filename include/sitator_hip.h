@@ -38,7 +38,8 @@ enum sit_status {
     SIT_ERR_ZERO_LANDMARK = 5,      /* ZeroLandmarkError,  landmark/helpers.pyx:116-118     */
     SIT_ERR_MULTIPLE_OCCUPANCY = 6, /* MultipleOccupancyError, SiteTrajectory.py:219-226    */
     SIT_ERR_NOT_CONVERGED = 7,      /* ValueError, util/DotProdClassifier.pyx:312-313       */
-    SIT_ERR_CAPACITY = 8            /* an internal capacity was exceeded (message says which)*/
+    SIT_ERR_CAPACITY = 8,           /* an internal capacity was exceeded (message says which)*/
+    SIT_RETRY = 9                   /* a deferred sit_fill must be repeated (sit_fill_result)  */
 };
 
 /* kind = one of sit_status; frame / index / aux as the matching reference exception:
@@ -114,17 +115,28 @@ typedef struct sit_fill_params {
     int32_t dynamic_lattice_mapping;   /* helpers.pyx:60-64,83 */
     int32_t relaxed_lattice_checks;    /* helpers.pyx:87       */
     int32_t check_for_zeros;           /* helpers.pyx:116-120  */
-    int32_t store_rows;                /* keep the sparse rows on the device (fit / mcl)   */
-    int32_t assign;                    /* run DotProdClassifier.predict behind the fill in the same call (needs centres) */
+    int32_t store_rows;                /* keep the sparse rows on the device (fit / mcl); without `assign` they always are */
+    int32_t assign;                    /* DotProdClassifier.predict (util/DotProdClassifier.pyx:129-197) in the same pass:
+                                          rows of up to four entries are assigned inside the fill kernel and never leave
+                                          the chip, wider ones by a second kernel (needs centres: sit_set_centers)        */
     int32_t predict_normed;            /* util/DotProdClassifier.pyx:155-161               */
     double  predict_threshold;         /* util/DotProdClassifier.pyx:184                   */
+    int32_t defer;                     /* 1: enqueue only - no host synchronisation; status, n_all_zero and the error of
+                                          this pass come from sit_fill_result (or a later sit_fill / sit_synchronize)  */
+    int32_t reserved_;
 } sit_fill_params;
 
 /* One streaming pass over the resident frames: wrap, static-lattice check, landmark vector
- * per (frame, ion); with `assign` the site assignment is enqueued behind it without a host round trip.
+ * per (frame, ion); with `assign` the site assignment in the same pass, without a host round trip.
  * n_all_zero = self.n_all_zero_lvecs.
- * On a domain error returns its status and fills *err.                                    */
+ * On a domain error returns its status and fills *err.
+ * With `defer` the call returns SIT_OK as soon as the pass is enqueued (*n_all_zero = -1); up to four such passes may be in
+ * flight.  The reference raises from inside its frame loop (helpers.pyx:76-92,116-118); a deferred pass raises when
+ * its result is collected: sit_fill_result waits for every pass in flight and returns the first failure (with *err),
+ * a later sit_fill returns a failure that has landed meanwhile INSTEAD of running, sit_synchronize returns it too.
+ * SIT_RETRY: a row was wider than the buffers of the pass (measured on the leading frames) - call sit_fill again.  */
 int sit_fill(sit_ctx *ctx, const sit_fill_params *p, int64_t *n_all_zero, sit_error *err);
+int sit_fill_result(sit_ctx *ctx, int64_t *n_all_zero, sit_error *err);
 
 /* sit_set_frames + sit_fill (rows stored) + sit_fit_reset + sit_fit_push_stored_rows(fit_threshold) in one call, with
  * the upload overlapped: the trajectory goes to the GPU in chunks on a copy stream while the chunks that have arrived
@@ -303,7 +315,7 @@ int sit_timers(sit_ctx *ctx, double *ms, int n);
  * rows at a cut) / [15] steps cut short by a wrong speculation, summed over the speculative fits of the context,
  * [16] generation of the fill kernel the last sit_fill launched (1 or 3), [17] survivor slots per wave and
  * [18] waves per workgroup of that launch, [19] capacity bits that ended a speculative fit (0: none) and
- * [20] the row it stopped at, [21] task-table entries per wave of that launch, [24..27] work census of a SITATOR_DEBUG_STOP=9 fill.                         */
+ * [20] the row it stopped at, [21] task-table entries per wave of that launch, [22] 1 if the last sit_fill assigned the narrow rows inside the fill kernel, [24..27] work census of a SITATOR_DEBUG_STOP=9 fill.                         */
 int sit_info(sit_ctx *ctx, double *out, int n);
 int sit_synchronize(sit_ctx *ctx);
 

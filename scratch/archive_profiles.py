@@ -57,6 +57,7 @@ if "SQ_INSTS_VALU" in fill and "GRBM_GUI_ACTIVE" in fill:
     json.dump({"kernel": FILL, "config": "C2", "insts_per_ion": round(fill["SQ_INSTS_VALU"] / ions, 2),
                "floor_insts_per_ion": round(floor / ions, 2), "salu_per_ion": round(fill["SQ_INSTS_SALU"] / ions, 2),
                "issue_frac": round(fill["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (fill["GRBM_GUI_ACTIVE"] / 8.0), 3),
+               "wait_frac": round(fill["SQ_WAIT_ANY"] / fill["SQ_WAVE_CYCLES"], 3),
                "lib_sha16": open(os.path.join(src, "lib_sha16")).read().strip(), "build": name,
                "note": "wave instructions per (frame, ion); floor = FP64 add / mul / fma / transcendental instructions; "
                        "issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs"},

@@ -10,10 +10,10 @@ import numpy as np
 from . import errors
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsitator_hip.so")
+LIB_PATH = os.environ.get("SITATOR_LIB") or os.path.join(_HERE, "lib", "libsitator_hip.so")     # SITATOR_LIB: another build (A/B runs)
 
 OK, E_INVALID, E_HIP, E_STATIC_THRESHOLD, E_STATIC_UNASSIGNED, E_ZERO_LANDMARK, \
-    E_MULTIPLE_OCCUPANCY, E_NOT_CONVERGED, E_CAPACITY = range(9)
+    E_MULTIPLE_OCCUPANCY, E_NOT_CONVERGED, E_CAPACITY, RETRY = range(10)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
@@ -30,7 +30,8 @@ class SitError(C.Structure):
 class FillParams(C.Structure):
     _fields_ = [("dynamic_lattice_mapping", C.c_int32), ("relaxed_lattice_checks", C.c_int32),
                 ("check_for_zeros", C.c_int32), ("store_rows", C.c_int32), ("assign", C.c_int32),
-                ("predict_normed", C.c_int32), ("predict_threshold", C.c_double)]
+                ("predict_normed", C.c_int32), ("predict_threshold", C.c_double), ("defer", C.c_int32),
+                ("reserved_", C.c_int32)]
 
 
 # every symbol include/sitator_hip.h declares: (restype, argtypes)
@@ -49,6 +50,7 @@ SIGNATURES = {
     "sit_set_frames_device": (C.c_int, [_vp, _vp, i64, i64, _ip, i64, _ip, i64, i64]),
     "sit_frames_device_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "sit_fill": (C.c_int, [_vp, C.POINTER(FillParams), _ip, C.POINTER(SitError)]),
+    "sit_fill_result": (C.c_int, [_vp, _ip, C.POINTER(SitError)]),
     "sit_upload_fill_fit": (C.c_int, [_vp, _dp, i64, i64, _ip, i64, _ip, i64, i64, C.POINTER(FillParams), C.c_double, _ip,
                                       C.POINTER(SitError), C.POINTER(C.c_int)]),
     "sit_static_seen": (C.c_int, [_vp, i64, _u8p]),
@@ -287,15 +289,31 @@ class HipContext(object):
 
     # -- landmark vectors
     def fill(self, dynamic_lattice_mapping=False, relaxed_lattice_checks=False, check_for_zeros=True,
-             assign=False, predict_threshold=0.0, store_rows=True):
+             assign=False, predict_threshold=0.0, store_rows=True, defer=False):
+        """One pass over the resident frames (``sit_fill``).  ``assign``: the site assignment in the same pass (rows of up
+        to four entries inside the fill kernel).  ``defer``: enqueue only; status, ``n_all_zero`` and the error come from
+        ``fill_result()`` (or a later ``fill`` / ``synchronize``)."""
         p = FillParams(int(dynamic_lattice_mapping), int(relaxed_lattice_checks), int(check_for_zeros),
-                       int(store_rows), int(assign), 1, float(predict_threshold))
+                       int(store_rows), int(assign), 1, float(predict_threshold), int(defer), 0)
         nz = i64(0)
         err = SitError()
         if assign:
             self.labels_version += 1
             self.labels_digest = None
+        self._last_fill = p
         rc = self.lib.sit_fill(self._h, C.byref(p), C.byref(nz), C.byref(err))
+        return rc, nz.value, err
+
+    def fill_result(self):
+        """Status, ``n_all_zero`` and error of the deferred passes in flight (waits for them; the first failure wins).
+        A pass whose rows outgrew the buffers measured on the leading frames (``SIT_RETRY``) is run again, blocking."""
+        nz = i64(0)
+        err = SitError()
+        rc = self.lib.sit_fill_result(self._h, C.byref(nz), C.byref(err))
+        if rc == RETRY:
+            p = self._last_fill
+            p.defer = 0
+            rc = self.lib.sit_fill(self._h, C.byref(p), C.byref(nz), C.byref(err))
         return rc, nz.value, err
 
     def static_seen(self, local_frame):
@@ -633,6 +651,7 @@ class HipContext(object):
         out["fill_kernel"], out["survivors_per_wave"], out["waves_per_workgroup"] = int(v[16]), int(v[17]), int(v[18])
         out["fit_capacity_hit"], out["fit_stop_row"] = int(v[19]), int(v[20])
         out["task_table_per_wave"] = int(v[21])
+        out["assignment_fused"] = bool(v[22])
         out["census"] = [float(x) for x in v[24:28]]
         return out
 

@@ -50,44 +50,11 @@ struct PredArgs {
 __device__ __forceinline__ i64 finish_predict(const PredArgs &a, i64 row, Best b)
 {
     i64 to; double conf;
-    if (b.i < 0 || (!b.nan && b.v == 0.0)) { to = 0; conf = 0.0; }
-    else { to = b.i; conf = b.v; }
-    if (conf < a.threshold) { to = -1; conf = 0.0; }                  // :184-186 (NaN: false)
+    finish_assignment(b, a.threshold, to, conf);                      // :184-186
     a.labels[row] = to;
     a.confs[row] = conf;
     return to;
 }
-
-// Running argmax of fabs(dot_k) / xn over centres visited in ASCENDING id (numpy argmax: first maximum, NaN first).
-// Dividing by the same xn is monotonic, so the quotient of a later centre can only be STRICTLY greater if its
-// |dot| is greater; when it is greater by more than a few ulps the quotient is certainly greater and no division
-// is needed, inside that band both quotients are computed (rare).  One division per row instead of one per centre.
-struct ArgMaxQ {
-    double m;      // |dot| of the incumbent (undivided)
-    i64 i;         // its centre id, -1 = none yet
-    int nan;
-
-    __device__ __forceinline__ void init() { m = 0.0; i = -1; nan = 0; }
-    __device__ __forceinline__ void push(double dot, i64 cid, double xn, bool normed)
-    {
-        const double v = fabs(dot);
-        if (nan) return;                                   // the first NaN stays (np.argmax)
-        if (isnan(v)) { m = v; i = cid; nan = 1; return; }
-        if (i < 0) { m = v; i = cid; return; }
-        if (!(v > m)) return;
-        if (normed && !(v > m * (1.0 + 1e-15))) {
-            if (!(v / xn > m / xn)) return;                // equal quotients: the earlier centre keeps the place
-        }
-        m = v; i = cid;
-    }
-    __device__ __forceinline__ Best result(double xn, bool normed) const
-    {
-        Best b;
-        b.i = i; b.nan = nan;
-        b.v = (i >= 0 && normed) ? m / xn : m;             // :177-178 (NaN / xn stays NaN)
-        return b;
-    }
-};
 
 // Rows with more than four entries.  Candidate centres are enumerated from the CSC columns of the row's dimensions;
 // the (row entry e, column entry) pair that sees a centre FIRST (no earlier row dimension holds it) owns it and
@@ -133,31 +100,12 @@ __device__ i64 predict_row_generic(const PredArgs &a, i64 row, int n, double xn)
 __device__ __forceinline__ i64 predict_row_merge(const PredArgs &a, i64 row, int n, double xn, const i32 *col_ptr,
                                                   const i32 *col_k, const double *col_val)
 {
-    ArgMaxQ am;
-    am.init();
-    i32 q0 = 0, q1 = 0, q2 = 0, q3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-    { const i32 d = a.row_idx[row]; q0 = col_ptr[d]; e0 = col_ptr[d + 1]; v0 = a.row_val[row]; }
-    if (n > 1) { const i32 d = a.row_idx[a.N + row]; q1 = col_ptr[d]; e1 = col_ptr[d + 1]; v1 = a.row_val[a.N + row]; }
-    if (n > 2) { const i32 d = a.row_idx[2 * a.N + row]; q2 = col_ptr[d]; e2 = col_ptr[d + 1]; v2 = a.row_val[2 * a.N + row]; }
-    if (n > 3) { const i32 d = a.row_idx[3 * a.N + row]; q3 = col_ptr[d]; e3 = col_ptr[d + 1]; v3 = a.row_val[3 * a.N + row]; }
-    const i32 none = 0x7fffffff;
-    i32 h0 = q0 < e0 ? col_k[q0] : none, h1 = q1 < e1 ? col_k[q1] : none;
-    i32 h2 = q2 < e2 ? col_k[q2] : none, h3 = q3 < e3 ? col_k[q3] : none;
-    while (true) {
-        i32 cid = h0 < h1 ? h0 : h1;
-        const i32 m23 = h2 < h3 ? h2 : h3;
-        cid = cid < m23 ? cid : m23;
-        if (cid == none) break;
-        double dot = 0.0;
-        bool first = true;
-        if (h0 == cid) { const double t = col_val[q0] * v0; dot = t; first = false; q0++; h0 = q0 < e0 ? col_k[q0] : none; }
-        if (h1 == cid) { const double t = col_val[q1] * v1; dot = first ? t : dot + t; first = false; q1++; h1 = q1 < e1 ? col_k[q1] : none; }
-        if (h2 == cid) { const double t = col_val[q2] * v2; dot = first ? t : dot + t; first = false; q2++; h2 = q2 < e2 ? col_k[q2] : none; }
-        if (h3 == cid) { const double t = col_val[q3] * v3; dot = first ? t : dot + t; first = false; q3++; h3 = q3 < e3 ? col_k[q3] : none; }
-        am.push(dot, cid, xn, a.normed != 0);                       // :177-179
-    }
-    return finish_predict(a, row, am.result(xn, a.normed != 0));
+    i32 d0 = a.row_idx[row], d1 = 0, d2 = 0, d3 = 0;
+    double v0 = a.row_val[row], v1 = 0, v2 = 0, v3 = 0;
+    if (n > 1) { d1 = a.row_idx[a.N + row]; v1 = a.row_val[a.N + row]; }
+    if (n > 2) { d2 = a.row_idx[2 * a.N + row]; v2 = a.row_val[2 * a.N + row]; }
+    if (n > 3) { d3 = a.row_idx[3 * a.N + row]; v3 = a.row_val[3 * a.N + row]; }
+    return finish_predict(a, row, merge4_row(n, d0, d1, d2, d3, v0, v1, v2, v3, xn, a.normed != 0, col_ptr, col_k, col_val));
 }
 
 // The same merge for rows of up to NW entries (ragged bases: C5 rows hold 5-13).  The column heads live in registers
@@ -224,22 +172,7 @@ __device__ __forceinline__ bool predict_row_head(const PredArgs &a, i64 row, int
 // the rows hold 5-8 entries, 29 % hold 9; mixed, every wave paid an 8-wide and a 16-wide merge).
 __device__ __forceinline__ void list_wide_rows(int n, bool live, i64 row, i32 *seg, unsigned *seg_count, i64 seg_cap, int lane)
 {
-    const bool ca = live && n > 4 && n <= 8, cb = live && n > 8;
-    const unsigned long long ma = __ballot(ca), mb = __ballot(cb);
-    if (ma) {                                                      // one atomic per wave and class, on the workgroup's own counter
-        const int leader = __ffsll((long long)ma) - 1;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(seg_count, (unsigned)__popcll(ma));
-        base = __shfl(base, leader);
-        if (ca) seg[base + __popcll(ma & ((1ull << lane) - 1ull))] = (i32)row;
-    }
-    if (mb) {
-        const int leader = __ffsll((long long)mb) - 1;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(seg_count + 1, (unsigned)__popcll(mb));
-        base = __shfl(base, leader);
-        if (cb) seg[seg_cap - 1 - (i64)(base + __popcll(mb & ((1ull << lane) - 1ull)))] = (i32)row;
-    }
+    list_rows_by_class(live && n > 4 && n <= 8, live && n > 8, row, seg, seg_count, seg_cap, lane);
 }
 
 __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows(PredArgs a, i32 *wide_list, unsigned *wide_count, i64 seg_cap)
@@ -527,6 +460,34 @@ static int run_predict(sit_ctx *c, double threshold, bool words_reset = false)
     } else k_predict_rows_dense<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
     HIP_TRY(c, hipGetLastError());
     if (!counted && (rc = sit_label_counts(c))) return rc;      // np.bincount(labels[labels >= 0]) (:92)
+    t.stop();
+    c->assign_valid = true;
+    return SIT_OK;
+}
+
+// Behind a fused fill (k_fill3 with FUSE = 1: the narrow rows are assigned, labels and confidences written): the rows it
+// listed - more than four entries, or a window that spilled to the row buffers - through the wide-row kernels, then the
+// label counts (np.bincount of :92) over all labels.
+int predict_listed_rows(sit_ctx *c, double threshold, i32 *wlist, unsigned *wcount, i64 seg_cap, int nseg)
+{
+    PredArgs a;
+    a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx; a.row_val = c->d_row_val;
+    a.col_ptr = c->d_col_ptr; a.col_k = c->d_col_k; a.col_val = c->d_col_val; a.dense = c->d_cen_dense;
+    a.labels = c->d_labels; a.confs = c->d_confs;
+    a.N = c->rows_N; a.K = c->K; a.D = c->D; a.normed = c->centers_normed; a.threshold = threshold;
+    const int ncu = c->num_cu > 0 ? c->num_cu : 256;
+    const size_t csc = (size_t)c->csc_nnz * 12 + (size_t)(c->D + 1) * 4 + 16;
+    const char *pl = getenv("SITATOR_PREDICT_LDS");
+    const bool wide_lds = csc <= 150 * 1024 && !(pl && pl[0] == '0');
+    StageTimer t(c, T_PREDICT);
+    if (wide_lds) {
+        HIP_TRY(c, lds_limit((const void *)k_predict_rows_wide_lds, csc, c->device));
+        k_predict_rows_wide_lds<<<dim3((unsigned)std::min(ncu, nseg)), dim3(PRED_WIDE_LDS_BLOCK), csc, c->stream>>>(a, wlist, wcount, seg_cap, nseg, (int)c->csc_nnz, nullptr);
+    } else
+        k_predict_rows_wide<<<dim3((unsigned)std::min(nseg, ncu * 8)), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, seg_cap, nseg, nullptr);
+    HIP_TRY(c, hipGetLastError());
+    int rc = sit_label_counts(c, false);
+    if (rc) return rc;
     t.stop();
     c->assign_valid = true;
     return SIT_OK;

@@ -221,7 +221,7 @@ extern "C" int sit_create(const double *cell, const double *cell_inv, int device
     c->copy_stream = stream_take(device, 1);
     if (!c->stream || !c->copy_stream) { c->msg = "stream creation failed"; return SIT_ERR_HIP; }
     for (int i = 0; i < T_N; i++) { HIP_TRY(c, hipEventCreate(&c->tev0[i])); HIP_TRY(c, hipEventCreate(&c->tev1[i])); }
-    HIP_TRY(c, hipHostMalloc(&c->h_pinned, 256));
+    HIP_TRY(c, hipHostMalloc(&c->h_pinned, 1024));      // [0, 512): one-off read-backs; [512, 1024): the results of deferred fills
     // the error key and the counters sit side by side: one read-back per call
     HIP_TRY(c, hipMalloc((void **)&c->d_err, sizeof(u64) * 17));
     c->d_scal = c->d_err + 1;
@@ -242,6 +242,7 @@ extern "C" void sit_destroy(sit_ctx *c)
                     c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scratch};
     for (void *p : ptrs) if (p) sit_dfree(c, p);
     fitfast_free(c);
+    fill_ring_free(c);
     stream_give(c->device, 1, c->copy_stream);
     for (int i = 0; i < T_N; i++) { if (c->tev0[i]) (void)hipEventDestroy(c->tev0[i]); if (c->tev1[i]) (void)hipEventDestroy(c->tev1[i]); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -268,7 +269,7 @@ extern "C" int sit_info(sit_ctx *c, double *out, int n)
                           c->tight_delta, (double)c->fallback_frames, (double)c->G[0], (double)c->G[1],
                           (double)c->G[2], (double)c->tG[0], (double)c->tG[1], (double)c->tG[2], (double)c->last_fpb,
                           (double)c->ff_batches, (double)c->ff_serial_rows, (double)c->ff_rewalks,
-                          (double)c->last_kernel, (double)c->last_iw, (double)c->last_nw, (double)c->ff_why, (double)c->ff_stop_row, (double)c->last_tt, 0.0, 0.0,
+                          (double)c->last_kernel, (double)c->last_iw, (double)c->last_nw, (double)c->ff_why, (double)c->ff_stop_row, (double)c->last_tt, c->last_fused ? 1.0 : 0.0, 0.0,
                           c->census[0], c->census[1], c->census[2], c->census[3]};
     for (int i = 0; i < n; i++) out[i] = i < 28 ? v[i] : 0.0;
     return SIT_OK;
@@ -279,7 +280,9 @@ extern "C" int sit_synchronize(sit_ctx *c)
     if (!c) return SIT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return SIT_OK;
+    // deferred fills: their results have landed now; a failure among them is this call's status (sit_fill_result has
+    // the details and clears it)
+    return fill_results_landed(c);
 }
 
 // ---- PBCCalculator surface ---------------------------------------------------------------

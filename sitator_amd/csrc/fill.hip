@@ -378,9 +378,9 @@ static int launch_label_hist(sit_ctx *c, const i64 *d_labels, i64 N, i64 K, u64 
     return SIT_OK;
 }
 
-int sit_label_counts(sit_ctx *c)
+int sit_label_counts(sit_ctx *c, bool zero)
 {
-    HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
+    if (zero) HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
     return launch_label_hist(c, c->d_labels, c->N, c->K, (u64 *)c->d_counts);
 }
 
@@ -471,22 +471,133 @@ static int measured_row_width(sit_ctx *c, const sit_fill_params *p, i64 *W_out)
     return SIT_OK;
 }
 
+// The words a fill leaves behind (error key, counters), read back and decoded.  A DEFERRED call (sit_fill_params.defer)
+// only enqueues the read-back of its words into a slot of a small ring of pinned buffers and records an event; the
+// result is decoded when it is asked for (sit_fill_result, sit_synchronize) or when a later call finds it has landed -
+// so a loop of passes keeps the GPU busy instead of waiting for 72 bytes after every pass.
+struct FillPending {
+    hipEvent_t ev = nullptr;
+    u64 *host = nullptr;              // 9 words in the pinned buffer
+    bool v3 = false, rows_measured = false;
+    bool live = false;
+};
+#define FILL_RING 4
+struct FillRing {
+    FillPending slot[FILL_RING];
+    int head = 0, count = 0;          // oldest live slot, number of live slots
+    int rc_first = SIT_OK;            // first failure among the decoded results not yet reported
+    sit_error err_first = {0, -1, -1, 0};
+    i64 n_all_zero_last = 0;
+};
+
+static FillRing *fill_ring(sit_ctx *c)
+{
+    if (!c->fill_ring) c->fill_ring = new FillRing();
+    return (FillRing *)c->fill_ring;
+}
+
+void fill_ring_free(sit_ctx *c)
+{
+    FillRing *r = (FillRing *)c->fill_ring;
+    if (!r) return;
+    for (FillPending &s : r->slot) if (s.ev) (void)hipEventDestroy(s.ev);
+    delete r;
+    c->fill_ring = nullptr;
+}
+
+// decode one landed result; returns its status
+static int fill_decode(sit_ctx *c, const FillPending &s, i64 *n_all_zero, sit_error *err)
+{
+    const u64 *hb = s.host;
+    const u64 hkey = hb[0], hs[4] = {hb[1], hb[2], hb[3], hb[4]};
+    for (int q = 0; q < 4; q++) c->census[q] = (double)hb[5 + q];
+    if (n_all_zero) *n_all_zero = (i64)hs[0];
+    c->fallback_frames = (i64)hs[2];
+    const int kind = decode_error(c, hkey, err);
+    if (kind != SIT_OK) { c->assign_valid = false; return kind; }
+    if (s.v3 && hs[3]) {
+        c->assign_valid = false; c->rows_valid = false;
+        if (s.rows_measured) { c->rows_overflowed = true; return SIT_RETRY; }       // a row beyond the measured width: once more at the rigorous one
+        c->msg = "landmark row wider than the pruning bound (internal error)";
+        return SIT_ERR_CAPACITY;
+    }
+    return SIT_OK;
+}
+
+// Results that have landed (wait = false) or all of them (wait = true), oldest first; the first failure is kept
+static int fill_drain(sit_ctx *c, bool wait)
+{
+    FillRing *r = fill_ring(c);
+    while (r->count > 0) {
+        FillPending &s = r->slot[r->head];
+        if (wait) HIP_TRY(c, hipEventSynchronize(s.ev));
+        else {
+            const hipError_t q = hipEventQuery(s.ev);
+            if (q == hipErrorNotReady) break;
+            HIP_TRY(c, q);
+        }
+        sit_error e = {0, -1, -1, 0};
+        i64 nz = 0;
+        const int rc = fill_decode(c, s, &nz, &e);
+        r->n_all_zero_last = nz;
+        if (rc != SIT_OK && r->rc_first == SIT_OK) { r->rc_first = rc; r->err_first = e; }
+        s.live = false;
+        r->head = (r->head + 1) % FILL_RING; r->count--;
+    }
+    return SIT_OK;
+}
+
+int fill_results_landed(sit_ctx *c)
+{
+    if (!c->fill_ring) return SIT_OK;
+    const int rc = fill_drain(c, false);
+    return rc ? rc : ((FillRing *)c->fill_ring)->rc_first;
+}
+
+extern "C" int sit_fill_result(sit_ctx *c, i64 *n_all_zero, sit_error *err)
+{
+    if (!c) return SIT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = fill_drain(c, true);
+    if (rc) return rc;
+    FillRing *r = fill_ring(c);
+    if (n_all_zero) *n_all_zero = r->n_all_zero_last;
+    if (err) *err = r->err_first;
+    rc = r->rc_first;
+    r->rc_first = SIT_OK; r->err_first = {0, -1, -1, 0};
+    return rc;
+}
+
 extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, sit_error *err)
 {
     if (!c || !p) return SIT_ERR_INVALID;
     SIT_REQUIRE(c, c->D > 0 && c->d_frames && c->M > 0, "sit_fill: basis and frames must be set first");
     HIP_TRY(c, hipSetDevice(c->device));
     if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
+    FillRing *ring = fill_ring(c);
+    int rc;
+    // earlier deferred passes: a failure that has landed is reported now, in place of this pass (a blocking call waits
+    // for all of them first)
+    if ((rc = fill_drain(c, !p->defer || ring->count == FILL_RING))) return rc;
+    if (ring->rc_first != SIT_OK) {
+        rc = ring->rc_first;
+        if (err) *err = ring->err_first;
+        ring->rc_first = SIT_OK; ring->err_first = {0, -1, -1, 0};
+        if (rc != SIT_RETRY) return rc;                      // (a retry request is served by this very call)
+    }
     const i64 N = c->N;
     i64 W = c->W;
     const bool v3 = c->fill_kernel == 3 && fill3_eligible(c);
-    bool assign = p->assign != 0;
-    bool store = true;   // the assignment is a second kernel that reads the stored rows
+    const bool assign = p->assign != 0;
     if (assign) SIT_REQUIRE(c, c->K > 0 && c->d_col_ptr, "sit_fill: assign requested but no centres set");
-    int rc;
+    // with `assign` the narrow rows are assigned inside the fill kernel (fill3.hip, FUSE) and the rows need not be
+    // stored; otherwise the assignment is a second kernel that reads the stored rows
+    const bool want_fuse = assign && v3 && !p->dynamic_lattice_mapping;
+    bool store = p->store_rows != 0 || !want_fuse;
     for (int attempt = 0; attempt < 2; attempt++) {
-        if (store && v3 && (rc = measured_row_width(c, p, &W))) return rc;
-        if (store && (c->rows_W != W || c->rows_N != N || !c->d_row_nnz)) {
+        if (v3 && (rc = measured_row_width(c, p, &W))) return rc;
+        const bool rows_measured = W < c->W;
+        if (c->rows_W != W || c->rows_N != N || !c->d_row_nnz) {
             c->rows_valid = false;
             if ((rc = dev_alloc(c, &c->d_row_nnz, N))) return rc;
             if ((rc = dev_alloc(c, &c->d_row_idx, N * W))) return rc;
@@ -503,41 +614,55 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         }
         if (v3 && c->F > 0 && (rc = ensure_tight_table(c))) return rc;
         bool pred_reset = false;
-        // (the lattice-mapping pass keeps its flags in the scratch buffer the assignment's counters live in)
-        if ((rc = assign && !p->dynamic_lattice_mapping ? predict_reset_with_fill(c, &pred_reset) : reset_fill_words(c))) return rc;
+        // (the lattice-mapping pass keeps its flags in the scratch buffer the assignment's counters live in; the fused
+        // pass resets its words itself, once its launch shape is known)
+        if (!want_fuse || c->F == 0) {
+            if ((rc = assign && !p->dynamic_lattice_mapping ? predict_reset_with_fill(c, &pred_reset) : reset_fill_words(c))) return rc;
+        }
         if (c->F == 0) {
             if (n_all_zero) *n_all_zero = 0;
             c->rows_valid = store; c->assign_valid = assign;
             if (assign) HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(i64) * (size_t)c->K, c->stream));
             return SIT_OK;
         }
-        StageTimer timer(c, T_FILL);
-        if (p->dynamic_lattice_mapping && (rc = launch_lattice_map(c, p))) return rc;
-        if (v3) rc = fill3_launch(c, p, store);
-        else { c->last_kernel = 1; rc = launch_fill_v1(c, p); }
-        if (rc) return rc;
-        timer.stop();
-        // the assignment is enqueued behind the fill without waiting for the fill's error word: one host
-        // synchronisation per call (if the fill did report an error the assignment is simply discarded)
-        c->rows_valid = store;
-        c->assign_valid = false;
-        if (assign && (rc = sit_predict_internal(c, p->predict_threshold, pred_reset))) return rc;
-        u64 *hb = (u64 *)c->h_pinned;          // [0] error key, [1..4] scalars
-        HIP_TRY(c, hipMemcpyAsync(hb, c->d_err, 72, hipMemcpyDeviceToHost, c->stream));      // d_scal follows d_err
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        const u64 hkey = hb[0], hs[4] = {hb[1], hb[2], hb[3], hb[4]};
-        for (int q = 0; q < 4; q++) c->census[q] = (double)hb[5 + q];
-        if (n_all_zero) *n_all_zero = (i64)hs[0];
-        c->fallback_frames = (i64)hs[2];
-        const int kind = decode_error(c, hkey, err);
-        if (kind != SIT_OK) { c->assign_valid = false; return kind; }
-        if (v3 && hs[3]) {
-            c->assign_valid = false; c->rows_valid = false;
-            if (c->rows_W < c->W && attempt == 0) { c->rows_overflowed = true; continue; }     // a row beyond the measured width: once more at the rigorous one
-            c->msg = "landmark row wider than the pruning bound (internal error)";
-            return SIT_ERR_CAPACITY;
+        bool fused = false;
+        {
+            StageTimer timer(c, T_FILL);
+            if (p->dynamic_lattice_mapping && (rc = launch_lattice_map(c, p))) return rc;
+            if (v3) rc = fill3_launch(c, p, store, 0, -1, want_fuse, &fused);
+            else { c->last_kernel = 1; c->last_fused = false; rc = launch_fill_v1(c, p); }
+            if (rc) return rc;
+            timer.stop();
         }
-        return SIT_OK;
+        // the assignment is enqueued behind the fill without waiting for the fill's error word (if the fill did report
+        // an error the assignment is simply discarded)
+        c->rows_valid = store || !fused;
+        c->assign_valid = false;
+        if (assign) {
+            if (fused) rc = predict_listed_rows(c, p->predict_threshold, c->fuse_wlist, c->fuse_wcount, c->fuse_seg_cap, c->fuse_nseg);
+            else rc = sit_predict_internal(c, p->predict_threshold, pred_reset);
+            if (rc) return rc;
+        }
+        // the words of this pass: error key, [1..4] scalars, [5..8] census (d_scal follows d_err)
+        FillPending &s = ring->slot[(ring->head + ring->count) % FILL_RING];
+        if (!s.ev) HIP_TRY(c, hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+        s.host = (u64 *)((char *)c->h_pinned + 512) + 9 * ((ring->head + ring->count) % FILL_RING);
+        s.v3 = v3; s.rows_measured = rows_measured; s.live = true;
+        HIP_TRY(c, hipMemcpyAsync(s.host, c->d_err, 72, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipEventRecord(s.ev, c->stream));
+        ring->count++;
+        if (p->defer) {
+            if (n_all_zero) *n_all_zero = -1;               // known when the result is collected
+            return SIT_OK;
+        }
+        if ((rc = fill_drain(c, true))) return rc;
+        if (n_all_zero) *n_all_zero = ring->n_all_zero_last;
+        rc = ring->rc_first;
+        if (err && rc != SIT_OK) *err = ring->err_first;
+        ring->rc_first = SIT_OK; ring->err_first = {0, -1, -1, 0};
+        if (rc == SIT_RETRY && attempt == 0) continue;
+        if (rc == SIT_RETRY) { c->msg = "landmark row wider than the pruning bound (internal error)"; return SIT_ERR_CAPACITY; }
+        return rc;
     }
     return SIT_ERR_CAPACITY;
 }

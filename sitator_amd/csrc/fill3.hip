@@ -1,34 +1,39 @@
-// Landmark-vector fill, third generation (the one `sit_fill` launches by default for landmarks of up to 8 vertices).
+// Landmark-vector fill, third generation (the one `sit_fill` launches by default for landmarks of up to 16 vertices),
+// with the narrow-row site assignment fused behind it (FUSE = 1: `sit_fill` with assign = 1).
 //
-// Same result as fill2.hip (landmark/helpers.pyx:12-212: the same distances in the reference's operation order, FP64,
-// no contraction of the reference's expressions, the same zero pattern); what changes is where the instructions go.
+// landmark/helpers.pyx:12-212.  The ZERO PATTERN is the reference's bit for bit: squared distances are computed in the
+// reference's operation order (FP64, no contraction) and compared with exact per-(landmark, vertex) thresholds (below).
+// The VALUES are accurate, not bit-identical: Newton sequences without their final correctly-rounding step and a
+// table-driven exp put them within ~1e-14 relative of the reference's (the contract is 1e-6).
 // On gfx950 every vector instruction of this kernel costs 4-5 cycles of a SIMD whatever it computes (an FP64 multiply
 // 5.0, a 32-bit shift-add 4.3, a compare 4.3; only plain 32-bit add / and / mov are cheaper, `scratch/issue_cost.hip`)
 // and scalar instructions are nearly free, so the design rule is: few vector instructions, full lanes, masks and loop
 // control on the scalar unit.
-//   * a workgroup parks one frame (of a 64-ion system) in LDS, wrapped in place; the thread that wraps a mobile ion
-//     also looks up the ion's bin (64 busy lanes; an owner stage per wave window had 16);
+//   * a workgroup parks one frame (of a 64-ion system) in LDS (LDS-DMA where the frame is one run of doubles: no
+//     registers, no LDS stores), wrapped in place; the thread that wraps a mobile ion also looks up the ion's bin;
 //   * each wave then owns a window of the ions.  The candidate landmarks of the window form one flat task index
 //     space (a prefix sum over the window's list lengths); a lane per TASK finds its ion with a maximum scan over
-//     start markers, loads its list entry - the byte offset of the landmark's CRITICAL vertex record (the vertex with
-//     the least room in the ion's bin, from the table builder) - and tests that vertex; what passes is compacted into
-//     the wave's task table with a ballot;
+//     start markers, loads its list entry - 16 bytes: the landmark's CRITICAL vertex (the vertex with the least room
+//     in the ion's bin, from the table builder), that vertex's LDS offset and its exact threshold - and tests that
+//     vertex; what passes is compacted into the wave's task table with a ballot;
 //   * the remaining tasks take (task, vertex) LANES: eight lanes per task, one squared distance each, compared with
 //     the EXACT squared-distance threshold of (landmark, vertex): the largest double d2 for which the reference's
 //     RN(RN(sqrt(d2)) / vcd) > cutoff is false, found on the host by bisection over the doubles (sqrt and the division
 //     are monotone, so the comparison d2 > T2 is the reference's decision bit for bit).  Which tasks keep all their
 //     lanes is worked out on the scalar unit from the ballot (shift-or folds, inverse ballot as the execution mask);
-//   * the same lanes go on to the logistic term of their vertex, 1 + exp(steepness (t - midpoint)) - the zero pattern is
-//     settled, so sqrt / division / exp / reciprocal only need to be accurate: Newton sequences without their final
-//     correctly-rounding step, a 128-entry exp table (values within ~1e-14 relative of the reference, the bar is 1e-6)
-//     - and multiply the terms of a task with three DPP steps; the first lane of a surviving task appends (product,
-//     task) to the wave's list of survivors: 12 bytes each, where a region of squared distances for a separate
-//     factor stage took 64 and set the number of workgroups per CU;
-//   * one lane per survivor takes the reciprocal n-th root of the product and writes the row entry directly (its position in the row is a
-//     population count over the wave's non-zero mask);
+//   * the same lanes go on to the logistic term of their vertex, 1 + exp(steepness (t - midpoint)), and multiply the
+//     terms of a task with DPP steps; the first lane of a surviving task appends (product, task) to the wave's list
+//     of survivors: 12 bytes each;
+//   * at the end of the window one lane per survivor takes the reciprocal n-th root of the product.  The survivors are
+//     in task order (ion-major, ascending landmark): the list IS the window's sparse rows.  They are written to the
+//     row buffers (store_rows) and / or left in place for the assignment;
+//   * FUSE: the rows of 64 ions - the windows of a GROUP of waves; the last wave of the group to finish does it, nobody
+//     waits - are assigned a lane per ion: merge4_row (sit_internal.h, the arithmetic of k_predict_rows*) against the
+//     centres' CSC arrays in global memory (L2-resident), label and confidence written, the row itself never leaves
+//     LDS.  Rows of more than four entries (and the windows whose survivors did not fit the list) are written to the
+//     row buffers and LISTED for k_predict_rows_wide*;
 //   * nothing in phase 2 is shared between waves but the read-only frame: no workgroup barrier after phase 1.
 // LDS per workgroup is ~21 KB at 64 ions and 512 statics (seven workgroups = 28 waves per CU).
-// Kept from fill2: tight/loose pruning tables, error keys, slot-major sparse rows.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -48,18 +53,31 @@ struct Fill3Args {
                                       //   static id, exact squared-distance threshold (+inf on padding), 1 / vcd (-inf on
                                       //   padding: the factor of a padded vertex is exactly 1), 8 bytes unused}
     const unsigned char *nvtab;       // [D]
-    const unsigned *pack;             // list entries of the primary table, then of the fallback table:
-                                      // landmark << (LG + 5) | critical vertex << 5 = byte offset of that record in vh
+    const uint4 *pack;                // list entries of the primary table, then of the fallback table, 16 bytes each:
+                                      // {landmark << (LG + 5) | critical vertex << 5 = byte offset of that record in vh,
+                                      //  24 * static id of that vertex, its exact threshold}: all a candidate test needs
     const i32 *p_off, *f_off;         // bin offsets of the primary (tight) and the fallback (loose) table
     const i32 *lattice_map;           // [F,S] or null
     i32 *row_nnz, *row_idx;
-    double *row_val;
+    double *row_val;                  // null: rows are not stored (FUSE: the buffers are always there, see `store`)
     i64 N;
     int D, W;
     int pG0, pG1, pG2, fG0, fG1, fG2;
     unsigned f_base;                  // first fallback entry in pack
     int check_zeros;
     double midpoint, steepness;
+    int nv_uniform;                   // > 0: every landmark has this many vertices (nvtab is not read)
+    // ---- fused site assignment (FUSE = 1) ----
+    int store;                        // rows are wanted in the row buffers as well
+    const i32 *col_ptr, *col_k;       // the centres, CSC over the landmarks (sit_set_centers)
+    const double *col_val;
+    i64 *labels;
+    double *confs;
+    i32 *wlist;                       // rows left to k_predict_rows_wide*: nseg segments of seg_cap entries
+    unsigned *wcount;                 // two lengths per segment
+    i64 seg_cap;
+    int nseg, normed;
+    double threshold;
 };
 
 struct Fill3Head {
@@ -71,14 +89,14 @@ struct Fill3Head {
     const double *exptab;
     u64 *err, *scal;
     i64 F, A, frame0, fbeg;           // the launch covers frames [fbeg, F)
-    int S, M, fpb, contig, debug_stop, rcap, iw, has_fallback, s0, m0, tt, mcap;
+    int S, M, fpb, contig, debug_stop, rcap, iw, has_fallback, s0, m0, tt, mcap, frame_mod;
     double delta2, thr2_lo, thr2_hi, static_thr, safe2;
 };
 typedef const Fill3Args __attribute__((address_space(4))) *Fill3ArgsPtr;
 
 // LDS of a workgroup, in bytes from the start of the dynamic allocation
 struct F3Layout {
-    int fmax, ioninfo, etab, wave0;                      // after xyz[fpb][S + M][3] at offset 0
+    int fmax, gsync, ioninfo, etab, wave0;               // after xyz[fpb][S + M][3] at offset 0
     int o_ionrec, o_ttab, o_sv, o_nzc, o_mark, wbytes;   // inside a wave's region (prod at its offset 0)
     int total;
 };
@@ -88,7 +106,9 @@ __host__ __device__ inline F3Layout f3_layout(int fpb, int SM, int M, int nw, in
 {
     F3Layout L;
     int o = fpb * SM * 24;
+    o = (o + 15) & ~15;                                  // LDS-DMA lands whole 16-byte pieces
     L.fmax = o; o += fpb * 8;
+    L.gsync = o; o += nw * 8;                            // FUSE: arrivals per group of waves, "window spilled" per wave
     L.ioninfo = o; o += fpb * M * 8;                     // {first entry, entries | fallback bin << 8} per ion
     L.etab = o; o += F3_EXPN * 8;
     o = (o + 15) & ~15;
@@ -133,7 +153,7 @@ __device__ __forceinline__ double rcp_nr(double b)
 // The constants of exp_tab / vertex_term, held in VECTOR registers: the kernel is short of scalar registers (every
 // constant the compiler parks there pushes another value into a spill lane and costs VALU instructions to move).
 struct ExpK {
-    double log2e_128, magic, ln2_128_hi, ln2_128_lo, c5, c4, c3, mid, steep;
+    double log2e_128, magic, ln2_128, c4, c3, mid, steep;
 };
 __device__ __forceinline__ double in_vgpr(double x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ ExpK expk_make(double mid, double steep)
@@ -141,25 +161,23 @@ __device__ __forceinline__ ExpK expk_make(double mid, double steep)
     ExpK k;
     k.log2e_128 = in_vgpr(0x1.71547652b82fep+7);
     k.magic = in_vgpr(6755399441055744.0);             // 1.5 * 2^52: the integer lands in the low mantissa bits
-    k.ln2_128_hi = in_vgpr(0x1.62e42fefp-8);
-    k.ln2_128_lo = in_vgpr(0x1.473de6af278edp-41);
-    k.c5 = in_vgpr(1.0 / 120); k.c4 = in_vgpr(1.0 / 24); k.c3 = in_vgpr(1.0 / 6);
+    k.ln2_128 = in_vgpr(0x1.62e42fefa39efp-8);         // ln 2 / 128 to 53 bits: |n| < 2^17, so n * (its error) < 1e-14
+    k.c4 = in_vgpr(1.0 / 24); k.c3 = in_vgpr(1.0 / 6);
     k.mid = in_vgpr(mid); k.steep = in_vgpr(steep);
     return k;
 }
 
 // exp(x) for x <= ~10 (helpers.pyx:205: x = steepness * (t - midpoint) <= log(1/1e-4 - 1) by the cut-off):
-// x = (128 k + j) ln2/128 + r, exp = 2^k * T[j] * (1 + expm1(r))
+// x = (128 k + j) ln2/128 + r, |r| <= ln2/256, exp = 2^k * T[j] * (1 + expm1(r)) with expm1 to degree 4 (the next
+// term is r^5 / 120 < 1.3e-15)
 __device__ __forceinline__ double exp_tab(double x, const double *tab, const ExpK &k)
 {
     x = __builtin_fmax(x, -700.0);                     // exp(-700) ~ 1e-304: 1 + e == 1 all the same, no denormals
     const double u = __builtin_fma(x, k.log2e_128, k.magic);
     const double n = u - k.magic;
     const int ni = (int)(unsigned)__double_as_longlong(u);
-    double r = __builtin_fma(-n, k.ln2_128_hi, x);
-    r = __builtin_fma(-n, k.ln2_128_lo, r);
-    double q = __builtin_fma(r, k.c5, k.c4);
-    q = __builtin_fma(r, q, k.c3);
+    const double r = __builtin_fma(-n, k.ln2_128, x);
+    double q = __builtin_fma(r, k.c4, k.c3);
     q = __builtin_fma(r, q, 0.5);
     q = __builtin_fma(r, q, 1.0);
     const double p = r * q;
@@ -333,6 +351,106 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
         }                                                                                                                  \
     } while (0)
 
+// T: the n-th root (helpers.pyx:212) of the product (:208), one lane per survivor of the wave's list; the row entry of a
+// component is the number of earlier non-zero components of its ion (the survivors are in task order: ion-major,
+// ascending landmark).  FINAL = 0: the list is full in mid-window - its entries go to the row buffers and the window
+// counts as spilled.  FINAL = 1, the end of the window: the entries go to the row buffers (rows stored, or a spilled
+// window) and / or stay in the list for the fused assignment (prod[] = the values, nzc[ion] = first survivor << 8 |
+// entries).
+#define F3_T_ROUND(FINAL)                                                                                                  \
+    do {                                                                                                                   \
+        double val = 0.0;                                                                                                  \
+        unsigned kk = 0;                                                                                                   \
+        const bool tact = lane < cnt;                                                                                      \
+        if (tact) {                                                                                                        \
+            kk = sv[lane];                                                                                                 \
+            const double pr = prod[lane];                                                                                  \
+            if (nvu > 0) val = root_chain(pr, nvu);                      /* a scalar branch: one chain */                  \
+            else val = root_chain(pr, (int)g.nvtab[kk >> KSH]);                                                            \
+        }                                                                                                                  \
+        const bool nz = tact && val != 0.0;                                                                                \
+        const int ion = tact ? (int)(kk & ~KMASK) : -1;                                                                    \
+        const int prev = __builtin_amdgcn_update_dpp(-1, ion, 0x138, 0xf, 0xf, false);      /* wave_shr:1 */               \
+        const int next = __builtin_amdgcn_update_dpp(-1, ion, 0x130, 0xf, 0xf, false);      /* wave_shl:1 */               \
+        const unsigned long long starts = __ballot(tact && prev != ion), nzm = __ballot(nz);                               \
+        if (FUSE && !(FINAL)) spilled = true;                                                                              \
+        if (FUSE && (FINAL) && __ballot(tact && !nz)) spilled = true;   /* a zero value (cannot happen for finite input) */ \
+        const bool keep = FUSE && (FINAL) && !spilled;                   /* the list stays for the assignment */           \
+        const bool to_rows = FUSE ? (spilled || g.store != 0) : g.row_val != nullptr;                                      \
+        if (tact) {                                                                                                        \
+            const int start = 63 - __clzll(starts & (ltmask | (1ull << lane)));               /* my ion's first survivor */ \
+            const int e = (int)nzc[ion] + __popcll(nzm & ltmask & ~((1ull << start) - 1ull));                             \
+            if (nz && to_rows) {                                                                                           \
+                const i64 row = f0 * M + ib0 + (i64)ion;                  /* rows are frame-major */                       \
+                if (e < g.W) { g.row_idx[(i64)e * g.N + row] = (i32)(kk >> KSH); g.row_val[(i64)e * g.N + row] = val; }  \
+                else atomicAdd(&h.scal[3], 1ull);                                                                          \
+            }                                                                                                              \
+            if (keep) prod[lane] = val;                                                                                    \
+            if (next != ion) nzc[ion] = keep ? ((unsigned)start << 8) | (unsigned)(e + 1) : (unsigned)(e + (nz ? 1 : 0)); \
+        }                                                                                                                  \
+        cnt = 0;                                                                                                           \
+    } while (0)
+
+// FUSE: the site assignment (util/DotProdClassifier.pyx:129-197) of the windows of waves W0 .. W0 + NWV - 1, a lane per
+// ion (IB = the first ion of the first of those windows; with GW = 1 the wave's own window).  A window's rows are the
+// runs of its survivor list: nzc[ion] = first survivor << 8 | entries, sv[] >> KSH the landmarks, prod[] the values.
+// Rows of one to four entries are assigned here (merge4_row: the arithmetic of k_predict_rows*); zero rows get -1 / 0.0
+// (:168-172); wider rows - and every row of a window that spilled to the row buffers - are listed for
+// k_predict_rows_wide*, their entries written to the row buffers first if they are not there yet.
+#define F3_ASSIGN(W0, NWV, IB)                                                                                             \
+    do {                                                                                                                   \
+        int wl = 0;                                                                                                        \
+        if (GW > 1) wl = (lane >= IW ? 1 : 0) + (lane >= 2 * IW ? 1 : 0) + (lane >= 3 * IW ? 1 : 0);                       \
+        const int li = lane - wl * IW;                                                                                     \
+        const int ionidx = (IB) + wl * IW + li;                                                                            \
+        const bool act = wl < (NWV) && li < IW && ionidx < nions;                                                          \
+        const char *wq = smem + L.wave0 + ((W0) + (act ? wl : 0)) * L.wbytes;                                              \
+        unsigned rec = 0u;                                                                                                 \
+        bool wsp = false;                                                                                                  \
+        if (act) {                                                                                                         \
+            rec = ((const unsigned *)(wq + L.o_nzc))[li];                                                                  \
+            wsp = GW > 1 ? wspill[(W0) + wl] != 0u : spilled;                                                              \
+        }                                                                                                                  \
+        const int n = wsp ? (int)rec : (int)(rec & 255u);                                                                  \
+        const int s0 = wsp ? 0 : (int)(rec >> 8);                                                                          \
+        const i64 row = f0 * M + (i64)ionidx;                                                                              \
+        const unsigned *svq = (const unsigned *)(wq + L.o_sv) + s0;                                                        \
+        const double *pq = (const double *)wq + s0;                                                                        \
+        if (act && n == 0) { g.labels[row] = -1; g.confs[row] = 0.0; }                                                     \
+        if (act && !wsp && n >= 1 && n <= 4) {                                                                             \
+            i32 d0 = (i32)(svq[0] >> KSH), d1 = 0, d2 = 0, d3 = 0;                                                         \
+            double v0 = pq[0], v1 = 0.0, v2 = 0.0, v3 = 0.0;                                                               \
+            if (n > 1) { d1 = (i32)(svq[1] >> KSH); v1 = pq[1]; }                                                          \
+            if (n > 2) { d2 = (i32)(svq[2] >> KSH); v2 = pq[2]; }                                                          \
+            if (n > 3) { d3 = (i32)(svq[3] >> KSH); v3 = pq[3]; }                                                          \
+            double x2 = 0.0;                                                                                               \
+            x2 += v0 * v0;                                                                                                 \
+            if (n > 1) x2 += v1 * v1;                                                                                      \
+            if (n > 2) x2 += v2 * v2;                                                                                      \
+            if (n > 3) x2 += v3 * v3;                                                                                      \
+            const double xn = sqrt(x2);                                                                                    \
+            const Best b = merge4_row(n, d0, d1, d2, d3, v0, v1, v2, v3, xn, g.normed != 0, g.col_ptr, g.col_k, g.col_val); \
+            i64 to;                                                                                                        \
+            double conf;                                                                                                   \
+            finish_assignment(b, g.threshold, to, conf);                                                                   \
+            g.labels[row] = to;                                                                                            \
+            g.confs[row] = conf;                                                                                           \
+        }                                                                                                                  \
+        if (act && !wsp && n > 4 && !g.store) {                                                                            \
+            for (int e = 0; e < n; e++) {                                                                                  \
+                if (e < g.W) { g.row_idx[(i64)e * g.N + row] = (i32)(svq[e] >> KSH); g.row_val[(i64)e * g.N + row] = pq[e]; } \
+                else atomicAdd(&h.scal[3], 1ull);                                                                          \
+            }                                                                                                              \
+            g.row_nnz[row] = n < g.W ? n : g.W;                                                                            \
+        }                                                                                                                  \
+        const bool listed = act && n >= 1 && (wsp || n > 4);                                                               \
+        if (__ballot(listed)) {                                                                                            \
+            const i64 sg = (i64)(blockIdx.x % (unsigned)g.nseg);                                                           \
+            list_rows_by_class(listed && n <= 8, listed && n > 8, row, g.wlist + sg * g.seg_cap, g.wcount + 2 * sg,        \
+                               g.seg_cap, lane);                                                                           \
+        }                                                                                                                  \
+    } while (0)
+
 // the value of lane + N of the same row of 16 lanes (0 for lanes without such a neighbour)
 template <int N>
 __device__ __forceinline__ double dpp_row_shl(double x)
@@ -344,11 +462,23 @@ __device__ __forceinline__ double dpp_row_shl(double x)
 
 // LG: log2 of the padded vertices per landmark (2, 3 or 4).  NW: waves per workgroup.  DYN: dynamic lattice mapping
 // (static ids go through the frame's lattice map; the static-lattice check was made by k_lattice_map).  FPB1: one frame
-// per workgroup (the LDS offsets of an ion follow from its number; otherwise they are looked up).
+// per workgroup (the LDS offsets of an ion follow from its number; otherwise they are looked up).  FUSE: the site
+// assignment of the narrow rows behind the fill (file header).
 // h.contig: 2 = the workgroup's atoms are one run of doubles in memory (statics then mobiles, nothing else),
-// 3 = the same in 16-byte pieces, 1 = static_idx / mobile_idx are two consecutive ranges, 0 = arbitrary index lists.
-template <int CELL, int LG, int NW, int DYN, int FPB1, int DBG>
-__global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr full)
+// 3 = the same in 16-byte pieces, 4 = the same by LDS-DMA, 1 = static_idx / mobile_idx are two consecutive ranges,
+// 0 = arbitrary index lists.
+// F3_WPE waves per SIMD: the register budget (the scalar registers are what binds: 96 allow seven waves per SIMD - the
+// LDS allows seven workgroups of four per CU - where the compiler, left alone, takes 106 and gets six)
+#ifndef F3_WPE
+#define F3_WPE 7
+#endif
+#if F3_WPE > 0
+#define F3_WPE_ATTR __attribute__((amdgpu_waves_per_eu(F3_WPE, F3_WPE)))
+#else
+#define F3_WPE_ATTR
+#endif
+template <int CELL, int LG, int NW, int DYN, int FPB1, int DBG, int FUSE>
+__global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill3ArgsPtr full)
 {
     constexpr int VP = 1 << LG;
     constexpr int NT = NW * 64;
@@ -365,6 +495,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     const F3Layout L = f3_layout(fpb, SM, M, NW, rcap, IW, TT, h.mcap, FPB1);
     double *xyz = (double *)smem;                               // [fpb][S + M][3]; mobiles become centroid - ion
     u64 *fmax = (u64 *)(smem + L.fmax);                         // [fpb]
+    unsigned *garrive = (unsigned *)(smem + L.gsync);           // [NW] waves of a group that have finished their window
+    unsigned *wspill = garrive + NW;                            // [NW] the wave's window went to the row buffers
     uint2 *ioninfo = (uint2 *)(smem + L.ioninfo);               // [fpb * M]
     double *etab = (double *)(smem + L.etab);
     char *wp = smem + L.wave0 + wave * L.wbytes;
@@ -381,14 +513,27 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
     const Fill3Args __attribute__((address_space(4))) &g = *full;
 
     if (tid < fpb) fmax[tid] = 0ull;
+    if (FUSE && tid < 2 * NW) garrive[tid] = 0u;
     double etv = 0.0;
     if (tid < F3_EXPN) etv = h.exptab[tid];                    // in flight beside the frame loads; parked below
     for (int q = lane; q < TT; q += 64) ttab[q] = 0u;          // stale entries must stay valid tasks (landmark 0, ion 0)
     for (int q = lane; q < (FPB1 ? IW : 4 * IW); q += 64) ionrec[q] = 0u;      // stale tasks look their ion up
-    // ---- phase 1a: copy this workgroup's atoms into LDS, eight independent loads per thread in flight ----
+    // ---- phase 1a: copy this workgroup's atoms into LDS ----
     {
-        const double *fbase = h.frames + f0 * h.A * 3;
-        if (h.contig == 3) {
+        // (h.frame_mod > 0, an experiment: the workgroups read the first frame_mod frames over and over - the frames then
+        // come from the L2 / Infinity cache, an upper bound on what hiding the HBM latency of this load could gain)
+        const double *fbase = h.frames + (h.frame_mod > 0 ? f0 % h.frame_mod : f0) * h.A * 3;
+        if (h.contig == 4) {
+            // one run of doubles, by LDS-DMA: a wave-instruction moves 64 x 16 bytes from per-lane addresses to
+            // consecutive LDS bytes - no registers, no LDS stores, no address arithmetic but the lane's own
+            const int n2 = (nf * SM * 3 + 1) >> 1;              // 16-byte pieces (the last may run 8 bytes into the slack)
+            const char *src = (const char *)fbase;
+            for (int e0 = wave * 64; e0 < n2; e0 += NT) {       // wave-uniform
+                if (e0 + lane < n2)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 16 * (size_t)(e0 + lane)),
+                                                     (__attribute__((address_space(3))) void *)(smem + 16 * e0), 16, 0, 0);
+            }
+        } else if (h.contig == 3) {
             // the same run as 16-byte pieces (the frame group starts on a 16-byte boundary and holds an even number
             // of doubles): half the loads, address computations and LDS stores
             const int n2 = (nf * SM * 3) >> 1;
@@ -488,15 +633,20 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
 
     // phase-2 constants
     const char *vh = (const char *)g.vh;
-    const unsigned *pack = g.pack;
+    const uint4 *pack = g.pack;
     const ExpK ek = expk_make(g.midpoint, g.steepness);
+    const int nvu = g.nv_uniform;
     const int hh = lane & (VP - 1), gi = lane >> LG;            // my vertex, my task of a pass
     const unsigned hh32 = (unsigned)hh << 5;
     const unsigned long long ltmask = (1ull << lane) - 1ull;
     const unsigned xyz_s = 24u * (unsigned)S;                   // byte offset of the first mobile ion in a frame of xyz[]
+    // FUSE: the windows of GW waves (64 ions or fewer) are assigned together, by the last of them to finish; a wave has
+    // ONE window (the host makes sure: fpb M <= NW IW, else the assignment stays a kernel of its own).
+    const int GW = FUSE ? (IW <= 32 ? 64 / IW : 1) : 1;
 
     // ---- phase 2: every wave on its own (windows of IW ions); no workgroup barrier from here on ----
     const int nions = nf * M;
+    bool spilled = false;                                       // wave-uniform
     for (int ib0 = wave * IW; ib0 < nions; ib0 += NW * IW) {
         const int nib = (nions - ib0) < IW ? (nions - ib0) : IW;
         // ---- A: a lane per ion of the window: its list, the first task of the list (a prefix sum) ----
@@ -529,7 +679,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
         }
         if (DBG && dbg == 9 && lane == 0) { atomicAdd(&h.scal[5], (u64)nlt); atomicAdd(&h.scal[7], 1ull); }
         const unsigned ionbase = xyz_s + 24u * (unsigned)ib0;   // FPB1: byte offset of the window's first offset vector
-        int t_end = 0, carry = 0;
+        int t_end = 0, carry = 0, cnt = 0;
+        spilled = false;
         const int nlt0 = (DBG && dbg == 2) ? 0 : nlt;           // ablation: stop after the owner stage
         for (int base = 0; base < nlt0; base += 64) {
             // ---- D0: a lane per candidate task: its ion (maximum scan over the start markers), its list entry, the
@@ -542,20 +693,20 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 int ion = wave_max_scan(mk);
                 ion = ion > carry ? ion : carry;
                 carry = __builtin_amdgcn_readlane(ion, 63);
-                unsigned entry = 0u, ionoff, statoff = 0u, tfl = 0u;
+                uint4 en = make_uint4(0u, 0u, 0u, 0x7ff00000u);   // an idle lane: landmark 0, static 0, threshold +inf
+                unsigned ionoff, statoff = 0u, tfl = 0u;
                 if (FPB1) {
                     const unsigned l0 = ionrec[ion];
-                    if (F3_LANES(vmask)) entry = *(const unsigned *)((const char *)pack + ((l0 + (unsigned)t) << 2));
+                    if (F3_LANES(vmask)) en = pack[l0 + (unsigned)t];
                     ionoff = ionbase + 24u * (unsigned)ion;
                 } else {
                     const uint4 ir = ((const uint4 *)ionrec)[ion];
-                    if (F3_LANES(vmask)) entry = *(const unsigned *)((const char *)pack + ((ir.x + (unsigned)t) << 2));
+                    if (F3_LANES(vmask)) en = pack[ir.x + (unsigned)t];
                     ionoff = ir.y; statoff = ir.z; tfl = ir.w;
                 }
-                const uint4 *rp = (const uint4 *)(vh + entry);
-                unsigned voff = rp->x;
-                if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)tfl) * S + (i64)rp->y];
-                const double hk = __hiloint2double((int)rp->w, (int)rp->z);
+                unsigned voff = en.y;
+                if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)tfl) * S + (i64)(en.y / 24u)];
+                const double hk = __hiloint2double((int)en.w, (int)en.z);
                 const double *sp = (const double *)(smem + (statoff + voff));
                 const double *op = (const double *)(smem + ionoff);
                 double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];
@@ -563,7 +714,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
                 const double d2 = (dx * dx + dy * dy) + dz * dz;
                 const unsigned long long km = __ballot(!(d2 > hk)) & vmask;
-                if (F3_LANES(km)) ttab[mask_rank(km, t_end)] = (entry & KMASK) | (unsigned)ion;
+                if (F3_LANES(km)) ttab[mask_rank(km, t_end)] = (en.x & KMASK) | (unsigned)ion;
                 t_end += __popcll(km);
             }
             if (t_end <= TT - 64 && base + 64 < nlt0) continue;         // room for another pass of candidates
@@ -578,7 +729,6 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                 //      the factors of a task are multiplied across its lanes and the tasks with every vertex inside
                 //      are appended to the survivors.  Two passes per iteration (loads and arithmetic of both
                 //      interleaved) while the list has room for every task of both ----
-                int cnt = 0;
                 while (cursor < pend && cnt + TPP <= rcap) {
                     if (cursor + 1 < pend && cnt + 2 * TPP <= rcap) {
                         F3_D1E_PASSES(2);
@@ -589,47 +739,45 @@ __global__ __launch_bounds__(NW * 64) void k_fill3(Fill3Head h, Fill3ArgsPtr ful
                     }
                 }
                 if (DBG && dbg == 9 && lane == 0) atomicAdd(&h.scal[6], (u64)cnt);
-                if (DBG && dbg == 5) cnt = 0;                   // ablation: stop after the logistic factors
-                // ---- T: the n-th root (helpers.pyx:212) of the product (:208), one lane per survivor; the row entry of
-                //      a component is the number of earlier non-zero components of its ion (the survivors are in task
-                //      order: ion-major, ascending landmark) ----
-                double val = 0.0;
-                unsigned kk = 0;
-                const bool tact = lane < cnt;
-                if (tact) {
-                    kk = sv[lane];
-                    const int nv = (int)g.nvtab[kk >> KSH];
-                    val = root_chain(prod[lane], nv);
-                }
-                const bool nz = tact && val != 0.0;
-                const int ion = tact ? (int)(kk & ~KMASK) : -1;
-                const int prev = __builtin_amdgcn_update_dpp(-1, ion, 0x138, 0xf, 0xf, false);      // wave_shr:1
-                const int next = __builtin_amdgcn_update_dpp(-1, ion, 0x130, 0xf, 0xf, false);      // wave_shl:1
-                const unsigned long long starts = __ballot(tact && prev != ion), nzm = __ballot(nz);
-                if (tact) {
-                    const int start = 63 - __clzll(starts & (ltmask | (1ull << lane)));               // my ion's first survivor
-                    const int e = (int)nzc[ion] + __popcll(nzm & ltmask & ~((1ull << start) - 1ull));
-                    if (nz && g.row_val != nullptr) {
-                        const i64 row = f0 * M + ib0 + (i64)ion;                  // rows are frame-major
-                        if (e < g.W) { g.row_idx[(i64)e * g.N + row] = (i32)(kk >> KSH); g.row_val[(i64)e * g.N + row] = val; }
-                        else atomicAdd(&h.scal[3], 1ull);
-                    }
-                    if (next != ion) nzc[ion] = (unsigned)(e + (nz ? 1 : 0));     // the ion's last survivor of this round
-                }
+                if (cursor < pend) F3_T_ROUND(0);               // the list is full: its entries leave for the row buffers
             }
             t_end = 0;
         }
+        if (DBG && dbg == 5) cnt = 0;                           // ablation: stop after the logistic factors
+        F3_T_ROUND(1);
         if (lane < nib) {
-            const int nnz = (DBG && dbg >= 2 && dbg <= 5) ? 1 : (int)nzc[lane];
+            int nnz = (int)nzc[lane];
+            if (FUSE && !spilled) nnz &= 255;
+            if (DBG && dbg >= 2 && dbg <= 5) nnz = 1;
             const i64 row = (f0 + fl) * M + j;
-            g.row_nnz[row] = nnz < g.W ? nnz : g.W;
+            if (!FUSE || spilled || g.store) g.row_nnz[row] = nnz < g.W ? nnz : g.W;
             if (nnz == 0) {                                               // helpers.pyx:116-120
                 if (g.check_zeros) atomicMin(h.err, (u64)(h.frame0 + f0 + fl) * errw + (u64)(S + 1 + j));
                 else atomicAdd(&h.scal[0], 1ull);
             }
         }
     }
+    if (FUSE) {
+        // the windows of a group of waves are assigned by whichever of them finishes last (nobody waits): LDS operations
+        // of a wave complete in order, so a wave's list is in place before its arrival is counted.  (The assignment
+        // sits behind the window loop, not in it: inside, its registers would add to the loop's and cost three waves
+        // per SIMD.)
+        const int grp = wave / GW, gw0 = grp * GW;
+        const int gsize = (NW - gw0) < GW ? (NW - gw0) : GW;
+        bool mine = true;
+        if (GW > 1) {
+            if (lane == 0) wspill[wave] = spilled ? 1u : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            unsigned arrived = 0u;
+            if (lane == 0) arrived = __hip_atomic_fetch_add(&garrive[grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+            mine = (int)arrived + 1 == gsize;
+            if (mine) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (mine) F3_ASSIGN(gw0, gsize, gw0 * IW);
+    }
 }
+#undef F3_ASSIGN
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 
@@ -700,6 +848,8 @@ static int fill3_basis_tables(sit_ctx *c)
         }
         nv[(size_t)k] = (unsigned char)cnt;
     }
+    c->nv_uniform = c->D > 0 ? (int)nv[0] : 0;                   // every landmark with the same number of vertices: no look-up
+    for (i64 k = 1; k < c->D; k++) if (nv[(size_t)k] != nv[0]) { c->nv_uniform = 0; break; }
     int rc;
     if ((rc = dev_upload(c, &c->d_nv, nv.data(), c->D))) return rc;
     std::vector<double> tab(F3_EXPN);
@@ -716,11 +866,15 @@ static int fill3_basis_tables(sit_ctx *c)
     return SIT_OK;
 }
 
-// list entries as the kernel wants them: landmark << ksh | critical vertex << 5 (the byte offset of that record in vh)
-__global__ __launch_bounds__(256) void k_pack_lists(const i32 *list, const unsigned char *crit, i64 n, int ksh, unsigned *out)
+// list entries as the kernel wants them, 16 bytes each: {landmark << ksh | critical vertex << 5 (the byte offset of that
+// vertex record in vh), 24 * its static id, its exact threshold} - a candidate test reads nothing else
+__global__ __launch_bounds__(256) void k_pack_lists(const i32 *list, const unsigned char *crit, i64 n, int ksh, const uint4 *vh, uint4 *out)
 {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = ((unsigned)list[i] << ksh) | ((unsigned)crit[i] << 5);
+    if (i >= n) return;
+    const unsigned off = ((unsigned)list[i] << ksh) | ((unsigned)crit[i] << 5);
+    const uint4 r = vh[off >> 4];
+    out[i] = make_uint4(off, r.x, r.z, r.w);
 }
 
 // one array with the entries of the tight table (if there is one) followed by those of the loose table
@@ -732,12 +886,13 @@ static int fill3_pack_lists(sit_ctx *c, bool have_tight)
     HIP_TRY(c, hipMemcpyAsync(&nl, c->d_bin_off + nbl, 4, hipMemcpyDeviceToHost, c->stream));
     if (have_tight) HIP_TRY(c, hipMemcpyAsync(&nt, c->d_tbin_off + nbt, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    SIT_REQUIRE(c, (i64)nt + (i64)nl < (1LL << 30), "sit_fill: candidate tables too large for the third-generation kernel");
+    SIT_REQUIRE(c, (i64)nt + (i64)nl < (1LL << 28), "sit_fill: candidate tables too large for the third-generation kernel");
     int rc;
-    if ((rc = dev_alloc(c, &c->d_pack, (i64)nt + (i64)nl + 1))) return rc;
+    if ((rc = dev_alloc(c, &c->d_pack, 4 * ((i64)nt + (i64)nl + 1)))) return rc;       // 16 bytes per entry
+    uint4 *pk = (uint4 *)c->d_pack;
     const int ksh = (f3_vp(c) == 16 ? 4 : (f3_vp(c) == 8 ? 3 : 2)) + 5;
-    if (nt > 0) k_pack_lists<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_tbin_list, c->d_tbin_crit, nt, ksh, c->d_pack);
-    if (nl > 0) k_pack_lists<<<dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_bin_list, c->d_bin_crit, nl, ksh, c->d_pack + nt);
+    if (nt > 0) k_pack_lists<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_tbin_list, c->d_tbin_crit, nt, ksh, (const uint4 *)c->d_vh, pk);
+    if (nl > 0) k_pack_lists<<<dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_bin_list, c->d_bin_crit, nl, ksh, (const uint4 *)c->d_vh, pk + nt);
     HIP_TRY(c, hipGetLastError());
     c->pack_nt = nt; c->pack_gen = c->table_gen; c->pack_tight = have_tight ? 1 : 0;
     return SIT_OK;
@@ -755,19 +910,20 @@ bool fill3_eligible(sit_ctx *c)
 
 // the instantiation for this cell / landmark width / waves per workgroup / mapping mode / frames per workgroup
 static hipError_t f3_dispatch(sit_ctx *c, const Fill3Head &h, Fill3ArgsPtr full, unsigned grid, size_t lds, int nw, int vp,
-                              bool diag, bool dynmap)
+                              bool diag, bool dynmap, bool fuse)
 {
-#define F3_LAUNCH(CELL, LGV, NWV, DY, F1, DB)                                                                                  \
+#define F3_LAUNCH(CELL, LGV, NWV, DY, F1, DB, FU)                                                                              \
     do {                                                                                                                   \
-        hipError_t e = lds_limit((const void *)k_fill3<CELL, LGV, NWV, DY, F1, DB>, lds, c->device);                       \
+        hipError_t e = lds_limit((const void *)k_fill3<CELL, LGV, NWV, DY, F1, DB, FU>, lds, c->device);                   \
         if (e != hipSuccess) return e;                                                                                     \
-        k_fill3<CELL, LGV, NWV, DY, F1, DB><<<dim3(grid), dim3(NWV * 64), lds, c->stream>>>(h, full);                      \
+        k_fill3<CELL, LGV, NWV, DY, F1, DB, FU><<<dim3(grid), dim3(NWV * 64), lds, c->stream>>>(h, full);                  \
     } while (0)
 #define F3_PICK3(CELL, LGV, NWV, F1)                                                                                           \
     do {                                                                                                                   \
-        if (dynmap) F3_LAUNCH(CELL, LGV, NWV, 1, F1, 0);                                                                   \
-        else if (h.debug_stop) F3_LAUNCH(CELL, LGV, NWV, 0, F1, 1);                                                        \
-        else F3_LAUNCH(CELL, LGV, NWV, 0, F1, 0);                                                                          \
+        if (dynmap) F3_LAUNCH(CELL, LGV, NWV, 1, F1, 0, 0);                                                                \
+        else if (h.debug_stop) F3_LAUNCH(CELL, LGV, NWV, 0, F1, 1, 0);                                                     \
+        else if (fuse) F3_LAUNCH(CELL, LGV, NWV, 0, F1, 0, 1);                                                             \
+        else F3_LAUNCH(CELL, LGV, NWV, 0, F1, 0, 0);                                                                       \
     } while (0)
 #define F3_PICK(CELL, LGV)                                                                                                     \
     do {                                                                                                                   \
@@ -804,9 +960,11 @@ int fill3_prepare(sit_ctx *c)
     return SIT_OK;
 }
 
-int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64 f_hi)
+int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64 f_hi, bool fuse, bool *fused)
 {
     static_assert(sizeof(Fill3Args) <= F3_ARGS_BYTES, "argument block");
+    if (fused) *fused = false;
+    const bool fuse_asked = fuse;
     if (f_hi < 0) f_hi = c->F;
     const i64 S = c->S, M = c->M;
     SIT_REQUIRE(c, c->D * f3_vp(c) < (1LL << 26) && c->F * S < (1LL << 40) && c->A < (1LL << 25), "sit_fill: sizes too large");
@@ -814,19 +972,24 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     if (rc) return rc;
     const bool have_tight = c->tight_delta >= 0;
     if ((rc = fill3_pack_lists(c, have_tight))) return rc;
+    // the fused assignment: narrow CSC columns only (the dense fall-back of the assignment has no merge), no dynamic
+    // mapping, not an ablation run
+    if (fuse && (p->dynamic_lattice_mapping || c->K <= 0 || !c->d_col_ptr || c->max_col > 24 || c->N >= (1LL << 31) ||
+                 f3_env_int("SITATOR_DEBUG_STOP", 0) || !f3_env_int("SITATOR_FUSE", 0))) fuse = false;
     Fill3Args a;
     memset(&a, 0, sizeof(a));
     a.vh = (const uint4 *)c->d_vh; a.nvtab = c->d_nv;
-    a.pack = c->d_pack;
+    a.pack = (const uint4 *)c->d_pack;
     a.f_off = c->d_bin_off; a.fG0 = c->G[0]; a.fG1 = c->G[1]; a.fG2 = c->G[2];
     a.f_base = (unsigned)c->pack_nt;
     if (have_tight) { a.p_off = c->d_tbin_off; a.pG0 = c->tG[0]; a.pG1 = c->tG[1]; a.pG2 = c->tG[2]; }
     else { a.p_off = c->d_bin_off; a.pG0 = c->G[0]; a.pG1 = c->G[1]; a.pG2 = c->G[2]; }
     a.lattice_map = p->dynamic_lattice_mapping ? c->d_lattice_map : nullptr;
-    a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx; a.row_val = store ? c->d_row_val : nullptr;
+    a.row_nnz = c->d_row_nnz; a.row_idx = c->d_row_idx;
     a.N = c->N; a.D = (int)c->D; a.W = (int)c->rows_W;
     a.check_zeros = p->check_for_zeros;
     a.midpoint = c->midpoint; a.steepness = c->steepness;
+    a.nv_uniform = f3_env_int("SITATOR_F3_NVU", 1) ? c->nv_uniform : 0;
 
     Fill3Head h;
     memset(&h, 0, sizeof(h));
@@ -858,8 +1021,8 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     int iw = f3_env_int("SITATOR_FILL_IW", 0);
     if (fpb < 1) { i64 f = 64 / M; if (f < 1) f = 1; if (f > 32) f = 32; fpb = (int)f; }      // about 64 ions per workgroup
     if (fpb > 32) fpb = 32;
-    const bool rcap_auto = rcap < 8;
-    if (rcap_auto) rcap = 64;
+    const bool rcap_auto = rcap < 8 && !fuse;                  // fused: the list should hold a window's survivors (64 slots)
+    if (rcap < 8) rcap = 64;
     rcap = (rcap + 7) / 8 * 8;
     if (rcap > 64) rcap = 64;
     if (rcap < 64 / vp) rcap = 64 / vp;                        // a pass of 64 / vp tasks must fit an empty region
@@ -882,9 +1045,10 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     const bool tt_auto = tt < 64 || tt > 1024;
     if (tt_auto) tt = 128;
     tt = (tt + 63) / 64 * 64;
+    const int lds_pad = f3_env_int("SITATOR_F3_LDS_PAD", 0);    // experiments: unused LDS per workgroup (fewer workgroups per CU)
     auto lds_bytes = [&](int nwv, int fpbv, int rcapv) {
         const int iwv = iw_for(nwv, fpbv);
-        return (size_t)f3_layout(fpbv, (int)(S + M), (int)M, nwv, rcapv, iwv, tt, mcap_for(iwv), fpbv == 1 ? 1 : 0).total + 32;
+        return (size_t)f3_layout(fpbv, (int)(S + M), (int)M, nwv, rcapv, iwv, tt, mcap_for(iwv), fpbv == 1 ? 1 : 0).total + 32 + (size_t)lds_pad;
     };
     if (nw != 4 && nw != 8 && nw != 16) {
         // Waves per workgroup: the count that keeps the most waves on a CU (workgroups are admitted by their LDS: the
@@ -933,6 +1097,30 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     iw = iw_for(nw, fpb);
     SIT_REQUIRE(c, (i64)iw * wmax <= 65536, "sit_fill: candidate lists too long for the third-generation kernel");
     h.fpb = fpb; h.iw = iw; h.mcap = mcap_for(iw);
+    // the fused assignment sits behind the window loop (and groups the windows of 64 / iw waves): one window per wave
+    if (fuse && (i64)fpb * M > (i64)nw * iw) fuse = false;
+    if (!fuse) store = true;                                    // the assignment kernels (if any) read the row buffers
+    a.row_val = fuse || store ? c->d_row_val : nullptr;
+    a.store = store ? 1 : 0;
+    const unsigned grid_all = (unsigned)((f_hi - f_lo + fpb - 1) / fpb);
+    int nseg = 0;
+    i64 seg_cap = 0;
+    if (fuse) {
+        // rows left to k_predict_rows_wide*: listed in nseg segments of the scratch buffer, workgroup b into segment b % nseg
+        if (c->num_cu <= 0) {
+            int v = 0;
+            c->num_cu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0 ? v : 256;
+        }
+        nseg = (int)std::min<i64>((i64)grid_all > 0 ? (i64)grid_all : 1, (i64)c->num_cu * 4);
+        seg_cap = ((i64)grid_all + nseg - 1) / nseg * ((i64)fpb * M);
+        if ((rc = ensure_scratch(c, ((i64)nseg * seg_cap + 2 * nseg + 64) * 4))) return rc;
+        a.wcount = (unsigned *)c->d_scratch;
+        a.wlist = (i32 *)c->d_scratch + ((2 * nseg + 63) / 64 * 64);
+        a.seg_cap = seg_cap; a.nseg = nseg;
+        a.col_ptr = c->d_col_ptr; a.col_k = c->d_col_k; a.col_val = c->d_col_val;
+        a.labels = c->d_labels; a.confs = c->d_confs;
+        a.normed = c->centers_normed; a.threshold = p->predict_threshold;
+    }
     if (c->fill_args_host.size() != sizeof(Fill3Args) || memcmp(c->fill_args_host.data(), &a, sizeof(Fill3Args)) != 0) {
         c->fill_args_host.assign((const char *)&a, (const char *)&a + sizeof(Fill3Args));
         HIP_TRY(c, hipMemcpyAsync(c->d_fill_args, c->fill_args_host.data(), sizeof(Fill3Args), hipMemcpyHostToDevice, c->stream));
@@ -948,11 +1136,14 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
         const bool even_groups = fpb % 2 == 0 && f_lo % 2 == 0 && (f_hi - f_lo) % fpb == 0;
         if (contig == 2 && f3_env_int("SITATOR_FILL_WIDE_COPY", 1) && ((uintptr_t)c->d_frames % 16) == 0 && (even_frame || even_groups))
             contig = 3;
+        // ... and by LDS-DMA (the last piece of a group may read 8 bytes past its frames: not past the buffer's last frame)
+        if (contig == 3 && f3_env_int("SITATOR_FILL_DMA", 1) && (even_frame || even_groups || f_hi < c->F)) contig = 4;
     }
     h.contig = contig;
+    h.frame_mod = f3_env_int("SITATOR_F3_FRAME_MOD", 0);
 
     // ---- survivor slots / task-table size: measured once per kind of fill ----
-    if (rcap_auto && tt_auto && h.debug_stop == 0 && f3_env_int("SITATOR_FILL_AUTOTUNE", 1) && (f_hi - f_lo) * M >= (1 << 18)) {
+    if (rcap_auto && tt_auto && !fuse && h.debug_stop == 0 && f3_env_int("SITATOR_FILL_AUTOTUNE", 1) && (f_hi - f_lo) * M >= (1 << 18)) {
         const i64 key[8] = {S, M, c->D, vp, have_tight ? c->W_tight : c->W, (i64)nw * 64 + fpb, dynmap ? 1 : 0, (i64)(c->tight_mean_candidates * 4.0 + 0.5)};   // candidates per ion in quarters: trajectories of one system share a key
         bool found = false;
         {
@@ -989,7 +1180,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
                 float tq = 1e30f;
                 for (int rep = 0; rep < 5; rep++) {                            // the first launch of a shape warms it up; best of four
                     HIP_TRY(c, hipEventRecord(e0, c->stream));
-                    HIP_TRY(c, f3_dispatch(c, ht, full, gt, ldq, nw, vp, diag, dynmap));
+                    HIP_TRY(c, f3_dispatch(c, ht, full, gt, ldq, nw, vp, diag, dynmap, false));
                     HIP_TRY(c, hipEventRecord(e1, c->stream));
                     HIP_TRY(c, hipEventSynchronize(e1));
                     float ms = 0;
@@ -1012,7 +1203,14 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
         fprintf(stderr, "k_fill3 shape: nw %d fpb %d rcap %d iw %d tt %d mcap %d, %zu bytes of LDS per workgroup\n", nw, fpb, rcap, iw, tt, h.mcap, lds);
     c->last_fpb = fpb; c->last_kernel = 3; c->last_iw = rcap; c->last_nw = nw; c->last_tt = tt;
     const unsigned grid = (unsigned)((f_hi - f_lo + fpb - 1) / fpb);
+    if (fused) *fused = fuse;
+    c->last_fused = fuse;
+    if (fuse) {
+        // the error words, the label counts and the lengths of the list's segments, in one launch ahead of the kernel
+        if ((rc = reset_step_words(c, true, a.wcount, 2 * nseg))) return rc;
+        c->fuse_wlist = a.wlist; c->fuse_wcount = a.wcount; c->fuse_seg_cap = seg_cap; c->fuse_nseg = nseg;
+    } else if (fuse_asked && (rc = reset_fill_words(c))) return rc;   // a caller that asks for the fused pass leaves the reset to it
     if (f_hi <= f_lo) return SIT_OK;
-    HIP_TRY(c, f3_dispatch(c, h, full, grid, lds, nw, vp, diag, dynmap));
+    HIP_TRY(c, f3_dispatch(c, h, full, grid, lds, nw, vp, diag, dynmap, fuse));
     return SIT_OK;
 }

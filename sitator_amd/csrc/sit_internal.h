@@ -78,6 +78,12 @@ struct sit_ctx {
     i64 idx_s0 = 0, idx_m0 = 0;
     double hmin = 0;                  // smallest perpendicular height of the cell
     int last_kernel = 0, last_iw = 0, last_nw = 0, last_tt = 0;
+    int nv_uniform = 0;               // > 0: every landmark has this many vertices
+    bool last_fused = false;          // the last sit_fill assigned the narrow rows inside the fill kernel
+    i32 *fuse_wlist = nullptr;        // ... and listed the others here (segments of the scratch buffer)
+    unsigned *fuse_wcount = nullptr;
+    i64 fuse_seg_cap = 0;
+    int fuse_nseg = 0;
     double census[4] = {0, 0, 0, 0};  // SITATOR_DEBUG_STOP=9: static tasks, landmark tasks, survivors, wave batches
 
     // trajectory (sit_set_frames)
@@ -133,6 +139,7 @@ struct sit_ctx {
     u64 *d_scal = nullptr;            // [16] general purpose counters
     void *d_scratch = nullptr;
     i64 scratch_bytes = 0;
+    void *fill_ring = nullptr;        // results of deferred fills not yet collected (fill.hip)
 };
 
 #define HIP_TRY(ctx, expr)                                                              \
@@ -284,6 +291,104 @@ __device__ __forceinline__ Best best_of(double v, i64 i)
 }
 
 
+// ---- the narrow-row site assignment (util/DotProdClassifier.pyx:129-197), shared by the assignment kernels of cluster.hip
+//      and the fused epilogue of k_fill3 (fill3.hip): ONE definition, so that both make the same decisions bit for bit ----
+
+// Running argmax of fabs(dot_k) / xn over centres visited in ASCENDING id (numpy argmax: first maximum, NaN first).
+// Dividing by the same xn is monotonic, so the quotient of a later centre can only be STRICTLY greater if its
+// |dot| is greater; when it is greater by more than a few ulps the quotient is certainly greater and no division
+// is needed, inside that band both quotients are computed (rare).  One division per row instead of one per centre.
+struct ArgMaxQ {
+    double m;      // |dot| of the incumbent (undivided)
+    i64 i;         // its centre id, -1 = none yet
+    int nan;
+
+    __device__ __forceinline__ void init() { m = 0.0; i = -1; nan = 0; }
+    __device__ __forceinline__ void push(double dot, i64 cid, double xn, bool normed)
+    {
+        const double v = fabs(dot);
+        if (nan) return;                                   // the first NaN stays (np.argmax)
+        if (isnan(v)) { m = v; i = cid; nan = 1; return; }
+        if (i < 0) { m = v; i = cid; return; }
+        if (!(v > m)) return;
+        if (normed && !(v > m * (1.0 + 1e-15))) {
+            if (!(v / xn > m / xn)) return;                // equal quotients: the earlier centre keeps the place
+        }
+        m = v; i = cid;
+    }
+    __device__ __forceinline__ Best result(double xn, bool normed) const
+    {
+        Best b;
+        b.i = i; b.nan = nan;
+        b.v = (i >= 0 && normed) ? m / xn : m;             // :177-178 (NaN / xn stays NaN)
+        return b;
+    }
+};
+
+// b = numpy argmax of |normed_centres . x| (/ |x|) over the centres that overlap the row; every other centre scores
+// exactly 0, so when nothing beats 0 the dense argmax is index 0.  Below the threshold: (-1, 0.0) (:184-186; NaN: false).
+__device__ __forceinline__ void finish_assignment(Best b, double threshold, i64 &to, double &conf)
+{
+    if (b.i < 0 || (!b.nan && b.v == 0.0)) { to = 0; conf = 0.0; }
+    else { to = b.i; conf = b.v; }
+    if (conf < threshold) { to = -1; conf = 0.0; }
+}
+
+// One row of n <= 4 entries (landmark d_e ascending, value v_e) held in registers: a 4-way merge of the (centre-sorted)
+// CSC columns of the row's landmarks.  Each step takes the smallest pending centre id and sums its terms in ascending
+// landmark order (the order of the dense dot product, :176, with its exact zeros left out).  The CSC arrays may live
+// in global memory or in LDS.
+__device__ __forceinline__ Best merge4_row(int n, i32 d0, i32 d1, i32 d2, i32 d3, double v0, double v1, double v2, double v3,
+                                           double xn, bool normed, const i32 *col_ptr, const i32 *col_k, const double *col_val)
+{
+    ArgMaxQ am;
+    am.init();
+    i32 q0 = 0, q1 = 0, q2 = 0, q3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+    { q0 = col_ptr[d0]; e0 = col_ptr[d0 + 1]; }
+    if (n > 1) { q1 = col_ptr[d1]; e1 = col_ptr[d1 + 1]; }
+    if (n > 2) { q2 = col_ptr[d2]; e2 = col_ptr[d2 + 1]; }
+    if (n > 3) { q3 = col_ptr[d3]; e3 = col_ptr[d3 + 1]; }
+    const i32 none = 0x7fffffff;
+    i32 h0 = q0 < e0 ? col_k[q0] : none, h1 = q1 < e1 ? col_k[q1] : none;
+    i32 h2 = q2 < e2 ? col_k[q2] : none, h3 = q3 < e3 ? col_k[q3] : none;
+    while (true) {
+        i32 cid = h0 < h1 ? h0 : h1;
+        const i32 m23 = h2 < h3 ? h2 : h3;
+        cid = cid < m23 ? cid : m23;
+        if (cid == none) break;
+        double dot = 0.0;
+        bool first = true;
+        if (h0 == cid) { const double t = col_val[q0] * v0; dot = t; first = false; q0++; h0 = q0 < e0 ? col_k[q0] : none; }
+        if (h1 == cid) { const double t = col_val[q1] * v1; dot = first ? t : dot + t; first = false; q1++; h1 = q1 < e1 ? col_k[q1] : none; }
+        if (h2 == cid) { const double t = col_val[q2] * v2; dot = first ? t : dot + t; first = false; q2++; h2 = q2 < e2 ? col_k[q2] : none; }
+        if (h3 == cid) { const double t = col_val[q3] * v3; dot = first ? t : dot + t; first = false; q3++; h3 = q3 < e3 ? col_k[q3] : none; }
+        am.push(dot, cid, xn, normed);                              // :177-179
+    }
+    return am.result(xn, normed);
+}
+
+// Rows the narrow assignment leaves to k_predict_rows_wide* are LISTED: a segment of the list holds two classes, `ca`
+// from its start upwards (length seg_count[0]: merges of up to 8 columns) and `cb` from its end downwards
+// (seg_count[1]: wider ones); one atomic per wave and class on the segment's counter.
+__device__ __forceinline__ void list_rows_by_class(bool ca, bool cb, i64 row, i32 *seg, unsigned *seg_count, i64 seg_cap, int lane)
+{
+    const unsigned long long ma = __ballot(ca), mb = __ballot(cb);
+    if (ma) {
+        const int leader = __ffsll((long long)ma) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(seg_count, (unsigned)__popcll(ma));
+        base = __shfl(base, leader);
+        if (ca) seg[base + __popcll(ma & ((1ull << lane) - 1ull))] = (i32)row;
+    }
+    if (mb) {
+        const int leader = __ffsll((long long)mb) - 1;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(seg_count + 1, (unsigned)__popcll(mb));
+        base = __shfl(base, leader);
+        if (cb) seg[seg_cap - 1 - (i64)(base + __popcll(mb & ((1ull << lane) - 1ull)))] = (i32)row;
+    }
+}
+
 // ---- exact, order-independent accumulation of doubles ------------------------------------------------------
 // A sum of doubles taken with floating-point atomics depends on the order the hardware happens to serve them.
 // Here a value is converted to 128-bit two's-complement fixed point (units of 2^-80; exact for |v| >= 2^-27,
@@ -322,7 +427,7 @@ __host__ __device__ inline double exact_value(u64 hi, u64 lo)
 // host-side pieces implemented in other translation units
 int sit_predict_internal(sit_ctx *c, double threshold, bool words_reset = false);   // words_reset: predict_reset_with_fill did it
 int predict_reset_with_fill(sit_ctx *c, bool *done);                // cluster.hip: the fill's and the assignment's words in one launch
-int sit_label_counts(sit_ctx *c);
+int sit_label_counts(sit_ctx *c, bool zero = true);              // zero = false: the counts were reset by the caller
 void fitfast_free(sit_ctx *c);
 bool fitfast_valid(sit_ctx *c);
 void fitfast_invalidate(sit_ctx *c);
@@ -335,9 +440,15 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
 int sit_build_candidates(sit_ctx *c, double displacement, double bin_target, i32 **d_off, i32 **d_list,
                          unsigned char **d_crit, int G_out[3], i64 *W, double *mean);
 bool fill3_eligible(sit_ctx *c);
-int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo = 0, i64 f_hi = -1);   // frames [f_lo, f_hi)
+// frames [f_lo, f_hi); fuse: assign the narrow rows in the same kernel (needs centres; *fused says whether it did - if
+// not, the rows were stored whatever `store` says and the caller runs the assignment kernels)
+int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo = 0, i64 f_hi = -1, bool fuse = false, bool *fused = nullptr);
+// cluster.hip: the rows k_fill3 listed (segments of the scratch buffer), then the label counts
+int predict_listed_rows(sit_ctx *c, double threshold, i32 *wlist, unsigned *wcount, i64 seg_cap, int nseg);
 int download_staged(sit_ctx *c, hipStream_t stream, void *dst, const void *src, size_t bytes);   // fill.hip: large read-backs
 int reset_fill_words(sit_ctx *c);                                  // ctx.hip: error key and counters in one launch
+void fill_ring_free(sit_ctx *c);                                   // fill.hip
+int fill_results_landed(sit_ctx *c);                               // fill.hip: decode what has landed, report the first failure
 // comm.hip: n exact accumulators (hi, lo) and nseen counters summed over the ranks of c->comm_peer, on c->stream;
 // work = 3 n words of device scratch
 int comm_allreduce_limbs_device(sit_ctx *c, u64 *dhi, u64 *dlo, i64 n, u64 *dseen, i64 nseen, u64 *work);

@@ -7,6 +7,7 @@ frame shard of a multi-GPU run) or a plain 2-D ndarray (uploaded to a private co
 """
 import logging
 import numbers
+import time
 
 import numpy as np
 
@@ -41,6 +42,26 @@ class LandmarkVectors(object):
             row = int(key) % self.shape[0] if self.shape[0] else 0
             return self.ctx.rows_dense(row, 1)[0]
         return np.asarray(self)[key]
+
+
+def _pack_sparse(centers, width):
+    """Rows of ``centers`` as fixed-width (landmark, value) lists: idx [K, width] (-1 = unused), val [K, width]."""
+    K = len(centers)
+    idx = np.full((K, width), -1, dtype=np.int64)
+    val = np.zeros((K, width))
+    rows, cols = np.nonzero(centers != 0)                  # row-major: a row's landmarks ascend (NaN != 0 is kept)
+    pos = np.arange(len(rows)) - np.searchsorted(rows, rows)
+    idx[rows, pos] = cols
+    val[rows, pos] = centers[rows, cols]
+    return idx, val
+
+
+def _unpack_sparse(idx, val, D):
+    K = len(idx)
+    out = np.zeros((K, D))
+    r, p = np.nonzero(idx >= 0)
+    out[r, idx[r, p]] = val[r, p]
+    return out
 
 
 def _as_device_rows(X):
@@ -86,13 +107,35 @@ class DotProdClassifier(object):
     # ---------------------------------------------------------------------------------------
     def fit_centers(self, X):
         """Leader clustering in sample order, then re-clustering of the centres until their number
-        is stable (:199-315).  Rows are streamed through one persistent workgroup per GPU; with
-        frame shards the clustering state is handed from rank to rank in frame order, which is
-        the same ordered stream the reference sees."""
+        is stable (:199-315).  On one GPU the rows are an ordered stream through the device's clustering state.
+
+        With frame shards (``X.comm.size > 1``) there are two modes, chosen by ``X.fit_mode``:
+
+        ``"exact"`` (default): the clustering state is handed from rank to rank in frame order - the same ordered
+        stream the reference sees, the same centres bit for bit; the fit does not get faster with more GPUs.
+
+        ``"shard-merge"``: every rank clusters ITS rows (all ranks at once), the ranks all-gather their clusters'
+        sufficient statistics - running-mean centre (sparse), sample count - in rank order, which is the order of first
+        appearance, and every rank merges them with the reference's own re-clustering pass over centres weighted by
+        their counts (iterations >= 2, :290-306).  Deterministic and identical on every rank, but NOT the reference's
+        sequence: a few labels differ from the exact mode, the site numbering may be permuted.  A
+        throughput mode."""
         X = _as_device_rows(X)
         ctx, comm = X.ctx, X.comm
         centers = np.zeros((0, ctx.D))
         counts = np.zeros(0, dtype=np.int64)
+        mode = getattr(X, "fit_mode", "exact") or "exact"
+        if mode not in ("exact", "shard-merge"):
+            raise ValueError("fit_mode must be 'exact' or 'shard-merge', not %r" % (mode,))
+        tm = {"fit_mode": mode if comm.size > 1 else "exact", "fit_s": 0.0, "exchange_s": 0.0, "merge_s": 0.0}
+        t0 = time.perf_counter()
+
+        def lap(key):
+            nonlocal t0
+            now = time.perf_counter()
+            tm[key] += now - t0
+            t0 = now
+
         prefit = getattr(X, "prefit_threshold", None)
         if prefit is not None and prefit == self._threshold and comm.size == 1:
             # the rows went through the fit while they were being made (sit_upload_fill_fit): the state is there
@@ -100,17 +143,40 @@ class DotProdClassifier(object):
             centers, counts = ctx.fit_get_state()
         else:
             prefit = None
-        for r in range(comm.size if prefit is None else 0):
-            if comm.rank == r:
-                if r == 0:
-                    ctx.fit_reset()
-                else:
-                    ctx.fit_set_state(centers, counts)
-                ctx.fit_push_stored_rows(self._threshold)
-                centers, counts = ctx.fit_get_state()
-            if comm.size > 1:
-                centers = comm.bcast(centers, root=r)
-                counts = comm.bcast(counts, root=r)
+        if prefit is None and comm.size > 1 and mode == "shard-merge":
+            ctx.fit_reset()
+            ctx.fit_push_stored_rows(self._threshold)                     # this shard's rows, every rank at once
+            mine_c, mine_n = ctx.fit_get_state()
+            lap("fit_s")
+            width = int((mine_c != 0).sum(axis=1).max()) if len(mine_c) else 0
+            shape = comm.allgather(np.array([len(mine_c), width], dtype=np.int64))
+            kmax, wmax = int(shape[:, 0].max()), max(int(shape[:, 1].max()), 1)
+            idx, val = _pack_sparse(mine_c, wmax)
+            pad = kmax - len(mine_c)
+            idx = np.concatenate([idx, np.full((pad, wmax), -1, dtype=np.int64)])
+            val = np.concatenate([val, np.zeros((pad, wmax))])
+            cnt = np.concatenate([mine_n.astype(np.int64), np.zeros(pad, dtype=np.int64)])
+            all_idx, all_val, all_cnt = comm.allgather(idx), comm.allgather(val), comm.allgather(cnt)
+            lap("exchange_s")
+            keep = [slice(0, int(k)) for k in shape[:, 0]]
+            centers = np.concatenate([_unpack_sparse(all_idx[r][keep[r]], all_val[r][keep[r]], ctx.D) for r in range(comm.size)])
+            counts = np.concatenate([all_cnt[r][keep[r]] for r in range(comm.size)])
+            tm["clusters_per_rank"] = [int(k) for k in shape[:, 0]]
+            # from here on: the reference's passes over (centre, count) pairs - the loop below
+        elif prefit is None:
+            for r in range(comm.size):
+                if comm.rank == r:
+                    if r == 0:
+                        ctx.fit_reset()
+                    else:
+                        ctx.fit_set_state(centers, counts)
+                    ctx.fit_push_stored_rows(self._threshold)
+                    centers, counts = ctx.fit_get_state()
+                    lap("fit_s")
+                if comm.size > 1:
+                    centers = comm.bcast(centers, root=r)
+                    counts = comm.bcast(counts, root=r)
+                    lap("exchange_s")
         last = len(centers)
         converged = False
         for _ in range(1, self._max_iters):
@@ -121,6 +187,9 @@ class DotProdClassifier(object):
                 converged = True
                 break
             last = len(centers)
+        lap("merge_s")
+        self.fit_timings = tm
+        X.fit_timings = tm
         if not converged:
             raise ValueError("Clustering did not converge after %i iterations" % self._max_iters)
         self._cluster_centers = centers

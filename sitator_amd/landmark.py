@@ -9,8 +9,8 @@ and the same exceptions; the work happens in hand-written HIP kernels behind the
                   (wrap + static-lattice check fused)     (fit / predict / Gram on device)
     --> site centres (two reductions) --> occupancy check --> SiteTrajectory
 
-Extra, reference-preserving keywords: ``comm`` (frame sharding across GPUs, see ``sharding.py``)
-and ``device``.
+Extra, reference-preserving keywords: ``comm`` (frame sharding across GPUs, see ``sharding.py``),
+``device``, ``fit_mode`` (how a sharded run fits the dotprod clustering; the default is the reference's sequence).
 """
 import importlib
 import os
@@ -57,7 +57,7 @@ class LandmarkAnalysis(object):
                  site_centers_method=SITE_CENTERS_REAL_WEIGHTED, check_for_zero_landmarks=True,
                  static_movement_threshold=1.0, dynamic_lattice_mapping=False,
                  relaxed_lattice_checks=False, max_mobile_per_site=1, force_no_memmap=False,
-                 verbose=True, comm=None, device=None, recenter_masses=None):
+                 verbose=True, comm=None, device=None, recenter_masses=None, fit_mode="exact"):
         self._cutoff_midpoint = cutoff_midpoint
         self._cutoff_steepness = cutoff_steepness
         self._minimum_site_occupancy = minimum_site_occupancy
@@ -73,6 +73,13 @@ class LandmarkAnalysis(object):
         self.force_no_memmap = force_no_memmap
         self._comm = comm if comm is not None else Comm()
         self._device = device
+        # Not in the reference (one process there): how a frame-sharded run fits the dotprod clustering.  "exact": the
+        # clustering state relayed from rank to rank in frame order - the reference's result, no speed-up of the fit;
+        # "shard-merge": every rank fits its shard, all-gather of the clusters' sufficient statistics, identical
+        # deterministic merge on every rank (DotProdClassifier.fit_centers) - scales, a few labels differ.
+        if fit_mode not in ("exact", "shard-merge"):
+            raise ValueError("fit_mode must be 'exact' or 'shard-merge'")
+        self._fit_mode = fit_mode
         # Not in the reference (default None = its behaviour): per-atom masses; the frames are recentred on the static
         # sub-lattice's centre of mass ON THE DEVICE before the analysis - what RecenterTrajectory.run (the step the
         # reference's own error message recommends, util/RecenterTrajectory.pyx:66-100) does to the host array, without
@@ -185,6 +192,7 @@ class LandmarkAnalysis(object):
                            % self.n_all_zero_lvecs)
         self._landmark_vectors = LandmarkVectors(ctx, comm)
         self._landmark_vectors.prefit_threshold = prefit    # the first pass of fit_centers is in the context already
+        self._landmark_vectors.fit_mode = self._fit_mode
 
         lap("fill")
         # Step 3: cluster (plugin located by name, :234-242)
@@ -234,6 +242,7 @@ class LandmarkAnalysis(object):
         lap("occupancy")
         self.timings = ctx.timers()
         self.wall_timings = wall
+        self.fit_timings = getattr(self._landmark_vectors, "fit_timings", None)     # dotprod: fit / exchange / merge seconds
         self._has_run = True
         return out_st
 

@@ -39,6 +39,23 @@ class Comm(object):
         pass
 
 
+def partition_mismatch(a, b):
+    """Number of positions on which two label arrays disagree once their numberings are matched: every label of ``a``
+    is mapped to the label of ``b`` it shares the most positions with (-1 = unassigned is a label like any other).  0
+    for identical partitions, whatever the numbering - the measure for the ``shard-merge`` fit against the exact one."""
+    a = np.asarray(a).reshape(-1)
+    b = np.asarray(b).reshape(-1)
+    assert a.shape == b.shape
+    if a.size == 0:
+        return 0
+    kb = int(b.max()) + 2
+    pair, cnt = np.unique((a.astype(np.int64) + 1) * kb + (b.astype(np.int64) + 1), return_counts=True)
+    la = pair // kb
+    best = np.zeros(int(la.max()) + 1, dtype=np.int64)
+    np.maximum.at(best, la, cnt)
+    return int(a.size - best.sum())
+
+
 _MAGIC = b"SITATOR-CTL1"
 
 

@@ -87,7 +87,7 @@ class FakeContext(object):
         return self.D
 
     def fill(self, dynamic_lattice_mapping=False, relaxed_lattice_checks=False, check_for_zeros=True,
-             assign=False, predict_threshold=0.0, store_rows=True):
+             assign=False, predict_threshold=0.0, store_rows=True, defer=False):
         mid, steep, thr = self.params
         try:
             self.X, nz = orc.fill(self.cell, self.wrapped, self.static_idx, self.mobile_idx, self.ref_static,

@@ -28,7 +28,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case_name, tag, outdir):
+def _worker(rank, world, port, case_name, tag, outdir, fit_mode="exact"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -44,7 +44,7 @@ def _worker(rank, world, port, case_name, tag, outdir):
     sn.centers = c.centers
     sn.vertices = c.vertices
     lo, hi = shard_frames(len(c.frames), rank, world)
-    la = LandmarkAnalysis(verbose=False, comm=TorchComm(), **c.kwargs(tag))
+    la = LandmarkAnalysis(verbose=False, comm=TorchComm(), fit_mode=fit_mode, **c.kwargs(tag))
     out = {"lo": lo, "hi": hi}
     try:
         st = la.run(sn, np.ascontiguousarray(c.frames[lo:hi]))
@@ -64,11 +64,11 @@ def _worker(rank, world, port, case_name, tag, outdir):
     dist.destroy_process_group()
 
 
-def _run(case_name, tag, world=2):
+def _run(case_name, tag, world=2, fit_mode="exact"):
     import torch.multiprocessing as mp
     port = _free_port()
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, port, case_name, tag, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, case_name, tag, d, fit_mode), nprocs=world, join=True)
         return [dict(np.load(os.path.join(d, "rank%d.npz" % r), allow_pickle=False)) for r in range(world)]
 
 
@@ -106,6 +106,46 @@ def test_first_offender_is_global_and_raised_on_every_rank(name, tag):
             assert int(o["site"]) == int(exp["error_site"])
         if "error_mobile_index" in exp:
             assert int(o["mobile_index"]) == int(exp["error_mobile_index"])
+
+
+@pytest.mark.parametrize("name,world,max_lost,max_frac,max_shift", [
+    ("c1_hex_scgrid", 2, 0, 0.001, 1e-3), ("c1_hex_scgrid", 3, 0, 0.001, 1e-3),
+    ("c1b_tri_bcctet", 2, 1, 0.08, 0.5), ("c1b_tri_bcctet", 3, 1, 0.08, 0.5)])
+def test_shard_merge_fit_finds_the_reference_sites(name, world, max_lost, max_frac, max_shift):
+    """fit_mode='shard-merge' (every rank fits its shard, all-gather of the clusters' sufficient statistics, identical
+    merge on every rank: util/DotProdClassifier.pyx:290-306) is NOT the reference's ordered stream, so labels may
+    differ - a throughput mode.  What it must deliver: the same result on every rank; sites that are the reference's
+    (every site centre on a golden one - within half an angstrom where the membership of a site changed); on the near-one-hot rows of the SCgrid host the golden partition itself;
+    on the overlap-rich BCC-tetrahedral host (4 ions, 1 000 frames: the hardest case for a blocked fit - a site visited
+    220 times in one shard only is absorbed by its neighbour in the merge) at most one site fewer and a partition that
+    differs from the golden one on at most 8 % of the positions (measured: 6.6 % / 6.0 % with 2 / 3 ranks, all of
+    them the lost site's samples turning unassigned)."""
+    from sitator_amd.sharding import partition_mismatch
+    outs = _run(name, "dotprod", world=world, fit_mode="shard-merge")
+    exp = G.Case(name).out("dotprod")
+    labels = np.concatenate([o["labels"] for o in outs])
+    assert labels.shape == exp["labels"].shape
+    k_ref = len(exp["site_centers"])
+    for o in outs:
+        assert "error" not in o
+        assert k_ref - max_lost <= len(o["centers"]) <= k_ref
+        assert np.array_equal(o["centers"], outs[0]["centers"]), "every rank must end with the same merged sites"
+    cell = G.Case(name).cell
+    inv = np.linalg.inv(cell)
+    for c in outs[0]["centers"]:                       # periodic distance to the nearest golden site centre
+        d = (exp["site_centers"] - c[None, :]) @ inv
+        d -= np.round(d)
+        assert np.min(np.linalg.norm(d @ cell, axis=1)) < max_shift
+    bad = partition_mismatch(labels, exp["labels"])
+    assert bad <= max_frac * labels.size, "%d of %d positions differ from the exact fit" % (bad, labels.size)
+
+
+def test_partition_mismatch_ignores_the_numbering():
+    from sitator_amd.sharding import partition_mismatch
+    a = np.array([0, 0, 1, 1, 2, -1, -1, 2])
+    assert partition_mismatch(a, a) == 0
+    assert partition_mismatch(a, np.array([5, 5, 3, 3, 0, -1, -1, 0])) == 0
+    assert partition_mismatch(a, np.array([5, 5, 3, 5, 0, -1, 0, 0])) == 2
 
 
 def test_shard_frames_partition():
