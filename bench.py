@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--config", default=None, help="C2 on one GPU, C4 on several (BASELINE.json configs[1] / configs[3])")
     ap.add_argument("--algo", default=None, help="clustering plugin of the end-to-end run: dotprod, or mcl (the default of C5)")
     ap.add_argument("--cpu-frames", type=int, default=1000, help="frames per core of the CPU-baseline cut (0 = skip)")
+    ap.add_argument("--no-scale-ref", action="store_true", help="N = 1, default workload: skip the C4-share pass that anchors the N > 1 series")
     return ap.parse_args()
 
 
@@ -176,6 +177,29 @@ def main():
            "fit": {k: v for k, v in la._ctx.info().items() if k.startswith("fit_")},
            "exchange": exchange}
     e2e_labels = st_full.traj.reshape(-1)
+    if world > 1 and args.algo == "dotprod":
+        # how the ranks spent the fit of the exact (relayed) run, and the same run with fit_mode="shard-merge" (every rank
+        # fits its shard, all-gather of the clusters' sufficient statistics, identical merge everywhere): seconds, and
+        # the positions whose site differs from the exact run's once the numberings are matched
+        ft = la.fit_timings or {}
+        e2e["fit_per_rank"] = {k: [round(float(v), 4) for v in comm.allgather(np.array([ft.get(k, 0.0)]))[:, 0]]
+                               for k in ("fit_s", "exchange_s", "merge_s")}
+        comm.barrier()
+        t0 = time.time()
+        la_m = LandmarkAnalysis(verbose=False, device=local, comm=comm, fit_mode="shard-merge", **la_kw)
+        st_m = la_m.run(sn, frames)
+        t_m = time.time() - t0
+        fm = la_m.fit_timings or {}
+        k_exact, k_merge = int(st_full.site_network.n_sites), int(st_m.site_network.n_sites)
+        e2e["shard_merge"] = {
+            "run_seconds": round(t_m, 4), "sites": k_merge,
+            "lvec_per_s": round(world * F * M / t_m, 1),
+            "positions_differing_from_exact": sharding.partition_mismatch_sharded(comm, st_full.traj, st_m.traj, k_exact, k_merge),
+            "positions": int(world * F * M),
+            "clusters_per_rank": fm.get("clusters_per_rank"),
+            "fit_per_rank": {k: [round(float(v), 4) for v in comm.allgather(np.array([fm.get(k, 0.0)]))[:, 0]]
+                             for k in ("fit_s", "exchange_s", "merge_s")}}
+        del la_m, st_m
 
     # --- resident context for the timed pass ---
     ctx = _lib.HipContext(host.cell, device=local)
@@ -283,12 +307,57 @@ def main():
         }
         if args.cpu_frames > 0 and world == 1:          # a reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(host, gen, frames, ref, fit_ctx_centers, M, args.cpu_frames, ncpu)
+        if world == 1 and args.config == "C2" and F == FRAMES_PER_GPU["C2"] and not args.no_scale_ref:
+            # The N > 1 runs time configs[3] (C4: 125 000 frames per GPU, weak scaling).  So that a 1 -> 8 series compares
+            # like with like, the N = 1 line also carries the same pass over ONE GPU's share of C4.
+            del frames, ctx, la, st_full
+            out["scale_ref"] = scale_reference(args, local)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()
         if hasattr(comm, "close"):
             comm.close()
+
+
+def scale_reference(args, device):
+    """The timed pass of `--gpus N` (N > 1) on one GPU: one rank's share of BASELINE configs[3]."""
+    import numpy as np
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth, _lib
+    cfg, F = "C4", FRAMES_PER_GPU["C4"]
+    host = synth.config_host(cfg)
+    M = synth.CONFIG_MOBILE[cfg]
+    gen = synth.TrajectoryGenerator(host, M, seed=synth.CONFIG_SEED[cfg], threads=16)
+    ref = gen.reference_positions()
+    frames = gen.generate(F)
+    sn = SiteNetwork(Structure(ref, host.cell), gen.static_mask, gen.mobile_mask)
+    sn.centers = host.centers
+    sn.vertices = host.vertices
+    t0 = time.time()
+    la = LandmarkAnalysis(verbose=False, device=device)
+    la.run(sn, frames)
+    t_run = time.time() - t0
+    ctx = la._ctx
+    centers = np.asarray(la.cluster_centers_)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ctx.set_centers(centers / np.linalg.norm(centers, axis=1)[:, None], True)
+
+    def passes(n):
+        for _ in range(n):
+            rc, nz, err = ctx.fill(False, False, True, assign=True, predict_threshold=0.8, store_rows=False, defer=True)
+            assert rc == 0, rc
+        rc, nz, err = ctx.fill_result()
+        assert rc == 0, rc
+        ctx.synchronize()
+
+    passes(12)
+    steps = max(3, args.steps // 2)
+    t0 = time.perf_counter()
+    passes(steps)
+    dt = time.perf_counter() - t0
+    return {"workload": "%s, %d frames (one GPU's share of the N > 1 runs)" % (synth.CONFIG_TEXT.get(cfg, cfg), F),
+            "value": F * M * steps / dt, "unit": "lvec/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "end_to_end_run_seconds_cold": round(t_run, 4)}
 
 
 def lib_sha():

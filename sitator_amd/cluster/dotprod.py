@@ -14,6 +14,8 @@ def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, ver
     clf = DotProdClassifier(threshold=params["clustering_threshold"], min_samples=min_samples)
     labels, confs = clf.fit_predict(landmark_vectors, predict_threshold=params["assignment_threshold"],
                                     verbose=verbose)
+    if hasattr(landmark_vectors, "ctx"):     # the centres the labels were assigned with (tests compare against the oracle)
+        landmark_vectors.assignment = {"centers": clf.cluster_centers, "normed": True, "threshold": params["assignment_threshold"]}
     return {
         "cluster-size": clf.cluster_counts,
         "cluster-labels": labels,

@@ -87,6 +87,17 @@ def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, ver
     on_device = comm.size > 1 and hasattr(comm, "ctx") and hasattr(X.ctx, "comm_attach")
     if on_device:
         X.ctx.comm_attach(comm.ctx)
+    try:
+        return _cluster(X, comm, params, n_lmk, n_rows, on_device, min_samples, verbose)
+    finally:
+        # whatever happens between the two reductions, the context must not stay attached: a later gram() on this rank
+        # would enter the collective alone
+        if on_device:
+            X.ctx.comm_attach(None)
+
+
+def _cluster(X, comm, params, n_lmk, n_rows, on_device, min_samples, verbose):
+    if on_device:
         gram, seen_ntimes = X.ctx.gram()                               # :54-55, summed over the ranks
         n_rows = int(comm.allreduce_sum(np.array([n_rows], dtype=np.int64))[0])
     elif comm.size > 1 and hasattr(X.ctx, "gram_limbs"):
@@ -156,12 +167,14 @@ def do_landmark_clustering(landmark_vectors, clustering_params, min_samples, ver
                                           verbose=verbose, return_info=True)
     kept = info["kept_clusters_mask"]
     groups = [g for i, g in enumerate(groups) if kept[i]]
+    # the centres the labels were assigned with (not part of the plugin contract: tests compare against the oracle)
+    landmark_vectors_handle = X
+    landmark_vectors_handle.assignment = {"centers": np.asarray(clf.cluster_centers), "normed": False, "threshold": predict_threshold}
 
     # representative landmark vector of each site: confidence-weighted mean of its rows (:114-122)
     weighted = params.get("weighted_representative_landmarks", True)
     if on_device:
         sums, wsum = X.ctx.weighted_row_sums(len(groups), weighted=weighted)      # summed over the ranks on the device
-        X.ctx.comm_attach(None)
     elif comm.size > 1 and hasattr(X.ctx, "weighted_row_sums_limbs"):
         from ..sharding import exact_sum_across
         K = len(groups)

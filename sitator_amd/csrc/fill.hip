@@ -420,12 +420,13 @@ extern "C" int sit_site_counts(sit_ctx *c, i64 K, i64 *counts)
 // instead: the leading frames are filled into scratch buffers, width = their longest row + 2 (at least 4); a longer row
 // later raises the kernel's capacity flag and the fill is repeated at the rigorous width.  Rows already allocated for
 // this trajectory length keep their width.  SITATOR_ROW_WIDTH=loose: always c->W; =<n>: n slots (tests).
+// out[0] = longest row, out[1] = entries of all rows (fits 32 bits: the leading frames hold <= 2^16 rows of <= 255)
 __global__ __launch_bounds__(256) void k_max_nnz(const i32 *nnz, i64 n, i32 *out)
 {
-    i32 m = 0;
-    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) m = nnz[i] > m ? nnz[i] : m;
-    for (int off = 32; off > 0; off >>= 1) { const i32 o = __shfl_down(m, off); m = o > m ? o : m; }
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+    i32 m = 0, t = 0;
+    for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) { const i32 v = nnz[i]; m = v > m ? v : m; t += v; }
+    for (int off = 32; off > 0; off >>= 1) { const i32 o = __shfl_down(m, off); m = o > m ? o : m; t += __shfl_down(t, off); }
+    if ((threadIdx.x & 63) == 0 && m > 0) { atomicMax(out, m); atomicAdd(out + 1, t); }
 }
 
 static int measured_row_width(sit_ctx *c, const sit_fill_params *p, i64 *W_out)
@@ -454,7 +455,7 @@ static int measured_row_width(sit_ctx *c, const sit_fill_params *p, i64 *W_out)
     const double k_delta = c->tight_delta;
     c->d_row_nnz = s_nnz; c->d_row_idx = s_idx; c->d_row_val = s_val; c->N = Ns; c->rows_W = W;
     c->tight_delta = -1.0;                        // the loose table will do (the rows are the same): no table is built for this
-    hipError_t e = hipMemsetAsync(s_max, 0, 4, c->stream);
+    hipError_t e = hipMemsetAsync(s_max, 0, 8, c->stream);
     if (e == hipSuccess && (rc = reset_fill_words(c)) == SIT_OK) rc = fill3_launch(c, p, true, 0, Fs);
     c->d_row_nnz = k_nnz; c->d_row_idx = k_idx; c->d_row_val = k_val; c->N = k_N; c->rows_W = k_W;
     c->tight_delta = k_delta;
@@ -462,9 +463,11 @@ static int measured_row_width(sit_ctx *c, const sit_fill_params *p, i64 *W_out)
     if (rc) return rc;
     k_max_nnz<<<dim3((unsigned)((Ns + 255) / 256 > 256 ? 256 : (Ns + 255) / 256)), dim3(256), 0, c->stream>>>(s_nnz, Ns, s_max);
     HIP_TRY(c, hipGetLastError());
-    i32 mx = 0;
-    HIP_TRY(c, hipMemcpyAsync(&mx, s_max, 4, hipMemcpyDeviceToHost, c->stream));
+    i32 mx2[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(mx2, s_max, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const i32 mx = mx2[0];
+    c->rows_mean_nnz = Ns > 0 ? (double)mx2[1] / (double)Ns : 0.0;       // decides where the assignment of a fused pass runs
     i64 w = (i64)mx + 2;
     if (w < 4) w = 4;
     *W_out = w < W ? w : W;
@@ -592,10 +595,25 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
     if (assign) SIT_REQUIRE(c, c->K > 0 && c->d_col_ptr, "sit_fill: assign requested but no centres set");
     // with `assign` the narrow rows are assigned inside the fill kernel (fill3.hip, FUSE) and the rows need not be
     // stored; otherwise the assignment is a second kernel that reads the stored rows
-    const bool want_fuse = assign && v3 && !p->dynamic_lattice_mapping;
+    // ... where that pays.  Measured: rows of up to four entries are assigned faster by the kernel
+    // that keeps the centres in LDS (C2: 0.92 against 1.38 ms per pass - the fused epilogue reads them from L2 in a
+    // chain of dependent loads while its workgroup holds its LDS); where most rows are wider (C5: 6 entries on
+    // average) the fused pass wins (3.5 against 5.0 ms) - it lists the wide rows as it makes them, where the narrow
+    // kernel reads every row to find them.  SITATOR_FUSE=0 / 1 overrides.
+    bool want_fuse = assign && v3 && !p->dynamic_lattice_mapping;
+    bool have_W = false;
+    if (want_fuse) {
+        const char *fe = getenv("SITATOR_FUSE");
+        if (fe && (fe[0] == '0' || fe[0] == '1')) want_fuse = fe[0] == '1';
+        else {
+            if ((rc = measured_row_width(c, p, &W))) return rc;
+            have_W = true;
+            want_fuse = c->rows_mean_nnz > 4.0;
+        }
+    }
     bool store = p->store_rows != 0 || !want_fuse;
     for (int attempt = 0; attempt < 2; attempt++) {
-        if (v3 && (rc = measured_row_width(c, p, &W))) return rc;
+        if (v3 && !(have_W && attempt == 0) && (rc = measured_row_width(c, p, &W))) return rc;
         const bool rows_measured = W < c->W;
         if (c->rows_W != W || c->rows_N != N || !c->d_row_nnz) {
             c->rows_valid = false;

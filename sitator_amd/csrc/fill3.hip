@@ -975,7 +975,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     // the fused assignment: narrow CSC columns only (the dense fall-back of the assignment has no merge), no dynamic
     // mapping, not an ablation run
     if (fuse && (p->dynamic_lattice_mapping || c->K <= 0 || !c->d_col_ptr || c->max_col > 24 || c->N >= (1LL << 31) ||
-                 f3_env_int("SITATOR_DEBUG_STOP", 0) || !f3_env_int("SITATOR_FUSE", 0))) fuse = false;
+                 f3_env_int("SITATOR_DEBUG_STOP", 0))) fuse = false;
     Fill3Args a;
     memset(&a, 0, sizeof(a));
     a.vh = (const uint4 *)c->d_vh; a.nvtab = c->d_nv;

@@ -101,6 +101,7 @@ struct sit_ctx {
     double *d_row_val = nullptr;
     bool rows_valid = false;
     bool rows_overflowed = false;     // a row was longer than the measured width: this context keeps the rigorous width
+    double rows_mean_nnz = 0;         // entries per row on the leading frames (measured_row_width)
 
     // assignment
     i64 *d_labels = nullptr;

@@ -36,9 +36,11 @@ class JumpAnalysis(object):
         logger.info("Running JumpAnalysis...")
         sn = st.site_network
         n_sites = sn.n_sites
-        # labels that came from the assignment kernel and never left the object are below n_sites by construction; an
-        # array the caller has had in hand is looked at (5 ms per 50 MB)
-        if (st._host_shared or st._ctx is None) and st._traj.size and int(st._traj.max()) >= n_sites:
+        # labels that came from the assignment kernel and never left the object are below n_sites by construction; any
+        # other array - built by the caller, or one the caller has had in hand - is looked at (5 ms per 50 MB): the
+        # kernels index K x K tables with them
+        trusted = getattr(st, "_labels_from_kernel", False) and not st._host_shared
+        if not trusted and st._traj.size and int(st._traj.max()) >= n_sites:
             # the reference's fancy indexing raises here (JumpAnalysis.py:75-88); the kernels index K x K tables
             raise IndexError("index %i is out of bounds for axis 0 with size %i" % (int(st._traj.max()), n_sites))
         ctx = st._device()

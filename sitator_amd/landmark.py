@@ -234,6 +234,7 @@ class LandmarkAnalysis(object):
         lap("site_centers")
         # the label array was made for this call and nothing else refers to it: adopted, not copied (0.9 GB at C3)
         out_st = SiteTrajectory(out_sn, lmk_lbls, lmk_confs, _ctx=ctx, _comm=comm, _adopt=True)
+        out_st._labels_from_kernel = True      # written by the assignment kernel against these very sites
         self.n_multiple_assignments, self.avg_mobile_per_site = out_st.check_multiple_occupancy(
             max_mobile_per_site=self.max_mobile_per_site)
         # the context is shared with this object (predict() through landmark_vectors rewrites its labels and bumps

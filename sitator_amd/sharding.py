@@ -39,6 +39,19 @@ class Comm(object):
         pass
 
 
+def partition_mismatch_sharded(comm, a, b, ka, kb):
+    """``partition_mismatch`` of label arrays that are sharded over the ranks of ``comm`` (``ka`` / ``kb``: number of
+    labels of each numbering, the same on every rank): the contingency table is summed over the ranks."""
+    a = np.asarray(a).reshape(-1).astype(np.int64) + 1
+    b = np.asarray(b).reshape(-1).astype(np.int64) + 1
+    table = np.zeros((ka + 1) * (kb + 1), dtype=np.int64)
+    np.add.at(table, a * (kb + 1) + b, 1)
+    if comm is not None and comm.size > 1:
+        table = comm.allreduce_sum(table)
+    table = table.reshape(ka + 1, kb + 1)
+    return int(table.sum() - table.max(axis=1).sum())
+
+
 def partition_mismatch(a, b):
     """Number of positions on which two label arrays disagree once their numberings are matched: every label of ``a``
     is mapped to the label of ``b`` it shares the most positions with (-1 = unassigned is a label like any other).  0

@@ -9,20 +9,23 @@ import numpy as np
 
 from . import _lib, errors
 
+import hashlib
+
 try:
     import xxhash as _xxhash
-except ImportError:             # the package is optional: a weaker (but still content-based) digest without it
+except ImportError:             # the package is optional: a slower digest of the same strength without it
     _xxhash = None
 
 
 def _digest(arr):
-    """Content digest of a label array (5 ms per 50 MB): what decides whether the device copy is still current."""
-    a = np.ascontiguousarray(arr)
+    """Content digest of a label array (xxh3: 5 ms per 50 MB; blake2b without the xxhash package: ~60 ms): what decides
+    whether the device copy is still current.  A real hash either way - a digest that two different arrays can share
+    would let jumps and occupancies be computed from stale device labels."""
+    a = np.ascontiguousarray(arr, dtype=np.int64)
+    raw = memoryview(a).cast("B")
     if _xxhash is not None:
-        return (a.shape, _xxhash.xxh3_128_intdigest(memoryview(a).cast("B")))
-    v = a.reshape(-1).view(np.uint64)
-    with np.errstate(over="ignore"):
-        return (a.shape, int(v.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(v * (np.arange(len(v), dtype=np.uint64) | np.uint64(1)))))
+        return (a.shape, _xxhash.xxh3_128_intdigest(raw))
+    return (a.shape, hashlib.blake2b(raw, digest_size=16).digest())
 
 
 class SiteTrajectory(object):
@@ -50,6 +53,9 @@ class SiteTrajectory(object):
         self._ctx = _ctx
         self._synced_version = _ctx.labels_version if _ctx is not None else -1
         self._host_shared = False
+        # True only for labels written by the assignment kernel (LandmarkAnalysis.run sets it) that have not left the
+        # object since: those are below n_sites by construction.  Anything else is looked at before it indexes a table.
+        self._labels_from_kernel = False
         self._comm = _comm
 
     # -- container protocol ---------------------------------------------------------------

@@ -174,26 +174,98 @@ def test_rows_wider_than_the_measured_width_are_filled_again_at_the_rigorous_wid
         assert np.array_equal(t_a, t) and np.array_equal(c_a, c) and np.array_equal(x_a, x)
 
 
-def test_fused_assign_equals_fill_then_predict(oracle):
+@pytest.mark.parametrize("cfg,M,F", [("C2", 64, 300), ("C3", 448, 24), ("C4", 256, 40), ("C5", 160, 120), ("C1b", 4, 700)])
+def test_fused_assign_equals_fill_then_predict(oracle, cfg, M, F):
+    """sit_fill with assign = 1 in its two forms - the assignment as kernels of its own behind the fill (SITATOR_FUSE=0),
+    and the narrow rows assigned INSIDE k_fill3 with the others listed for the wide-row kernel (SITATOR_FUSE=1; rows
+    stored or not) - against fill, then predict, and against the oracle.  Every host shape: one window per group of
+    four waves (C2), a wave per window (C3, C4), mostly wide rows (C5), four ions in one wave (C1b)."""
     from sitator_amd import synth
-    host = synth.config_host("C2")
-    ctx, frames, sm, mm, ref = _setup(host, 64, 300, seed=5)
+    host = synth.config_host(cfg)
+    ctx, frames, sm, mm, ref = _setup(host, M, F, seed=5)
     assert ctx.fill()[0] == 0
     X = ctx.rows_dense()
     centers = oracle.fit_centers(X, 0.45)
-    normed = centers / np.linalg.norm(centers, axis=1)[:, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        normed = centers / np.linalg.norm(centers, axis=1)[:, None]
     ctx.set_centers(normed, True)
     lab_a, conf_a, cnt_a = ctx.predict(0.8)
-    rc, _, _ = ctx.fill(assign=True, predict_threshold=0.8, store_rows=False)
-    assert rc == 0
-    lab_b, conf_b, cnt_b = ctx.assignments()
-    assert np.array_equal(lab_a, lab_b)
-    assert np.array_equal(conf_a, conf_b)
-    assert np.array_equal(cnt_a, cnt_b)
+    for fuse, store in (("0", True), ("1", True), ("1", False)):
+        os.environ["SITATOR_FUSE"] = fuse
+        try:
+            rc, _, _ = ctx.fill(assign=True, predict_threshold=0.8, store_rows=store)
+        finally:
+            os.environ.pop("SITATOR_FUSE", None)
+        assert rc == 0
+        assert ctx.info()["assignment_fused"] == (fuse == "1"), "the requested form of the pass did not run"
+        lab_b, conf_b, cnt_b = ctx.assignments()
+        assert np.array_equal(lab_a, lab_b), (fuse, store)
+        assert np.array_equal(conf_a, conf_b), (fuse, store)
+        assert np.array_equal(cnt_a, cnt_b), (fuse, store)
+        if store:
+            assert np.array_equal(ctx.rows_dense(), X)
     lab_o, conf_o = oracle.predict(X, centers, 0.8, True)
     assert np.array_equal(lab_o, lab_b)
     m = lab_o >= 0
     np.testing.assert_allclose(conf_b[m], conf_o[m], rtol=1e-6)
+
+
+def test_fused_assign_when_a_window_outgrows_its_survivor_list():
+    """The fused pass keeps a window's rows in the wave's survivor list; a window with more survivors than the list
+    holds (forced here: 16 slots) spills to the row buffers and its rows go through the listed-rows kernel.  Same
+    labels, confidences and counts."""
+    from sitator_amd import synth
+    host = synth.config_host("C5")
+    ctx, frames, sm, mm, ref = _setup(host, 160, 60, seed=15)
+    assert ctx.fill()[0] == 0
+    from sitator_amd.dotprod_classifier import DotProdClassifier, LandmarkVectors
+    clf = DotProdClassifier(threshold=0.45)
+    clf.fit_centers(LandmarkVectors(ctx))
+    cen = np.asarray(clf.cluster_centers)
+    normed = cen / np.linalg.norm(cen, axis=1)[:, None]
+    ctx.set_centers(normed, True)
+    lab_a, conf_a, cnt_a = ctx.predict(0.8)
+    os.environ.update(SITATOR_FUSE="1", SITATOR_FILL_RCAP="16")
+    try:
+        rc, _, _ = ctx.fill(assign=True, predict_threshold=0.8, store_rows=False)
+    finally:
+        os.environ.pop("SITATOR_FUSE", None)
+        os.environ.pop("SITATOR_FILL_RCAP", None)
+    assert rc == 0 and ctx.info()["assignment_fused"]
+    lab_b, conf_b, cnt_b = ctx.assignments()
+    assert np.array_equal(lab_a, lab_b) and np.array_equal(conf_a, conf_b) and np.array_equal(cnt_a, cnt_b)
+
+
+def test_deferred_fill_reports_through_fill_result():
+    """sit_fill with defer = 1 only enqueues; the status, the zero-vector count and the first offender of the passes in
+    flight come from fill_result() - and a later call returns a failure that has landed instead of running."""
+    from sitator_amd import synth, _lib
+    host = synth.config_host("C2")
+
+    def sit_on_host(frames, sm, mm):
+        frames[37, np.where(mm)[0][5]] = host.static_pos[0] + 0.01      # no landmark in reach of this ion
+
+    ctx, frames, sm, mm, ref = _setup(host, 64, 120, seed=3, mutate=sit_on_host)
+    for _ in range(3):                                                   # counted, not raised
+        rc, nz, err = ctx.fill(check_for_zeros=False, defer=True)
+        assert rc == 0 and nz == -1
+    rc, nz, err = ctx.fill_result()
+    assert rc == 0 and nz == 1
+    rc_b, nz_b, _ = ctx.fill(check_for_zeros=False)
+    assert rc_b == 0 and nz_b == 1
+    rc, nz, err = ctx.fill(check_for_zeros=True, defer=True)             # raised: when the result is collected ...
+    assert rc == 0
+    rc, nz, err = ctx.fill_result()
+    assert rc == _lib.E_ZERO_LANDMARK and (err.frame, err.index) == (37, 5)
+    rc, nz, err = ctx.fill(check_for_zeros=True, defer=True)
+    assert rc == 0
+    ctx.lib.sit_synchronize(ctx._h)                                      # ... or by the next call once it has landed
+    rc, nz, err = ctx.fill(check_for_zeros=True, defer=True)
+    assert rc == _lib.E_ZERO_LANDMARK and (err.frame, err.index) == (37, 5)
+    rc, nz, err = ctx.fill_result()                                      # reported once
+    assert rc == 0
+    rc, nz, err = ctx.fill(check_for_zeros=False)
+    assert rc == 0 and nz == 1
 
 
 @pytest.mark.parametrize("cfg,M,F", [("C2", 64, 400), ("C5", 160, 120)])

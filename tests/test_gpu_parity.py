@@ -337,3 +337,40 @@ def test_pipelined_call_reports_the_first_offender_of_a_late_chunk(kind):
         assert got[0].frame == got[1].frame == 11000 and list(got[0].lattice_atoms) == list(got[1].lattice_atoms)
     else:
         assert (got[0].frame, got[0].mobile_index) == (got[1].frame, got[1].mobile_index)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["static", "count"])
+def test_pipelined_call_keeps_what_chunk_zero_reported_through_a_later_shape_trial(kind):
+    """ADVICE r2's directed case.  The first fill of a kind times a few launch shapes on its leading frames - but only
+    a launch of 2^18 rows or more does.  With 32 ions and 20 000 frames the pipelined call's chunk 0 (5 000 frames =
+    160 000 rows) is below that and the merged launch of the later chunks is above it: the trial launches of that later
+    launch must not wipe what chunk 0 has reported (they report into words of their own).  An offender / a zero vector
+    planted in chunk 0 must come out exactly as from the separate calls."""
+    import os
+    from sitator_amd import synth, errors
+    host = synth.config_host("C2")
+    gen = synth.TrajectoryGenerator(host, 32, seed=79)
+    frames = gen.generate(20000)
+    sidx, midx = np.where(gen.static_mask)[0], np.where(gen.mobile_mask)[0]
+    if kind == "static":
+        frames[1234, sidx[7]] += (0.0, 1.8, 0.0)                # beyond static_movement_threshold, in chunk 0
+        frames[17000, sidx[3]] += (1.9, 0.0, 0.0)
+        got = []
+        for pipeline in (True, False):
+            with pytest.raises(errors.StaticLatticeError) as ei:
+                _run_c2(frames, gen, host, pipeline)
+            got.append(ei.value)
+        assert got[0].frame == got[1].frame == 1234 and list(got[0].lattice_atoms) == list(got[1].lattice_atoms) == [7]
+    else:
+        frames[777, midx[3]] = host.static_pos[0] + 0.01        # a zero landmark vector in chunk 0, counted not raised
+        frames[15000, midx[9]] = host.static_pos[5] + 0.01
+        os.environ["SITATOR_FILL_AUTOTUNE"] = "1"
+        try:
+            la_p, st_p = _run_c2(frames, gen, host, True, check_for_zero_landmarks=False)
+            la_s, st_s = _run_c2(frames, gen, host, False, check_for_zero_landmarks=False)
+        finally:
+            os.environ.pop("SITATOR_FILL_AUTOTUNE", None)
+        assert la_p._pipelined and not la_s._pipelined
+        assert la_p.n_all_zero_lvecs == la_s.n_all_zero_lvecs == 2
+        assert np.array_equal(st_p.traj, st_s.traj)
