@@ -689,7 +689,7 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
 // slots, each slot leaves by DMA on `stream` as soon as it is staged and is reused once its DMA has finished.  (A plain
 // hipMemcpyAsync of pageable memory is as fast, 55 GB/s, but it blocks the runtime for other threads' launches while it
 // runs: this one only enqueues.)  Returns when the whole range has arrived.
-#define RING_SLOTS 8
+#define RING_SLOTS 16         // (eight until the fit stopped being the longer leg: four staging threads then capped the upload at 40 GB/s)
 #define RING_CHUNK ((size_t)4 << 20)
 static std::mutex g_ring_mutex;
 static char *g_ring = nullptr;

@@ -18,12 +18,21 @@
 //                 last join before the row: highest set bit below the row in the centre's bitmap).  By induction the
 //                 first row whose decision differs from its speculation is the first wrong one; rows before it are
 //                 exact, and so is ITS re-decision.
-//   D  commit     cut = first row that is wrong / founds a cluster.  Every centre takes the version left by its last
-//                 join before the cut (no re-walk); one wave applies row `cut` itself with its verified decision
-//                 (founding a cluster, or a join that may grow the centre's support), publishes support growth to the
-//                 per-dimension lists and writes the control block of the next step.  When the batch was cut at its
-//                 very first row by a founding row, the same wave keeps deciding and applying rows one at a time
-//                 while they found clusters (the first frames of a trajectory, a stream of cluster centres).
+//   A' found      (round 4) rows that found a cluster no longer end the batch.  One workgroup takes the rows speculated to
+//                 be below the threshold against every centre and settles them among themselves: the first founds
+//                 TENTATIVE centre K, a later one joins the best earlier founder it matches or founds K + 1, ... (up to
+//                 FS_TF founders) - still a speculation (founders are scored as their rows, not as they will have
+//                 evolved).  A tentative centre gets its slot in the state arrays (beyond K: invisible to
+//                 anybody else), a bitmap for its joins and a growth record per dimension, so that B walks it and C
+//                 scores it like any other centre.  The reference's sequence is what C enforces: a row that should have
+//                 founded / joined otherwise is the first wrong row, as ever.
+//   D  commit     cut = first row that is wrong, must go the serial way, or is the first founding row A' did not take.
+//                 Every centre - the tentative ones founded before the cut become real - takes the version left by its
+//                 last join before the cut (no re-walk); one wave applies row `cut` itself with its verified decision
+//                 (founding a cluster, or a join that may grow the centre's support), publishes support growth and
+//                 foundings to the per-dimension lists and writes the control block of the next step.  When the batch
+//                 was cut at its very first row by a founding row, the same wave keeps deciding and applying rows one
+//                 at a time while they found clusters.
 // Centres are kept sparse (sorted support, <= FS_CS entries); dot products sum in ascending dimension order, norms
 // sum in ascending order: identical to dense left-to-right sums (zeros add nothing).  A capacity that does not fit
 // (support, candidates, centres per dimension) stops the stream with the state exact as of that row; the caller
@@ -47,6 +56,8 @@
 #define FS_NP 16                  // row entries staged per joining row
 #define FS_LCAP 8192              // joining rows listed at a time by a walking wave
 #define FS_TAIL 64                // rows the commit may apply one at a time
+#define FS_TF 64                  // tentative centres (founding rows taken inside a batch) per step
+#define FS_LGS 512                // growth records the verification stages in LDS
 #define FS_NEW (-1)
 #define FS_BREAK (-2)             // row must go the serial way (zero row, capacity)
 #define FS_CHUNK 64               // steps enqueued between two looks at the control block
@@ -70,7 +81,9 @@ struct FSCtl {
     i32 halt;                                 // 0 running, 1 stream done, 2 centre arrays must grow, 3 capacity (flags)
     i32 steps, bad_steps, single_rows;
     i64 trace_n;
-    i32 pad[14];
+    i32 nfound;                               // tentative centres of this step (K .. K + nfound - 1), set by k_fs_found
+    i32 any_new;                              // some row of the batch was speculated to found a cluster
+    i32 pad[12];
 };
 static_assert(sizeof(FSCtl) == 128, "FSCtl layout");
 
@@ -88,11 +101,16 @@ struct FS {
     i32 *dec, *vdec, *ov_n, *ov_id;
     double *xn;
     VsEnt *vs_ent;            // versions: state of the joined centre right after batch row j joined it [FS_BMAX][FS_CS]
-    i32 *log;                 // growth records of the walk: (centre, dimension, batch row)
+    i32 *log;                 // growth records of the walk and the foundings of A': (centre, dimension, batch row)
     u64 *bm0, *bm1;
+    u64 *nbm;                 // [FS_W0] batch rows speculated to found a cluster ("new" rows)
+    i32 *tf_row;              // [FS_TF] batch row of every tentative founder, ascending
+    i32 *nw_t;                // [FS_BMAX] per listed new row: the tentative founder it is speculated to join (-1: none yet)
+    double *nw_v;             // ... and its score against it
     FSCtl *ctl;               // [2]
     i64 *trace;               // diagnostics (SITATOR_FF_TRACE), 6 values per step
     i64 D, Kcap;
+    int newcap;               // new rows k_fs_found takes per step (SITATOR_FF_NEWCAP)
 };
 
 #define OV(s, j, p) (s).ov_id[(i64)(p) * FS_BMAX + (j)]     // slot-major: coalesced across rows
@@ -116,6 +134,16 @@ __device__ __forceinline__ void wave_mem_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
+}
+
+// exclusive sum scan over the wave; total = the sum
+__device__ __forceinline__ int wave_excl_scan_i(int x, int lane, int &total)
+{
+    int v = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
+    total = __shfl(v, 63);
+    return v - x;
 }
 
 template <int G>
@@ -401,7 +429,11 @@ __device__ __forceinline__ void fs_speculate(const FS &s, const FSRows &r, FSCtl
         if (dec >= 0) {
             atomicOr((unsigned long long *)&s.bm0[(i64)dec * FS_W0 + (j >> 6)], 1ull << (j & 63));
             atomicOr((unsigned long long *)&s.bm1[(i64)dec * FS_W1 + (j >> 12)], 1ull << ((j >> 6) & 63));
-        } else atomicMin(&ctl->first_new, j);
+        } else if (dec == FS_NEW) {                                // k_fs_found takes it from here
+            atomicOr((unsigned long long *)&s.nbm[j >> 6], 1ull << (j & 63));
+            ctl->any_new = 1;
+        }
+        else atomicMin(&ctl->first_new, j);                        // the serial way: the batch ends before it
     }
 }
 
@@ -417,6 +449,271 @@ __global__ __launch_bounds__(256) void k_fs_speculate(FS s, FSRows r, int par, d
     // small batches: a wave per row (latency); large ones: sixteen lanes per row (throughput)
     if (nb <= 16384) fs_speculate<NR, NS, 64>(s, r, ctl, nb, K, pos, threshold, ovl + (threadIdx.x >> 6) * FS_OC, seen + (threadIdx.x >> 6) * FS_BMW);
     else fs_speculate<NR, NS, 16>(s, r, ctl, nb, K, pos, threshold, ovl + (threadIdx.x >> 4) * FS_OC, seen + (threadIdx.x >> 4) * FS_BMW);
+}
+
+// ---- A': founding rows inside the batch ----------------------------------------------------------------------
+// One workgroup of 1024 threads.  The rows of the batch that the speculation found below the threshold against every
+// centre ("new" rows: an ion that has reached a site nobody has visited stays there, so a batch holds one founding row
+// and then a thousand like it, for every such site) are listed in row order and settled among themselves in ROUNDS.
+// Every listed row carries a 32-bit signature of its landmarks; rows whose signatures do not meet share no landmark
+// and cannot score against each other.  In a round every unsettled row bids for its signature bits with its list
+// position (a minimum per bit); a row that holds all its bits has no unsettled row before it that it could join: it
+// FOUNDS a tentative centre (:250-260: the centre is the row) - all such rows at once, they cannot score against each
+// other either.  Then every row that is not settled yet is scored against the new founders BEFORE it whose signature
+// meets its own and, at or above the threshold, is speculated to JOIN the best founder so far (first maximum).  Rounds
+// go on until every row is settled: two to four of them, where founding one row at a time took a round - a chain of
+// memory round trips - per founder (twenty to thirty in the early batches of C2).
+// Tentative centres are numbered in ROW order (the order the reference founds them in) once all are known; founders
+// get their state slot, their growth records (centre, dimension, founding row) and a place in tf_row, joiners their
+// decision and their bit in the founder's bitmap.  More than FS_TF founders, or more rows than the threads hold: the
+// batch ends before the first row that is left (ctl->first_new).  Nothing here is trusted: founders are scored as
+// their rows, not as they will have evolved, and k_fs_verify re-decides every one of these rows against the versions.
+template <int NR, int NS>
+__global__ __launch_bounds__(1024) void k_fs_found(FS s, FSRows r, int par, double threshold)
+{
+    constexpr int UC = NR <= 4 ? 12 : 6;                          // listed rows per thread: three registers each
+    __shared__ int part[16];
+    __shared__ int owner[32];
+    __shared__ int sh_fcount, sh_unset, sh_cut, sh_qlim;
+    __shared__ int hist[64];
+    __shared__ int f_q[FS_TF], f_j[FS_TF], f_n[FS_TF], f_rank[FS_TF], f_lbase[FS_TF];
+    __shared__ unsigned f_sig[FS_TF];
+    __shared__ double f_nrm[FS_TF];
+    __shared__ __attribute__((aligned(16))) i32 f_ri[FS_TF * FS_NP];
+    __shared__ __attribute__((aligned(16))) double f_rv[FS_TF * FS_NP];
+    FSCtl *ctl = s.ctl + par;
+    if (ctl->halt) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = ctl->nb, K = ctl->K;
+    if (nb <= 0 || !ctl->any_new) return;                         // (most batches of a long stream hold no such row)
+    const i64 pos = ctl->pos;
+    int lim = nb;
+    { const int fnw = ctl->first_new; if (fnw < lim) lim = fnw; }
+    // the new rows below lim, in order: s.vdec[0, nnew) (the verification overwrites it later); the bitmap is cleared
+    // for the next step on the way
+    i32 *nl = s.vdec;
+    u64 word = 0ull;
+    if (tid < ((nb + 63) >> 6)) {
+        word = s.nbm[tid];
+        if (word) s.nbm[tid] = 0ull;
+        if (tid * 64 >= lim) word = 0ull;
+        else if (tid * 64 + 64 > lim) word &= (1ull << (lim - tid * 64)) - 1ull;
+    }
+    int wtot;
+    int p = wave_excl_scan_i(__popcll(word), lane, wtot);
+    if (lane == 0) part[wave] = wtot;
+    if (tid == 0) { sh_fcount = 0; sh_cut = 0x7fffffff; }
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    int nnew = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) p += part[w]; nnew += part[w]; }
+    while (word) { nl[p++] = tid * 64 + __ffsll((long long)word) - 1; word &= word - 1; }
+    if (tid == 0) { ctl->nfound = 0; ctl->any_new = nnew; }
+    if (nnew == 0) return;                                        // uniform
+    __syncthreads();                                              // the list is read by other threads than those that wrote it
+    {
+        // more rows than the threads hold (or than pays: the rounds below cost one CU's time per listed row): the batch
+        // ends before the rest
+        int cap = UC * 1024;
+        if (s.newcap > 0 && s.newcap < cap) cap = s.newcap;
+        if (nnew > cap) {
+            if (tid == 0) atomicMin(&ctl->first_new, nl[cap]);
+            nnew = cap;
+        }
+    }
+    // per listed row (q = tid + u * 1024): its batch row, the signature of its landmarks, and st = (founder slot + 1) <<
+    // 24 | score in units of 2^-23 (0: unsettled; slot 0xfe: a founder itself)
+    unsigned sig[UC], st[UC];
+    int jc[UC];
+#pragma unroll
+    for (int u = 0; u < UC; u++) {
+        const int q = tid + u * 1024;
+        sig[u] = 0u; st[u] = 0u; jc[u] = 0;
+        if (q < nnew) {
+            jc[u] = nl[q];
+            const i64 row = pos + jc[u];
+            const int n = r.nnz[row];
+            for (int e = 0; e < n; e++) sig[u] |= 1u << ((unsigned)(r.idx[(i64)e * r.stride + row] * 0x9E3779B1u) >> 27);
+        }
+    }
+    const double settled = threshold > 0.8 ? threshold : 0.8;
+    const unsigned settled_q = settled >= 1.0 ? 0xffffffu : (unsigned)(settled * 8388608.0);
+    int fdone = 0;                                                // founders of the rounds so far
+    for (;;) {
+        if (tid < 32) owner[tid] = 0x7fffffff;
+        if (tid == 0) sh_unset = 0;
+        __syncthreads();
+        // every unsettled row bids for its bits
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            const int q = tid + u * 1024;
+            if (q >= nnew || st[u]) continue;
+            any = true;
+            unsigned m = sig[u];
+            while (m) { const int bit = __ffs((int)m) - 1; m &= m - 1u; atomicMin(&owner[bit], q); }
+        }
+        if (__ballot(any) && lane == 0) sh_unset = 1;
+        __syncthreads();
+        if (!sh_unset) break;                                       // every row is settled
+        // a row that holds all its bits founds a tentative centre
+        unsigned fmask = 0u;
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            const int q = tid + u * 1024;
+            if (q >= nnew || st[u]) continue;
+            bool mineall = true;
+            unsigned m = sig[u];
+            while (m) { const int bit = __ffs((int)m) - 1; m &= m - 1u; mineall = mineall && owner[bit] == q; }
+            if (mineall) fmask |= 1u << u;
+        }
+        // more candidates than the FS_TF slots have room for (the first frame of a trajectory, a stream of cluster centres:
+        // every row founds): they are taken in ROW order - a histogram of their list positions over 64 buckets says how
+        // far the room reaches; the rest waits (and the batch ends before the first row that is left when the slots are full)
+        {
+            const int bsz = (nnew + 63) >> 6;
+#pragma unroll
+            for (int u = 0; u < UC; u++) if ((fmask >> u) & 1u) atomicAdd(&hist[(tid + u * 1024) / bsz], 1);
+            __syncthreads();
+            if (wave == 0) {
+                int tot;
+                const int before = wave_excl_scan_i(hist[lane], lane, tot);
+                const int room = FS_TF - sh_fcount;
+                // the first bucket that does not fit whole still gets what room is left (in no particular order)
+                const u64 fit = __ballot(before + hist[lane] <= room);
+                const int nfit = fit == ~0ull ? 64 : __ffsll((long long)~fit) - 1;
+                if (lane == 0) sh_qlim = tot <= room ? 0x7fffffff : (nfit + 1) * bsz;
+                hist[lane] = 0;
+            }
+            __syncthreads();
+            const int qlim = sh_qlim;
+#pragma unroll
+            for (int u = 0; u < UC; u++) if (tid + u * 1024 >= qlim) fmask &= ~(1u << u);
+        }
+        while (fmask) {                                             // (one copy of the staging code: the registers)
+            const int uu = __ffs((int)fmask) - 1;
+            fmask &= fmask - 1u;
+            int j = jc[0];
+            unsigned sg = sig[0];
+#pragma unroll
+            for (int u = 1; u < UC; u++) { j = u == uu ? jc[u] : j; sg = u == uu ? sig[u] : sg; }
+            const i64 row = pos + j;
+            const int n = r.nnz[row];
+            const bool ok = n >= 1 && n <= FS_NP && n <= FS_SMAX;   // else: not a state this engine holds
+            const int slot = ok ? atomicAdd(&sh_fcount, 1) : FS_TF;
+            unsigned mark = 0xfe000000u;
+            if (slot >= FS_TF) { atomicMin(&sh_cut, j); mark = ok ? 0u : 0xff000000u; }   // no slot (it stays unsettled) / not holdable: the batch ends before it
+            else {
+                f_q[slot] = tid + uu * 1024; f_j[slot] = j; f_n[slot] = n; f_sig[slot] = sg; f_nrm[slot] = s.xn[j];
+                for (int e = 0; e < n; e++) { f_ri[slot * FS_NP + e] = r.idx[(i64)e * r.stride + row]; f_rv[slot * FS_NP + e] = r.val[(i64)e * r.stride + row]; }
+            }
+#pragma unroll
+            for (int u = 0; u < UC; u++) if (u == uu) st[u] = mark;
+        }
+        __syncthreads();
+        int fnow = sh_fcount;
+        if (fnow > FS_TF) fnow = FS_TF;
+        // the rows that are not settled (well) yet against the new founders before them
+        unsigned todo = 0u;
+#pragma unroll
+        for (int u = 0; u < UC; u++) {
+            const int q = tid + u * 1024;
+            if (q >= nnew || (st[u] >> 24) >= 0xfeu || ((st[u] >> 24) && (st[u] & 0xffffffu) >= settled_q)) continue;
+            bool hit = false;
+            for (int f = fdone; f < fnow; f++) hit = hit || ((sig[u] & f_sig[f]) && f_q[f] < q);
+            if (hit) todo |= 1u << u;
+        }
+        while (todo) {                                              // (one copy of the scoring code)
+            const int uu = __ffs((int)todo) - 1;
+            todo &= todo - 1u;
+            int j = jc[0];
+            unsigned sg = sig[0], cur = st[0];
+#pragma unroll
+            for (int u = 1; u < UC; u++) { j = u == uu ? jc[u] : j; sg = u == uu ? sig[u] : sg; cur = u == uu ? st[u] : cur; }
+            const int q = tid + uu * 1024;
+            Row<NR> R;
+            row_load(R, r, pos + j);
+            const double xn = s.xn[j];
+            for (int f = fdone; f < fnow; f++) {
+                if (!(sg & f_sig[f]) || f_q[f] >= q) continue;
+                Sup<NS> S;
+                sup_load(S, f_ri + f * FS_NP, f_rv + f * FS_NP, f_n[f]);
+                int first;
+                double dot = row_dot(R, r, pos + j, S, first);
+                dot /= f_nrm[f];                                    // :239 (a founded centre's norm is its row's)
+                dot /= xn;                                          // :240
+                if (!(dot < threshold)) {                           // (NaN joins: verified later)
+                    const unsigned sq = dot >= 1.9 || !(dot == dot) ? 0xffffffu : (dot > 0.0 ? (unsigned)(dot * 8388608.0) : 0u);
+                    // first maximum in ROW order of the founders: the founder of an earlier row wins ties
+                    const bool better = !(cur >> 24) || sq > (cur & 0xffffffu) ||
+                                        (sq == (cur & 0xffffffu) && f_q[f] < f_q[(cur >> 24) - 1]);
+                    if (better) cur = ((unsigned)(f + 1) << 24) | sq;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UC; u++) if (u == uu) st[u] = cur;
+        }
+        fdone = fnow;
+        if (sh_fcount >= FS_TF) {                                   // no room for further founders: the batch ends before the
+            int cutj = 0x7fffffff;                                  // first row that is still unsettled
+#pragma unroll
+            for (int u = 0; u < UC; u++) if (tid + u * 1024 < nnew && !st[u] && jc[u] < cutj) cutj = jc[u];
+            if (cutj != 0x7fffffff) atomicMin(&sh_cut, cutj);
+            __syncthreads();
+            break;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // tentative centres are numbered in row order; state slots, growth records, tf_row
+    int nf = sh_fcount;
+    if (nf > FS_TF) nf = FS_TF;
+    if (tid < nf) {
+        int rk = 0;
+        for (int g = 0; g < nf; g++) rk += f_q[g] < f_q[tid] ? 1 : 0;
+        f_rank[tid] = rk;
+    }
+    __syncthreads();
+    if (tid < nf) {
+        int lb = 0;
+        for (int g = 0; g < nf; g++) lb += f_rank[g] < f_rank[tid] ? f_n[g] : 0;
+        f_lbase[tid] = lb;
+    }
+    __syncthreads();
+    {
+        // a wave per founder: lane e writes entry e
+        for (int f = wave; f < nf; f += 16) {
+            const i64 kk = (i64)K + f_rank[f];
+            const int n = f_n[f], j = f_j[f];
+            if (lane < n) {
+                const i32 d = f_ri[f * FS_NP + lane];
+                s.cs_idx[kk * FS_CS + lane] = d; s.cs_val[kk * FS_CS + lane] = f_rv[f * FS_NP + lane];
+                i32 *lg = s.log + 3 * (f_lbase[f] + lane);
+                lg[0] = (i32)kk; lg[1] = d; lg[2] = j;
+            }
+            if (lane == 0) {
+                s.cs_n[kk] = n; s.c_cnt[kk] = r.weights ? r.weights[pos + j] : 1; s.c_nrm[kk] = f_nrm[f];
+                s.tf_row[f_rank[f]] = j;
+            }
+        }
+    }
+    // joiners: their decision, their bit in the founder's bitmap
+#pragma unroll
+    for (int u = 0; u < UC; u++) {
+        const unsigned fs1 = st[u] >> 24;
+        if (tid + u * 1024 >= nnew || fs1 == 0u || fs1 >= 0xfeu) continue;
+        const int j = jc[u];
+        const i64 kk = (i64)K + f_rank[fs1 - 1];
+        s.dec[j] = (i32)kk;
+        atomicOr((unsigned long long *)&s.bm0[kk * FS_W0 + (j >> 6)], 1ull << (j & 63));
+        atomicOr((unsigned long long *)&s.bm1[kk * FS_W1 + (j >> 12)], 1ull << ((j >> 6) & 63));
+    }
+    if (tid == 0) {
+        int ltot = 0;
+        for (int g = 0; g < nf; g++) ltot += f_n[g];
+        ctl->nfound = nf; ctl->log_n = ltot;
+        if (sh_cut != 0x7fffffff) atomicMin(&ctl->first_new, sh_cut);
+    }
 }
 
 // ---- the join lists: bitmaps --------------------------------------------------------------------------------
@@ -802,9 +1099,9 @@ __global__ __launch_bounds__(64) void k_fs_walk(FS s, FSRows r, int par)
     __shared__ WalkLds L;
     FSCtl *ctl = s.ctl + par;
     if (ctl->halt) return;
-    const int K = ctl->K, lane = threadIdx.x;
+    const int K = ctl->K + ctl->nfound, lane = threadIdx.x;       // the tentative centres of this step walk like any other
     int jlim = ctl->nb;
-    { const int fnw = ctl->first_new; if (fnw < jlim) jlim = fnw; }   // the batch ends before the first founding row
+    { const int fnw = ctl->first_new; if (fnw < jlim) jlim = fnw; }   // the batch ends before the first row left to the commit
     if (jlim <= 0) return;
     const i64 pos = ctl->pos;
     if (lane == 0) L.zero = 0.0;
@@ -839,7 +1136,7 @@ __device__ __forceinline__ Best fs_score_seen(const FS &s, const FSRows &r, cons
 
 template <int NR, int NS, int G>
 __device__ __forceinline__ void fs_verify(const FS &s, const FSRows &r, FSCtl *ctl, int jlast, int K, i64 pos,
-                                          double threshold, i32 *ovl)
+                                          double threshold, i32 *ovl, const i32 *lgp, int nlg)
 {
     const int gl = threadIdx.x & (G - 1);
     const int j = (int)(((i64)blockIdx.x * 256 + threadIdx.x) / G);
@@ -850,6 +1147,14 @@ __device__ __forceinline__ void fs_verify(const FS &s, const FSRows &r, FSCtl *c
     const int n = R.n;
     const double xn = s.xn[j];
     int m = s.ov_n[j];
+    // the centres that exist when row j is decided: K and the tentative ones founded by earlier rows of the batch (they
+    // reach the candidates through their growth records)
+    {
+        const int nf = ctl->nfound;
+        int before = 0;
+        for (int t0 = 0; t0 < nf; t0 += G) before += __popcll(gballot<G>(t0 + gl < nf && s.tf_row[t0 + gl] < j));
+        K += before;
+    }
     int vdec;
     if (n == 0) vdec = K == 0 ? FS_NEW : FS_BREAK;
     else if (m > FS_OC) vdec = FS_BREAK;
@@ -861,13 +1166,12 @@ __device__ __forceinline__ void fs_verify(const FS &s, const FSRows &r, FSCtl *c
             best = best_merge(best, fs_score_seen<NR, NS>(s, r, R, row, j, cc, xn));
         }
         __builtin_amdgcn_wave_barrier();
-        // centres that gained one of my dimensions earlier in this batch overlap me now without being listed
-        int nlg = ctl->log_n;
-        if (nlg > FS_LOG) nlg = FS_LOG;
+        // centres that gained one of my dimensions earlier in this batch (support growth, foundings) overlap me now
+        // without being listed
         bool over = false;
         for (int q = 0; q < nlg; q++) {
-            if (s.log[3 * q + 2] >= j) continue;
-            const i32 kk = s.log[3 * q], dd = s.log[3 * q + 1];
+            if (lgp[3 * q + 2] >= j) continue;
+            const i32 kk = lgp[3 * q], dd = lgp[3 * q + 1];
             if (!row_has(R, r, row, dd)) continue;
             bool listed = false;
             for (int p = gl; p < m; p += G) listed = listed || ovl[p] == kk;
@@ -894,14 +1198,23 @@ template <int NR, int NS>
 __global__ __launch_bounds__(256) void k_fs_verify(FS s, FSRows r, int par, double threshold)
 {
     __shared__ i32 ovl[16 * FS_OC];
+    __shared__ i32 lg[3 * FS_LGS];                               // the growth records, staged: every row of the block scans them
     FSCtl *ctl = s.ctl + par;
     if (ctl->halt) return;
     const int nb = ctl->nb, K = ctl->K;
     if (nb <= 0) return;
-    int jlast = nb - 1;                                          // the first founding row is re-decided too
+    int jlast = nb - 1;                                          // the row the batch ends before is re-decided too
     { const int fnw = ctl->first_new; if (fnw < jlast) jlast = fnw; }
-    if (nb <= 16384) fs_verify<NR, NS, 64>(s, r, ctl, jlast, K, ctl->pos, threshold, ovl + (threadIdx.x >> 6) * FS_OC);
-    else fs_verify<NR, NS, 16>(s, r, ctl, jlast, K, ctl->pos, threshold, ovl + (threadIdx.x >> 4) * FS_OC);
+    int nlg = ctl->log_n;
+    if (nlg > FS_LOG) nlg = FS_LOG;
+    const i32 *lgp = s.log;
+    if (nlg <= FS_LGS) {
+        for (int q = threadIdx.x; q < 3 * nlg; q += 256) lg[q] = s.log[q];
+        __syncthreads();
+        lgp = lg;
+    }
+    if (nb <= 16384) fs_verify<NR, NS, 64>(s, r, ctl, jlast, K, ctl->pos, threshold, ovl + (threadIdx.x >> 6) * FS_OC, lgp, nlg);
+    else fs_verify<NR, NS, 16>(s, r, ctl, jlast, K, ctl->pos, threshold, ovl + (threadIdx.x >> 4) * FS_OC, lgp, nlg);
 }
 
 // ---- D: commit -----------------------------------------------------------------------------------------
@@ -1018,13 +1331,14 @@ __global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, doubl
         if (blockIdx.x == 0 && lane < 32) ((i32 *)nxt)[lane] = ((const i32 *)ctl)[lane];
         return;
     }
-    const int nb = ctl->nb, K = ctl->K;
+    const int nb = ctl->nb, K = ctl->K, nf = ctl->nfound;
     int cut = nb;
     { const int a = ctl->first_new, b = ctl->first_bad; if (a < cut) cut = a; if (b < cut) cut = b; }
     const int single = cut < nb ? s.vdec[cut] : FS_BREAK - 1;    // verified decision of the row at the cut
     if (blockIdx.x > 0) {
-        // centre k takes the version left by its last join before the cut
-        for (int k = blockIdx.x - 1; k < K; k += gridDim.x - 1) {
+        // centre k takes the version left by its last join before the cut (a tentative centre founded at or beyond the
+        // cut has no such join: only its bitmap is cleared)
+        for (int k = blockIdx.x - 1; k < K + nf; k += gridDim.x - 1) {
             if (k == single) continue;
             const u64 l1 = lane < FS_W1 ? s.bm1[(i64)k * FS_W1 + lane] : 0ull;
             if (!__ballot(l1 != 0)) continue;
@@ -1036,7 +1350,9 @@ __global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, doubl
     }
     // ---- the wave that ends the step ----
     const i64 pos = ctl->pos;
-    int Kn = K;
+    // the tentative centres founded before the cut are real now (their dimensions reach the per-dimension lists with
+    // the growth records below)
+    int Kn = K + __popcll(__ballot(lane < nf && s.tf_row[lane < nf ? lane : 0] < cut));
     // support growth of the committed joins becomes visible in the per-dimension lists
     if (lane == 0) {
         int nlg = ctl->log_n;
@@ -1098,10 +1414,12 @@ __global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, doubl
         else if (Kn + 64 > s.Kcap) halt = 2;
         if (s.trace && ctl->trace_n < FS_TRACE_CAP) {
             i64 *t = s.trace + 6 * ctl->trace_n;
-            t[0] = pos; t[1] = nb; t[2] = ctl->first_new < nb ? ctl->first_new : -1; t[3] = ctl->first_bad < nb ? ctl->first_bad : -1;
-            t[4] = ctl->log_n; t[5] = K;
+            t[0] = pos; t[1] = nb; t[2] = ctl->first_new < nb ? ctl->first_new : -1; t[3] = (i64)(unsigned)(ctl->first_bad < nb ? ctl->first_bad : -1) | ((i64)ctl->any_new << 32);
+            const int fb = ctl->first_bad < nb ? ctl->first_bad : -1;
+            t[4] = (i64)ctl->log_n | ((i64)nf << 32);
+            t[5] = (i64)K | ((i64)((fb >= 0 ? s.dec[fb] : 0) & 0xffffff) << 24) | ((i64)((fb >= 0 ? s.vdec[fb] : 0) & 0xffffff) << 48);
         }
-        nxt->first_new = 0x7fffffff; nxt->first_bad = 0x7fffffff; nxt->log_n = 0; nxt->flags = flags;
+        nxt->first_new = 0x7fffffff; nxt->first_bad = 0x7fffffff; nxt->log_n = 0; nxt->flags = flags; nxt->nfound = 0; nxt->any_new = 0;
         nxt->why = ctl->why; nxt->K = Kn; nxt->nb = halt ? 0 : (int)(left < B ? left : B); nxt->B = B;
         nxt->pos = pos2; nxt->nrows = ctl->nrows; nxt->halt = halt;
         nxt->steps = ctl->steps + 1; nxt->bad_steps = ctl->bad_steps + (cut < nb && single != FS_NEW ? 1 : 0);
@@ -1163,7 +1481,7 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     if (f->blob) { sit_dfree(c, f->blob); f->blob = nullptr; }
     const i64 D = c->D;
     const size_t total = (size_t)Kcap * (4 + FS_CS * 12 + 16 + FS_W0 * 8 + FS_W1 * 8) + (size_t)D * (4 + FS_DC * 4)
-                       + (size_t)FS_BMAX * (4 + 4 + 4 + FS_OC * 4 + 8 + FS_CS * 16) + (size_t)FS_LOG * 12 + 65536;
+                       + (size_t)FS_BMAX * (4 + 4 + 4 + FS_OC * 4 + 8 + FS_CS * 16) + (size_t)FS_LOG * 12 + (size_t)FS_W0 * 8 + (size_t)FS_BMAX * 12 + 65536;
     HIP_TRY(c, sit_dmalloc(c, &f->blob, total));
     if (!f->h_ctl) HIP_TRY(c, hipHostMalloc((void **)&f->h_ctl, sizeof(FSCtl)));
     HIP_TRY(c, hipMemsetAsync(f->blob, 0, total, c->stream));
@@ -1185,6 +1503,10 @@ static int ff_alloc(sit_ctx *c, FitFast *f, i64 Kcap)
     s.xn = (double *)carve(p, (size_t)FS_BMAX * 8);
     s.vs_ent = (VsEnt *)carve(p, (size_t)FS_BMAX * FS_CS * sizeof(VsEnt));
     s.log = (i32 *)carve(p, (size_t)FS_LOG * 12);
+    s.nbm = (u64 *)carve(p, (size_t)FS_W0 * 8);
+    s.tf_row = (i32 *)carve(p, (size_t)FS_TF * 4);
+    s.nw_t = (i32 *)carve(p, (size_t)FS_BMAX * 4);
+    s.nw_v = (double *)carve(p, (size_t)FS_BMAX * 8);
     s.ctl = (FSCtl *)carve(p, 2 * sizeof(FSCtl));
     s.D = D; s.Kcap = Kcap;
     s.trace = nullptr;
@@ -1316,6 +1638,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
     for (;;) {
         FS s = f->st;
         s.trace = tp ? f->d_trace : nullptr;
+        { const char *nc = getenv("SITATOR_FF_NEWCAP"); s.newcap = nc ? atoi(nc) : 0; }
         FSCtl z;
         memset(&z, 0, sizeof(z));
         z.first_new = z.first_bad = 0x7fffffff;
@@ -1332,7 +1655,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
             for (int i = 0; i < chunk; i++) {
                 const i64 nbmax = bb > FS_BMAX ? FS_BMAX : bb;
                 const i64 lanes = nbmax <= 16384 ? nbmax * 64 : (i64)FS_BMAX * 16;
-                const unsigned grows = (unsigned)((lanes + 255) / 256), gk = (unsigned)(st.K + 64);
+                const unsigned grows = (unsigned)((lanes + 255) / 256), gk = (unsigned)(st.K + 640);     // (the centre count may have grown by FS_TF + 1 per step since it was read)
 #define FS_LAUNCH(name, kern, grid, block, ...)                                                         \
     do {                                                                                                \
         kern<<<dim3(grid), dim3(block), 0, c->stream>>>(__VA_ARGS__);                                    \
@@ -1340,11 +1663,13 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
     } while (0)
                 if (wide) {
                     FS_LAUNCH("speculate", (k_fs_speculate<8, 16>), grows, 256, s, rb, par, threshold);
+                    FS_LAUNCH("found", (k_fs_found<8, 16>), 1, 1024, s, rb, par, threshold);
                     FS_LAUNCH("walk", k_fs_walk, gk, 64, s, rb, par);
                     FS_LAUNCH("verify", (k_fs_verify<8, 16>), grows, 256, s, rb, par, threshold);
                     FS_LAUNCH("commit", (k_fs_commit<8, 16>), gk + 1, 64, s, rb, par, threshold);
                 } else {
                     FS_LAUNCH("speculate", (k_fs_speculate<4, 8>), grows, 256, s, rb, par, threshold);
+                    FS_LAUNCH("found", (k_fs_found<4, 8>), 1, 1024, s, rb, par, threshold);
                     FS_LAUNCH("walk", k_fs_walk, gk, 64, s, rb, par);
                     FS_LAUNCH("verify", (k_fs_verify<4, 8>), grows, 256, s, rb, par, threshold);
                     FS_LAUNCH("commit", (k_fs_commit<4, 8>), gk + 1, 64, s, rb, par, threshold);
