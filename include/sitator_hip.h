@@ -279,10 +279,11 @@ int sit_recenter_resident(sit_ctx *ctx, const double *masses, const double *fact
 /* ---- frame sharding across GPUs ------------------------------------ */
 
 /* The reference has no communication layer (it is single-process); these are the exchange steps a frame-sharded
- * run() adds between one process per GPU: RCCL collectives over xGMI on the context's device and stream.  Buffers
- * are HOST buffers (the payloads are small per-rank statistics: first-offender keys, counts, the D x D Gram matrix
- * of landmark/cluster/mcl.py:55, the site-centre sums of util/PBCCalculator.pyx:127-134); staging is internal.
- * librccl.so is loaded on the first call.                                                               */
+ * run() adds between one process per GPU: RCCL collectives over xGMI on the context's device and stream.  The buffers
+ * of sit_comm_allreduce / _allgather / _broadcast are HOST buffers (small per-rank statistics: first-offender keys,
+ * counts, site-centre sums; payloads of up to 512 bytes go through the context's pinned block); the large statistics of
+ * the mcl plugin - the D x D Gram matrix of landmark/cluster/mcl.py:55, the weighted row sums of :114-122 - never leave
+ * the device: see sit_comm_attach.  librccl.so is loaded on the first call.                               */
 int sit_comm_unique_id(uint8_t *id128);                 /* ncclGetUniqueId: rank 0 makes it, every rank gets it */
 int sit_comm_create(sit_ctx *ctx, const uint8_t *id128, int rank, int world);
 int sit_comm_destroy(sit_ctx *ctx);

@@ -546,9 +546,13 @@ class HipContext(object):
         lout = np.empty(self.M, dtype=np.int64); tout = np.empty(self.M, dtype=np.int64)
         lin = None if last_known_in is None else _i64(last_known_in)
         tin = None if time_at_current_in is None else _i64(time_at_current_in)
-        self._check(self.lib.sit_jump_analysis(self._h, int(K), None if lin is None else _i(lin),
-                                               None if tin is None else _i(tin), _d(n_ij), _d(tsum), _i(tn), _i(total),
-                                               C.byref(nprob), _i(lout), _i(tout)))
+        rc = self.lib.sit_jump_analysis(self._h, int(K), None if lin is None else _i(lin),
+                                        None if tin is None else _i(tin), _d(n_ij), _d(tsum), _i(tn), _i(total),
+                                        C.byref(nprob), _i(lout), _i(tout))
+        if rc == E_INVALID and self.message().startswith("index "):
+            # a label beyond the site tables: the reference's fancy indexing raises this (dynamics/JumpAnalysis.py:75-88)
+            raise IndexError(self.message())
+        self._check(rc)
         return n_ij, tsum, tn, total, nprob.value, lout, tout
 
     def assign_last_known(self, frame_threshold, last_known_in=None, time_unknown_in=None, out=None):

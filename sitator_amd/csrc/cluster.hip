@@ -881,13 +881,20 @@ extern "C" int sit_fit_push_dense_rows(sit_ctx *c, const double *rows, const i64
 // accumulated (a row's entries ascend in landmark id, so e2 >= e1 is d2 >= d1; v1 * v2 == v2 * v1 bit for bit) and
 // k_gram_mirror copies it below the diagonal: half the integer atomics.
 // `seen` (how many rows hold a landmark) is counted per workgroup in LDS when D fits (LSEEN), else with global atomics
+// `copies` > 1: workgroup b adds into copy b % copies of the accumulators (copy q at Ghi + q * stride, Glo likewise); the
+// copies are summed by k_gram_fold.  Integer sums: the same bits for any number of copies.
 template <bool LSEEN>
-__global__ __launch_bounds__(256) void k_gram(const i32 *nnz, const i32 *idx, const double *val, i64 N, i64 D, u64 *Ghi, u64 *Glo, u64 *seen)
+__global__ __launch_bounds__(256) void k_gram(const i32 *nnz, const i32 *idx, const double *val, i64 N, i64 D, u64 *Ghi, u64 *Glo, u64 *seen,
+                                              int copies, i64 stride)
 {
     extern __shared__ __attribute__((aligned(16))) char kg_smem[];
-    unsigned *sseen = (unsigned *)kg_smem;
+    // LSEEN: per workgroup in LDS, flushed once - the hit counts, and the DIAGONAL of the Gram matrix (a quarter of a
+    // row's terms, and the hottest addresses: every row that holds a landmark adds to its square)
+    u64 *sdh = (u64 *)kg_smem, *sdl = sdh + D;
+    unsigned *sseen = (unsigned *)(sdl + D);
+    if (copies > 1) { const i64 off = (i64)(blockIdx.x % (unsigned)copies) * stride; Ghi += off; Glo += off; }
     if (LSEEN) {
-        for (i64 q = threadIdx.x; q < D; q += 256) sseen[q] = 0u;
+        for (i64 q = threadIdx.x; q < D; q += 256) { sseen[q] = 0u; sdh[q] = 0ull; sdl[q] = 0ull; }
         __syncthreads();
     }
     const i64 row = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -896,8 +903,9 @@ __global__ __launch_bounds__(256) void k_gram(const i32 *nnz, const i32 *idx, co
         for (int e1 = 0; e1 < n; e1++) {
             const i32 d1 = idx[(i64)e1 * N + row];
             const double v1 = val[(i64)e1 * N + row];
-            if (LSEEN) atomicAdd(&sseen[d1], 1u); else atomicAdd(&seen[d1], 1ull);
-            for (int e2 = e1; e2 < n; e2++) {
+            if (LSEEN) { atomicAdd(&sseen[d1], 1u); exact_add(&sdh[d1], &sdl[d1], v1 * v1); }
+            else atomicAdd(&seen[d1], 1ull);
+            for (int e2 = LSEEN ? e1 + 1 : e1; e2 < n; e2++) {
                 const i64 q = (i64)d1 * D + idx[(i64)e2 * N + row];
                 exact_add(&Ghi[q], &Glo[q], v1 * val[(i64)e2 * N + row]);
             }
@@ -905,8 +913,32 @@ __global__ __launch_bounds__(256) void k_gram(const i32 *nnz, const i32 *idx, co
     }
     if (LSEEN) {
         __syncthreads();
-        for (i64 q = threadIdx.x; q < D; q += 256) { const unsigned v = sseen[q]; if (v) atomicAdd(&seen[q], (u64)v); }
+        for (i64 q = threadIdx.x; q < D; q += 256) {
+            const unsigned v = sseen[q];
+            if (v) atomicAdd(&seen[q], (u64)v);
+            const u64 h = sdh[q], l = sdl[q];
+            if (h | l) {                                              // 128-bit integer add into the shared accumulator
+                u64 carry = 0ull;
+                if (l) { const u64 old = atomicAdd(&Glo[q * D + q], l); carry = (old + l) < old ? 1ull : 0ull; }
+                if (h + carry) atomicAdd(&Ghi[q * D + q], h + carry);
+            }
+        }
     }
+}
+
+// copy 0 += copies 1 .. copies - 1 (128-bit integer sums, carries from the low word)
+__global__ void k_gram_fold(u64 *hi, u64 *lo, i64 n, int copies, i64 stride)
+{
+    const i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    u64 h = hi[q], l = lo[q];
+    for (int k = 1; k < copies; k++) {
+        const u64 l2 = lo[k * stride + q];
+        const u64 s = l + l2;
+        h += hi[k * stride + q] + (s < l ? 1ull : 0ull);
+        l = s;
+    }
+    hi[q] = h; lo[q] = l;
 }
 
 __global__ void k_gram_mirror(u64 *hi, u64 *lo, i64 D)
@@ -929,18 +961,26 @@ static int gram_impl(sit_ctx *c, double *G, u64 *hi, u64 *lo, i64 *seen)
     SIT_REQUIRE(c, c->rows_valid, "sit_gram: no landmark rows on the device");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 D = c->D, DD = D * D;
-    int rc = ensure_scratch(c, DD * 24 + D * 8 + (c->comm_peer ? DD * 24 : 0));
+    // The adds of a pair of landmarks are served one after the other wherever its accumulator lives, and a landmark's
+    // neighbours are few: the rows of a long trajectory hammer a few thousand addresses.  Workgroups therefore add into
+    // one of `copies` sets of accumulators, summed afterwards (integers: the same bits).  SITATOR_GRAM_COPIES overrides.
+    static const int copies_env = [] { const char *v = getenv("SITATOR_GRAM_COPIES"); const int n = v ? atoi(v) : 0; return n >= 1 && n <= 64 ? n : 0; }();
+    int copies = copies_env ? copies_env : 8;
+    while (copies > 1 && (copies * DD * 16 > (2LL << 30) || c->N < 4096 * copies)) copies >>= 1;   // small inputs, very large D: fewer
+    const i64 acc = DD * 16 * copies;                                 // [hi copies][lo copies]
+    int rc = ensure_scratch(c, acc + D * 8 + DD * 8 + (c->comm_peer ? DD * 24 : 0));
     if (rc) return rc;
-    u64 *dhi = (u64 *)c->d_scratch, *dlo = dhi + DD, *ds = dlo + DD;
+    u64 *dhi = (u64 *)c->d_scratch, *dlo = dhi + DD * copies, *ds = dlo + DD * copies;
     double *dG = (double *)(ds + D);
     u64 *work = (u64 *)(dG + DD);
-    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(DD * 16 + D * 8), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(acc + D * 8), c->stream));
     StageTimer t(c, T_GRAM);
     if (c->N > 0) {
-        if (D * 4 <= 48 * 1024)
-            k_gram<true><<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), (size_t)D * 4, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dhi, dlo, ds);
+        if (D * 20 <= 60 * 1024)
+            k_gram<true><<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), (size_t)D * 20, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dhi, dlo, ds, copies, DD);
         else
-            k_gram<false><<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dhi, dlo, ds);
+            k_gram<false><<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dhi, dlo, ds, copies, DD);
+        if (copies > 1) k_gram_fold<<<dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, c->stream>>>(dhi, dlo, DD, copies, DD);
         k_gram_mirror<<<dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, c->stream>>>(dhi, dlo, D);
         HIP_TRY(c, hipGetLastError());
     }

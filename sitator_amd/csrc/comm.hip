@@ -7,6 +7,9 @@
 
 #include <rccl/rccl.h>
 
+#include <mutex>
+#include <vector>
+
 #include "sit_internal.h"
 
 namespace {
@@ -94,9 +97,27 @@ extern "C" int sit_comm_create(sit_ctx *c, const uint8_t *id128, int rank, int w
     return SIT_OK;
 }
 
+// contexts whose statistics another context's communicator reduces (sit_comm_attach): when either side goes away the
+// link goes with it - a context must never be left pointing at a destroyed communicator
+static std::mutex g_attach_mu;
+static std::vector<sit_ctx *> g_attached;
+
+static void attach_forget(sit_ctx *gone)
+{
+    std::lock_guard<std::mutex> lock(g_attach_mu);
+    for (size_t i = 0; i < g_attached.size();) {
+        sit_ctx *a = g_attached[i];
+        if (a == gone) { g_attached.erase(g_attached.begin() + (long)i); continue; }
+        if (a->comm_peer == gone) { a->comm_peer = nullptr; g_attached.erase(g_attached.begin() + (long)i); continue; }
+        i++;
+    }
+}
+
 extern "C" int sit_comm_destroy(sit_ctx *c)
 {
     if (!c) return SIT_ERR_INVALID;
+    attach_forget(c);                                           // (also called by sit_destroy for every context)
+    c->comm_peer = nullptr;
     if (!c->comm) return SIT_OK;
     RcclApi *api = rccl();
     (void)hipSetDevice(c->device);
@@ -105,6 +126,8 @@ extern "C" int sit_comm_destroy(sit_ctx *c)
     c->comm = nullptr; c->comm_size = 1; c->comm_rank = 0;
     return SIT_OK;
 }
+
+#define SMALL_PINNED ((size_t)512)      // the first half of sit_ctx::h_pinned (the second holds deferred fill results)
 
 // dtype: 0 = float64, 1 = int64, 2 = uint64; op: 0 = sum, 1 = min, 2 = max.  In place on a host buffer.
 extern "C" int sit_comm_allreduce(sit_ctx *c, void *buf, int64_t count, int dtype, int op)
@@ -119,10 +142,16 @@ extern "C" int sit_comm_allreduce(sit_ctx *c, void *buf, int64_t count, int dtyp
     if ((rc = ensure_scratch(c, count * 8))) return rc;
     const ncclDataType_t dt = dtype == 0 ? ncclFloat64 : (dtype == 1 ? ncclInt64 : ncclUint64);
     const ncclRedOp_t ro = op == 0 ? ncclSum : (op == 1 ? ncclMin : ncclMax);
-    HIP_TRY(c, hipMemcpyAsync(c->d_scratch, buf, (size_t)count * 8, hipMemcpyHostToDevice, c->stream));
+    // small payloads (keys, counts, the barrier's word) travel through the context's pinned block: copies to and from
+    // pageable memory are staged by the runtime, each with a synchronisation of its own
+    const size_t nbytes = (size_t)count * 8;
+    void *h = nbytes <= SMALL_PINNED ? c->h_pinned : buf;
+    if (h != buf) memcpy(h, buf, nbytes);
+    HIP_TRY(c, hipMemcpyAsync(c->d_scratch, h, nbytes, hipMemcpyHostToDevice, c->stream));
     RCCL_TRY(c, api, api->AllReduce(c->d_scratch, c->d_scratch, (size_t)count, dt, ro, (ncclComm_t)c->comm, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(buf, c->d_scratch, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_scratch, nbytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h != buf) memcpy(buf, h, nbytes);
     return SIT_OK;
 }
 
@@ -138,10 +167,15 @@ extern "C" int sit_comm_allgather(sit_ctx *c, const void *send, void *recv, int6
     const i64 total = nbytes * (c->comm_size + 1);
     if ((rc = ensure_scratch(c, total))) return rc;
     char *d_send = (char *)c->d_scratch, *d_recv = d_send + nbytes;
-    HIP_TRY(c, hipMemcpyAsync(d_send, send, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    const size_t nall = (size_t)(nbytes * c->comm_size);
+    const bool small = nall + (size_t)nbytes <= SMALL_PINNED;
+    char *hs = small ? (char *)c->h_pinned : (char *)send, *hr = small ? (char *)c->h_pinned + nbytes : (char *)recv;
+    if (small) memcpy(hs, send, (size_t)nbytes);
+    HIP_TRY(c, hipMemcpyAsync(d_send, hs, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
     RCCL_TRY(c, api, api->AllGather(d_send, d_recv, (size_t)nbytes, ncclUint8, (ncclComm_t)c->comm, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(recv, d_recv, (size_t)(nbytes * c->comm_size), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hr, d_recv, nall, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (small) memcpy(recv, hr, nall);
     return SIT_OK;
 }
 
@@ -155,10 +189,15 @@ extern "C" int sit_comm_broadcast(sit_ctx *c, void *buf, int64_t nbytes, int roo
     if (nbytes <= 0) return SIT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     if ((rc = ensure_scratch(c, nbytes))) return rc;
-    if (c->comm_rank == root) HIP_TRY(c, hipMemcpyAsync(c->d_scratch, buf, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    void *h = (size_t)nbytes <= SMALL_PINNED ? c->h_pinned : buf;
+    if (c->comm_rank == root) {
+        if (h != buf) memcpy(h, buf, (size_t)nbytes);
+        HIP_TRY(c, hipMemcpyAsync(c->d_scratch, h, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    }
     RCCL_TRY(c, api, api->Broadcast(c->d_scratch, c->d_scratch, (size_t)nbytes, ncclUint8, root, (ncclComm_t)c->comm, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(buf, c->d_scratch, (size_t)nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_scratch, (size_t)nbytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (h != buf) memcpy(buf, h, (size_t)nbytes);
     return SIT_OK;
 }
 
@@ -176,7 +215,9 @@ extern "C" int sit_comm_attach(sit_ctx *c, sit_ctx *comm_ctx)
         SIT_REQUIRE(c, comm_ctx->comm != nullptr, "sit_comm_attach: the other context has no communicator");
         SIT_REQUIRE(c, comm_ctx->device == c->device, "sit_comm_attach: both contexts must be on one device");
     }
+    attach_forget(c);
     c->comm_peer = comm_ctx;
+    if (comm_ctx) { std::lock_guard<std::mutex> lock(g_attach_mu); g_attached.push_back(c); }
     return SIT_OK;
 }
 

@@ -6,6 +6,8 @@
 #include <cmath>
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include <cstdio>
+
 #include "sit_internal.h"
 
 // ---- JumpAnalysis --------------------------------------------------------------------------------------
@@ -92,14 +94,17 @@ __global__ __launch_bounds__(64) void k_ja_chunk_replay(const i64 *labels, i64 F
 
 // Pass 2 (frames in parallel): numpy's fancy-index "+=" semantics of :72-86 -- within ONE frame duplicate
 // indices count once, and for the summed jump times the LAST duplicate's value is the one added.
+// A site index beyond the K x K tables (labels a caller built or edited: the reference's fancy indexing raises there,
+// dynamics/JumpAnalysis.py:75-88) is not applied; the largest such index + 1 goes to *oob and the call fails with it.
 __global__ __launch_bounds__(256) void k_ja_accumulate(const i32 *jfrom, const i32 *jto, const i32 *jtime, i64 F, i64 M, i64 K,
-                                                       double *n_ij, double *tsum, u64 *tn, u64 *total_time)
+                                                       double *n_ij, double *tsum, u64 *tn, u64 *total_time, u64 *oob)
 {
     const i64 f = blockIdx.x;
     const i32 *pf = jfrom + f * M, *pt = jto + f * M, *pm = jtime + f * M;
     for (i64 j = threadIdx.x; j < M; j += blockDim.x) {
         const i32 to = pt[j], from = pf[j];
         if (to < 0) continue;
+        if (to >= K || from >= K) { atomicMax(oob, (u64)(to > from ? to : from) + 1ull); continue; }
         bool first_to = true, first_pair = true, last_jump_pair = pm[j] > 0;
         for (i64 q = 0; q < j; q++) {
             if (pt[q] == to) { first_to = false; if (pf[q] == from) { first_pair = false; break; } }
@@ -162,16 +167,24 @@ extern "C" int sit_jump_analysis(sit_ctx *c, i64 K, const i64 *last_known_in, co
         c->d_labels, F, M, nch, last_known_in ? d_lin : nullptr, last_known_in ? d_tin : nullptr, d_fk, d_lk, d_fp, d_jp,
         d_cl, d_ct, d_lout, d_tout);
     if (nch > 0) k_ja_chunk_replay<<<cgrid, dim3(64), 0, c->stream>>>(c->d_labels, F, M, d_cl, d_ct, d_from, d_to, d_time, d_np);
-    if (F > 0) k_ja_accumulate<<<dim3((unsigned)F), dim3(256), 0, c->stream>>>(d_from, d_to, d_time, F, M, K, d_nij, d_ts, d_tn, d_tt);
+    if (F > 0) k_ja_accumulate<<<dim3((unsigned)F), dim3(256), 0, c->stream>>>(d_from, d_to, d_time, F, M, K, d_nij, d_ts, d_tn, d_tt, d_np + 1);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(n_ij, d_nij, (size_t)(K * K) * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(time_sum, d_ts, (size_t)(K * K) * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(time_n, d_tn, (size_t)(K * K) * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(total_time, d_tt, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(n_problems, d_np, 8, hipMemcpyDeviceToHost, c->stream));
+    u64 *h_np = (u64 *)c->h_pinned;                             // [0] problems, [1] largest out-of-range site index + 1
+    HIP_TRY(c, hipMemcpyAsync(h_np, d_np, 16, hipMemcpyDeviceToHost, c->stream));
     if (last_known_out) HIP_TRY(c, hipMemcpyAsync(last_known_out, d_lout, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
     if (time_at_current_out) HIP_TRY(c, hipMemcpyAsync(time_at_current_out, d_tout, (size_t)M * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_problems = (i64)h_np[0];
+    if (h_np[1]) {
+        char text[128];
+        snprintf(text, sizeof(text), "index %lld is out of bounds for axis 0 with size %lld", (long long)h_np[1] - 1, (long long)K);
+        c->msg = text;
+        return SIT_ERR_INVALID;
+    }
     return SIT_OK;
 }
 

@@ -388,13 +388,14 @@ int sit_label_counts(sit_ctx *c, bool zero)
 // caller's label array in the scratch buffer when that is where the labels are)
 int label_counts_of(sit_ctx *c, const i64 *d_labels, i64 N, i64 K, i64 *counts_host)
 {
+    // the histogram lives in the recycled small-buffer pool (a raw hipFree is a device-wide synchronisation)
     u64 *d_cnt = nullptr;
-    HIP_TRY(c, hipMalloc((void **)&d_cnt, (size_t)K * 8));
+    HIP_TRY(c, sit_dmalloc(c, (void **)&d_cnt, (size_t)K * 8));
     hipError_t e = hipMemsetAsync(d_cnt, 0, (size_t)K * 8, c->stream);
     if (e == hipSuccess && launch_label_hist(c, d_labels, N, K, d_cnt) != SIT_OK) e = hipErrorUnknown;
     if (e == hipSuccess) e = hipMemcpyAsync(counts_host, d_cnt, (size_t)K * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d_cnt);
+    sit_dfree(c, d_cnt);
     HIP_TRY(c, e);
     return SIT_OK;
 }
@@ -689,7 +690,7 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
 // slots, each slot leaves by DMA on `stream` as soon as it is staged and is reused once its DMA has finished.  (A plain
 // hipMemcpyAsync of pageable memory is as fast, 55 GB/s, but it blocks the runtime for other threads' launches while it
 // runs: this one only enqueues.)  Returns when the whole range has arrived.
-#define RING_SLOTS 16         // (eight until the fit stopped being the longer leg: four staging threads then capped the upload at 40 GB/s)
+#define RING_SLOTS 8
 #define RING_CHUNK ((size_t)4 << 20)
 static std::mutex g_ring_mutex;
 static char *g_ring = nullptr;
@@ -839,7 +840,8 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
     if (!(c->d_row_nnz && c->rows_N == N && c->rows_W > 0 && c->rows_W <= c->W) && !c->rows_overflowed) {
         // the row width is measured on the leading frames (measured_row_width): they go up ahead of the pipeline
         i64 Fs = (1 << 16) / M;
-        Fs = Fs < 16 ? 16 : (Fs > F ? F : Fs);
+        Fs = Fs < 16 ? 16 : Fs;
+        if (Fs > F) Fs = F;                                   // (as measured_row_width: never past the caller's frames)
         HIP_TRY(c, hipMemcpyAsync(c->d_frames, frames, (size_t)(Fs * A * 24), hipMemcpyHostToDevice, c->stream));
         F_head = Fs;
         if ((rc = fill3_prepare(c))) return rc;

@@ -1157,8 +1157,10 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
             const int min_rcap = 64 / vp > 32 ? 64 / vp : 32;
             const int NC = 5;
             const int cand[NC][2] = {{rcap, tt}, {rcap, want}, {64, want}, {min_rcap, want}, {min_rcap, want > 256 ? 256 : want}};
-            hipEvent_t e0, e1;
-            HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
+            // (destroyed on every way out of this block)
+            struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev0, ev1;
+            HIP_TRY(c, hipEventCreate(&ev0.e)); HIP_TRY(c, hipEventCreate(&ev1.e));
+            const hipEvent_t e0 = ev0.e, e1 = ev1.e;
             // the trial launches write the rows of the leading frames (the launch proper writes them again) but report
             // into words of their own: errors and counts of earlier launches of a pipelined call stay untouched
             Fill3Head ht = h;
@@ -1190,7 +1192,6 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
                 if (tq < best * (q == 0 ? 1.0f : 0.96f)) { best = tq; br = cand[q][0]; bt = cand[q][1]; }   // the default wins ties (a 60 us trial has jitter)
             }
             tt = keep_tt;
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
             rcap = br; tt = bt;
             F3Tuned t; memcpy(t.key, key, sizeof(key)); t.rcap = rcap; t.tt = tt;
             { std::lock_guard<std::mutex> lock(g_f3_mutex); g_f3_tuned.push_back(t); }

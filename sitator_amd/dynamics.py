@@ -36,13 +36,9 @@ class JumpAnalysis(object):
         logger.info("Running JumpAnalysis...")
         sn = st.site_network
         n_sites = sn.n_sites
-        # labels that came from the assignment kernel and never left the object are below n_sites by construction; any
-        # other array - built by the caller, or one the caller has had in hand - is looked at (5 ms per 50 MB): the
-        # kernels index K x K tables with them
-        trusted = getattr(st, "_labels_from_kernel", False) and not st._host_shared
-        if not trusted and st._traj.size and int(st._traj.max()) >= n_sites:
-            # the reference's fancy indexing raises here (JumpAnalysis.py:75-88); the kernels index K x K tables
-            raise IndexError("index %i is out of bounds for axis 0 with size %i" % (int(st._traj.max()), n_sites))
+        # a label beyond n_sites (only an array the caller built or edited can hold one) is caught where the labels are
+        # read anyway: the accumulation kernel checks what it indexes its K x K tables with and the call raises the
+        # reference's IndexError (dynamics/JumpAnalysis.py:75-88) - no pass of the host over the 50-MB label array
         ctx = st._device()
         comm = st._comm
         n_frames = st.n_frames

@@ -1,7 +1,8 @@
 """Minimal ``SiteNetwork`` data contract consumed and produced by ``LandmarkAnalysis.run``
-(reference: ``sitator/SiteNetwork.py:48-125,167-223``).  Only what the landmark path touches:
-structure/masks/counts, ``static_structure``, ``centers``, ``vertices``, ``site_types``, the named per-site /
-per-edge arrays the next-tier operators attach, ``copy()``.  Plotting is out of scope.
+(reference: ``sitator/SiteNetwork.py:48-141,167-223,311-346``).  What the landmark path and a script handling its result
+touch: structure/masks/counts, ``static_structure``, ``centers`` (+ ``update_centers``), ``vertices``, ``site_types``, the
+named per-site / per-edge arrays the next-tier operators attach, subsets (``sn[key]``, ``of_type``), ``get_site`` /
+``get_edge``, ``copy()``.  Plotting is out of scope.
 """
 import re
 
@@ -186,6 +187,62 @@ class SiteNetwork(object):
     @property
     def site_ids(self):
         return np.arange(self.n_sites)
+
+    # -- subsets and single sites (SiteNetwork.py:97-141,199-207,311-346) ----------------------------------------------
+    def __getitem__(self, key):
+        """The network of the sites ``key`` selects (an index array, a boolean mask, a slice): centres, vertices, types
+        and per-site arrays of those sites, per-edge matrices cut down on both axes (``:97-125``)."""
+        rec = self._sites
+        part = SiteNetwork(self.structure, self.static_mask, self.mobile_mask)
+        if rec["centers"] is None:
+            return part
+        pick = np.arange(self.n_sites)[key]                    # what the selection means, once, for every array
+        pick = np.atleast_1d(pick)
+        part.centers = rec["centers"][pick]
+        if rec["vertices"] is not None:
+            part.vertices = [rec["vertices"][int(i)] for i in pick]
+        if rec["types"] is not None:
+            part.site_types = rec["types"][pick]
+        for name, (kind, array) in rec["named"].items():
+            part._store(kind, name, array[pick] if kind == self._SITE else array[pick][:, pick])
+        return part
+
+    def of_type(self, stype):
+        """The sites of one type as a network of their own (``:127-141``)."""
+        kinds = self._sites["types"]
+        if kinds is None:
+            raise ValueError("This SiteNetwork has no type information.")
+        if stype not in kinds:
+            raise ValueError("This SiteNetwork has no sites of type %i" % stype)
+        return self[kinds == stype]
+
+    def update_centers(self, newcenters):
+        """New coordinates for the SAME sites: vertices, types and named arrays stay (``:199-207``; the ``centers``
+        setter is for a new set of sites and drops them)."""
+        newcenters = np.asarray(newcenters)
+        old = self._sites["centers"]
+        if old is None or newcenters.shape != old.shape:
+            raise ValueError("New `centers` must have same shape as old; try using the setter `.centers = ...`")
+        self._sites["centers"] = newcenters
+
+    def get_site(self, site):
+        """Everything known about one site, as a dict (``:311-329``)."""
+        rec = self._sites
+        out = {"center": self.centers[site]}
+        if rec["vertices"] is not None:
+            out["vertices"] = rec["vertices"][site]
+        if rec["types"] is not None:
+            out["type"] = rec["types"][site]
+        for name in self.site_attributes:
+            out[name] = rec["named"][name][1][site]
+        return out
+
+    def get_edge(self, edge):
+        """Every per-edge value of the edge ``(i, j)`` (``:331-346``)."""
+        names = self.edge_attributes
+        if not names:
+            raise ValueError("This SiteNetwork has no edge attributes")
+        return {name: self._sites["named"][name][1][edge] for name in names}
 
     def copy(self):
         twin = SiteNetwork(self.structure, self.static_mask, self.mobile_mask)
