@@ -2,8 +2,9 @@
 import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tr = "/tmp/ff_trace.txt"
-if os.path.exists(tr):
-    os.remove(tr)
+for _f in (tr, tr + ".found"):
+    if os.path.exists(_f):
+        os.remove(_f)
 os.environ["SITATOR_FF_TRACE"] = tr
 os.environ["SITATOR_PIPELINE"] = "0"
 import numpy as np
@@ -38,4 +39,9 @@ for i, (pos, nb, fn, fb, lognf, kd) in enumerate(rows):
     if i < 40 or (kind == "bad" and kinds["bad"] < 40):
         print(i, "pos", pos, "nb", nb, "first_new", fn, "first_bad", fb, "nnew", nnew, "nfound", nf, "log", logn, "K", K, "dec", dec, "vdec", vdec, kind)
 print(kinds)
+if os.path.exists(tr + ".found"):
+    fr = [tuple(int(x) for x in l.split()) for l in open(tr + ".found")]
+    print("k_fs_found phases (cycles): step, nnew, nf | set-up, bidding, staging, scoring, kernel, rounds")
+    for i, (r_, o_) in enumerate(zip(fr, out)):
+        if r_[4] > 100000: print(i, o_[2], o_[3], "|", *r_)
 json.dump(out, open(os.environ.get("FF_STEPS_JSON", "/tmp/ff_steps.json"), "w"))

@@ -177,7 +177,7 @@ extern "C" int sit_device_count(int *count)
 // contexts, whose two streams are created back to back.
 namespace {
 std::mutex g_stream_mu;
-std::vector<std::pair<int, hipStream_t>> g_free_streams[2];
+std::vector<std::pair<int, hipStream_t>> g_free_streams[3];      // 0: compute streams (handed on), 1 / 2: the two copy streams of a device (shared)
 
 hipStream_t stream_take(int device, int kind)
 {
@@ -189,7 +189,7 @@ hipStream_t stream_take(int device, int kind)
     }
     hipStream_t s = nullptr;
     if ((kind == 0 ? hipStreamCreate(&s) : hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return nullptr;
-    if (kind == 1) { std::lock_guard<std::mutex> lock(g_stream_mu); g_free_streams[1].emplace_back(device, s); }   // one per device, shared
+    if (kind >= 1) { std::lock_guard<std::mutex> lock(g_stream_mu); g_free_streams[kind].emplace_back(device, s); }   // one per device, shared
     return s;
 }
 
@@ -197,7 +197,7 @@ void stream_give(int device, int kind, hipStream_t s)
 {
     if (!s) return;
     (void)hipStreamSynchronize(s);
-    if (kind == 1) return;
+    if (kind >= 1) return;
     std::lock_guard<std::mutex> lock(g_stream_mu);
     g_free_streams[kind].emplace_back(device, s);
 }
@@ -219,7 +219,8 @@ extern "C" int sit_create(const double *cell, const double *cell_inv, int device
     if (hipSetDevice(device) != hipSuccess) { c->msg = "hipSetDevice failed"; return SIT_ERR_HIP; }
     c->stream = stream_take(device, 0);
     c->copy_stream = stream_take(device, 1);
-    if (!c->stream || !c->copy_stream) { c->msg = "stream creation failed"; return SIT_ERR_HIP; }
+    c->copy_stream2 = stream_take(device, 2);
+    if (!c->stream || !c->copy_stream || !c->copy_stream2) { c->msg = "stream creation failed"; return SIT_ERR_HIP; }
     for (int i = 0; i < T_N; i++) { HIP_TRY(c, hipEventCreate(&c->tev0[i])); HIP_TRY(c, hipEventCreate(&c->tev1[i])); }
     HIP_TRY(c, hipHostMalloc(&c->h_pinned, 1024));      // [0, 512): one-off read-backs; [512, 1024): the results of deferred fills
     // the error key and the counters sit side by side: one read-back per call
@@ -244,6 +245,7 @@ extern "C" void sit_destroy(sit_ctx *c)
     fitfast_free(c);
     fill_ring_free(c);
     stream_give(c->device, 1, c->copy_stream);
+    stream_give(c->device, 2, c->copy_stream2);
     for (int i = 0; i < T_N; i++) { if (c->tev0[i]) (void)hipEventDestroy(c->tev0[i]); if (c->tev1[i]) (void)hipEventDestroy(c->tev1[i]); }
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     stream_give(c->device, 0, c->stream);

@@ -686,21 +686,25 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
     return SIT_ERR_CAPACITY;
 }
 
-// Host -> device copy of part of a pageable buffer through a ring of pinned staging buffers: copy threads (4; SITATOR_COPY_THREADS: more did not help, the fit is the longer leg) fill 4 MB
-// slots, each slot leaves by DMA on `stream` as soon as it is staged and is reused once its DMA has finished.  (A plain
-// hipMemcpyAsync of pageable memory is as fast, 55 GB/s, but it blocks the runtime for other threads' launches while it
-// runs: this one only enqueues.)  Returns when the whole range has arrived.
-#define RING_SLOTS 8
+// Host -> device copy of part of a pageable buffer through a ring of pinned staging buffers: copy threads (8;
+// SITATOR_COPY_THREADS) fill 4 MB slots, each slot leaves by DMA as soon as it is staged - the pieces alternating between
+// TWO streams - and is reused once its DMA has finished.  Measured on the MI355X box (scratch/ring_probe.hip, 1.38 GB):
+// a plain hipMemcpy of pageable memory 56 GB/s (but it holds the runtime's lock against other threads' launches while
+// it runs); this ring with ONE stream 46 GB/s whatever the slots, piece size, threads, pinned-memory flags or way of
+// waiting (36-40 GB/s beside the fit's kernels: until round 4 the fit was the longer leg and nobody noticed); with two
+// streams 55 GB/s.  Returns when the whole range has arrived.
+#define RING_SLOTS 16
 #define RING_CHUNK ((size_t)4 << 20)
 static std::mutex g_ring_mutex;
 static char *g_ring = nullptr;
 
 static int upload_staged(sit_ctx *c, hipStream_t stream, hipEvent_t *slot_ev, void *dst, const void *src, size_t bytes)
 {
+    hipStream_t two[2] = {stream, c->copy_stream2 ? c->copy_stream2 : stream};
     std::lock_guard<std::mutex> lock(g_ring_mutex);
     if (!g_ring && hipHostMalloc((void **)&g_ring, RING_SLOTS * RING_CHUNK) != hipSuccess) { g_ring = nullptr; return SIT_ERR_HIP; }
     const size_t nchunks = (bytes + RING_CHUNK - 1) / RING_CHUNK;
-    static const int want_threads = [] { const char *v = getenv("SITATOR_COPY_THREADS"); const int n = v ? atoi(v) : 0; return n >= 1 && n <= 32 ? n : 4; }();
+    static const int want_threads = [] { const char *v = getenv("SITATOR_COPY_THREADS"); const int n = v ? atoi(v) : 0; return n >= 1 && n <= 32 ? n : 8; }();
     const int nthreads = (int)std::min<size_t>((size_t)want_threads, nchunks);
     std::vector<std::atomic<int>> staged(nchunks);
     std::atomic<long long> released(RING_SLOTS), next(0);
@@ -723,8 +727,8 @@ static int upload_staged(sit_ctx *c, hipStream_t stream, hipEvent_t *slot_ev, vo
         while (!staged[i].load(std::memory_order_acquire)) std::this_thread::sleep_for(std::chrono::microseconds(10));
         const size_t off = i * RING_CHUNK, n = std::min(RING_CHUNK, bytes - off);
         const int slot = (int)(i % RING_SLOTS);
-        if (rc == SIT_OK && (hipMemcpyAsync((char *)dst + off, ring + (size_t)slot * RING_CHUNK, n, hipMemcpyHostToDevice, stream) != hipSuccess ||
-                             hipEventRecord(slot_ev[slot], stream) != hipSuccess)) rc = SIT_ERR_HIP;
+        if (rc == SIT_OK && (hipMemcpyAsync((char *)dst + off, ring + (size_t)slot * RING_CHUNK, n, hipMemcpyHostToDevice, two[i & 1]) != hipSuccess ||
+                             hipEventRecord(slot_ev[slot], two[i & 1]) != hipSuccess)) rc = SIT_ERR_HIP;
         if (i + 1 >= RING_SLOTS / 2) {          // the slot of the oldest chunk in flight is handed back once its DMA is done
             const size_t done = i + 1 - RING_SLOTS / 2;
             if (rc == SIT_OK && hipEventSynchronize(slot_ev[done % RING_SLOTS]) != hipSuccess) rc = SIT_ERR_HIP;
@@ -733,7 +737,7 @@ static int upload_staged(sit_ctx *c, hipStream_t stream, hipEvent_t *slot_ev, vo
     }
     released.store((long long)nchunks + RING_SLOTS, std::memory_order_release);
     for (auto &t : pool) t.join();
-    if (rc == SIT_OK && hipStreamSynchronize(stream) != hipSuccess) rc = SIT_ERR_HIP;
+    if (rc == SIT_OK && (hipStreamSynchronize(two[0]) != hipSuccess || hipStreamSynchronize(two[1]) != hipSuccess)) rc = SIT_ERR_HIP;
     return rc;
 }
 
@@ -898,6 +902,7 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
         if (code != SIT_OK) failed.store(1);        // the upload thread skips the chunks it has not started
         up.join();
         (void)hipStreamSynchronize(c->copy_stream);
+        if (c->copy_stream2) (void)hipStreamSynchronize(c->copy_stream2);
         return code;
     };
     auto wait_chunk = [&](int i) -> int {

@@ -41,6 +41,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "sit_internal.h"
 
@@ -58,6 +60,7 @@
 #define FS_TAIL 64                // rows the commit may apply one at a time
 #define FS_TF 64                  // tentative centres (founding rows taken inside a batch) per step
 #define FS_LGS 512                // growth records the verification stages in LDS
+#define FS_LGD 16384              // landmark dimensions its bitmap of named dimensions covers
 #define FS_NEW (-1)
 #define FS_BREAK (-2)             // row must go the serial way (zero row, capacity)
 #define FS_CHUNK 64               // steps enqueued between two looks at the control block
@@ -511,6 +514,17 @@ __global__ __launch_bounds__(1024) void k_fs_found(FS s, FSRows r, int par, doub
     if (tid == 0) { ctl->nfound = 0; ctl->any_new = nnew; }
     if (nnew == 0) return;                                        // uniform
     __syncthreads();                                              // the list is read by other threads than those that wrote it
+    // A batch that opens with a new row and is mostly new rows - the first frame of a trajectory, the second pass of
+    // fit_centers over the centres themselves: every row founds - goes the old way: cut at row 0, the commit's run of
+    // founding rows (one pairwise pass per 64 rows; the rounds below need one per hash collision among them)
+    if (nl[0] == 0 && 2 * nnew >= lim) {
+        if (tid == 0) atomicMin(&ctl->first_new, 0);
+        return;
+    }
+    // diagnostics (SITATOR_FF_TRACE): cycles of the phases of this kernel, second half of the trace buffer
+    i64 *tq = s.trace && ctl->trace_n < FS_TRACE_CAP / 2 ? s.trace + 6 * (ctl->trace_n + FS_TRACE_CAP / 2) : nullptr;
+    long long tk0 = tq ? clock64() : 0, tk_bid = 0, tk_stage = 0, tk_score = 0;
+    int nrounds = 0;
     {
         // more rows than the threads hold (or than pays: the rounds below cost one CU's time per listed row): the batch
         // ends before the rest
@@ -538,8 +552,11 @@ __global__ __launch_bounds__(1024) void k_fs_found(FS s, FSRows r, int par, doub
     }
     const double settled = threshold > 0.8 ? threshold : 0.8;
     const unsigned settled_q = settled >= 1.0 ? 0xffffffu : (unsigned)(settled * 8388608.0);
+    const long long tk1 = tq ? clock64() : 0;
     int fdone = 0;                                                // founders of the rounds so far
     for (;;) {
+        const long long tr0 = tq ? clock64() : 0;
+        nrounds++;
         if (tid < 32) owner[tid] = 0x7fffffff;
         if (tid == 0) sh_unset = 0;
         __syncthreads();
@@ -551,11 +568,15 @@ __global__ __launch_bounds__(1024) void k_fs_found(FS s, FSRows r, int par, doub
             if (q >= nnew || st[u]) continue;
             any = true;
             unsigned m = sig[u];
-            while (m) { const int bit = __ffs((int)m) - 1; m &= m - 1u; atomicMin(&owner[bit], q); }
+            // (a look before the atomic: the bits are few and the rows many - thousands of minima on 32 words took 50 us
+            // a round; rows come in ascending order over u, so the early bids settle most bits)
+            while (m) { const int bit = __ffs((int)m) - 1; m &= m - 1u; if (q < owner[bit]) atomicMin(&owner[bit], q); }
         }
         if (__ballot(any) && lane == 0) sh_unset = 1;
         __syncthreads();
         if (!sh_unset) break;                                       // every row is settled
+        const long long tr1 = tq ? clock64() : 0;
+        tk_bid += tr1 - tr0;
         // a row that holds all its bits founds a tentative centre
         unsigned fmask = 0u;
 #pragma unroll
@@ -611,6 +632,8 @@ __global__ __launch_bounds__(1024) void k_fs_found(FS s, FSRows r, int par, doub
             for (int u = 0; u < UC; u++) if (u == uu) st[u] = mark;
         }
         __syncthreads();
+        const long long tr2 = tq ? clock64() : 0;
+        tk_stage += tr2 - tr1;
         int fnow = sh_fcount;
         if (fnow > FS_TF) fnow = FS_TF;
         // the rows that are not settled (well) yet against the new founders before them
@@ -653,6 +676,7 @@ __global__ __launch_bounds__(1024) void k_fs_found(FS s, FSRows r, int par, doub
 #pragma unroll
             for (int u = 0; u < UC; u++) if (u == uu) st[u] = cur;
         }
+        tk_score += (tq ? clock64() : 0) - tr2;
         fdone = fnow;
         if (sh_fcount >= FS_TF) {                                   // no room for further founders: the batch ends before the
             int cutj = 0x7fffffff;                                  // first row that is still unsettled
@@ -708,6 +732,7 @@ __global__ __launch_bounds__(1024) void k_fs_found(FS s, FSRows r, int par, doub
         atomicOr((unsigned long long *)&s.bm0[kk * FS_W0 + (j >> 6)], 1ull << (j & 63));
         atomicOr((unsigned long long *)&s.bm1[kk * FS_W1 + (j >> 12)], 1ull << ((j >> 6) & 63));
     }
+    if (tid == 0 && tq) { tq[0] = tk1 - tk0; tq[1] = tk_bid; tq[2] = tk_stage; tq[3] = tk_score; tq[4] = clock64() - tk0; tq[5] = nrounds; }
     if (tid == 0) {
         int ltot = 0;
         for (int g = 0; g < nf; g++) ltot += f_n[g];
@@ -1136,7 +1161,7 @@ __device__ __forceinline__ Best fs_score_seen(const FS &s, const FSRows &r, cons
 
 template <int NR, int NS, int G>
 __device__ __forceinline__ void fs_verify(const FS &s, const FSRows &r, FSCtl *ctl, int jlast, int K, i64 pos,
-                                          double threshold, i32 *ovl, const i32 *lgp, int nlg)
+                                          double threshold, i32 *ovl, const i32 *lgp, int nlg, const unsigned *dimbits)
 {
     const int gl = threadIdx.x & (G - 1);
     const int j = (int)(((i64)blockIdx.x * 256 + threadIdx.x) / G);
@@ -1169,7 +1194,13 @@ __device__ __forceinline__ void fs_verify(const FS &s, const FSRows &r, FSCtl *c
         // centres that gained one of my dimensions earlier in this batch (support growth, foundings) overlap me now
         // without being listed
         bool over = false;
-        for (int q = 0; q < nlg; q++) {
+        int nscan = nlg;
+        if (dimbits) {                                              // most rows hold none of the dimensions the records name
+            bool named = false;
+            for (int e = 0; e < n; e++) { const i32 d = row_dim(R, r, row, e); named = named || ((dimbits[d >> 5] >> (d & 31)) & 1u); }
+            if (!named) nscan = 0;
+        }
+        for (int q = 0; q < nscan; q++) {
             if (lgp[3 * q + 2] >= j) continue;
             const i32 kk = lgp[3 * q], dd = lgp[3 * q + 1];
             if (!row_has(R, r, row, dd)) continue;
@@ -1199,6 +1230,7 @@ __global__ __launch_bounds__(256) void k_fs_verify(FS s, FSRows r, int par, doub
 {
     __shared__ i32 ovl[16 * FS_OC];
     __shared__ i32 lg[3 * FS_LGS];                               // the growth records, staged: every row of the block scans them
+    __shared__ unsigned lgdim[FS_LGD / 32];                      // ... but first asks whether any of them names one of its dimensions
     FSCtl *ctl = s.ctl + par;
     if (ctl->halt) return;
     const int nb = ctl->nb, K = ctl->K;
@@ -1208,13 +1240,20 @@ __global__ __launch_bounds__(256) void k_fs_verify(FS s, FSRows r, int par, doub
     int nlg = ctl->log_n;
     if (nlg > FS_LOG) nlg = FS_LOG;
     const i32 *lgp = s.log;
+    const unsigned *dimbits = nullptr;
+    if (nlg > 0 && s.D <= FS_LGD) {
+        for (int q = threadIdx.x; q < (int)((s.D + 31) >> 5); q += 256) lgdim[q] = 0u;
+        __syncthreads();
+        for (int q = threadIdx.x; q < nlg; q += 256) { const i32 dd = s.log[3 * q + 1]; atomicOr(&lgdim[dd >> 5], 1u << (dd & 31)); }
+        dimbits = lgdim;
+    }
     if (nlg <= FS_LGS) {
         for (int q = threadIdx.x; q < 3 * nlg; q += 256) lg[q] = s.log[q];
-        __syncthreads();
         lgp = lg;
     }
-    if (nb <= 16384) fs_verify<NR, NS, 64>(s, r, ctl, jlast, K, ctl->pos, threshold, ovl + (threadIdx.x >> 6) * FS_OC, lgp, nlg);
-    else fs_verify<NR, NS, 16>(s, r, ctl, jlast, K, ctl->pos, threshold, ovl + (threadIdx.x >> 4) * FS_OC, lgp, nlg);
+    __syncthreads();
+    if (nb <= 16384) fs_verify<NR, NS, 64>(s, r, ctl, jlast, K, ctl->pos, threshold, ovl + (threadIdx.x >> 6) * FS_OC, lgp, nlg, dimbits);
+    else fs_verify<NR, NS, 16>(s, r, ctl, jlast, K, ctl->pos, threshold, ovl + (threadIdx.x >> 4) * FS_OC, lgp, nlg, dimbits);
 }
 
 // ---- D: commit -----------------------------------------------------------------------------------------
@@ -1632,7 +1671,7 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
     i32 K = 0;
     { int rc = ff_read_K(c, f, &K); if (rc) return rc; }
     const char *tp = getenv("SITATOR_FF_TRACE");              // diagnostics: one line per step
-    if (tp && !f->d_trace) HIP_TRY(c, hipMalloc((void **)&f->d_trace, (size_t)FS_TRACE_CAP * 48));
+    if (tp && !f->d_trace) { HIP_TRY(c, hipMalloc((void **)&f->d_trace, (size_t)FS_TRACE_CAP * 48)); HIP_TRY(c, hipMemset(f->d_trace, 0, (size_t)FS_TRACE_CAP * 48)); }
     i64 base = 0;                                             // rows consumed before the current control chain
     int B = f->B_keep;                                        // (a pipelined run streams its rows in 4-16 calls: 8 doubling steps each)
     for (;;) {
@@ -1701,6 +1740,16 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
                 for (i64 q = 0; q < nt; q++)
                     fprintf(fp, "%lld %lld %lld %lld %lld %lld\n", (long long)(t[6 * q] + base), (long long)t[6 * q + 1], (long long)t[6 * q + 2],
                             (long long)t[6 * q + 3], (long long)t[6 * q + 4], (long long)t[6 * q + 5]);
+                fclose(fp);
+            }
+            // the phases of k_fs_found, per step (cycles: set-up, bidding, staging, scoring, whole kernel; rounds)
+            const i64 nt2 = nt < FS_TRACE_CAP / 2 ? nt : FS_TRACE_CAP / 2;
+            std::vector<i64> t2((size_t)nt2 * 6);
+            HIP_TRY(c, hipMemcpy(t2.data(), f->d_trace + 6 * (FS_TRACE_CAP / 2), (size_t)nt2 * 48, hipMemcpyDeviceToHost));
+            if (FILE *fp = fopen((std::string(tp) + ".found").c_str(), "a")) {
+                for (i64 q = 0; q < nt2; q++)
+                    fprintf(fp, "%lld %lld %lld %lld %lld %lld\n", (long long)t2[6 * q], (long long)t2[6 * q + 1], (long long)t2[6 * q + 2],
+                            (long long)t2[6 * q + 3], (long long)t2[6 * q + 4], (long long)t2[6 * q + 5]);
                 fclose(fp);
             }
         }

@@ -30,7 +30,7 @@ struct sit_ctx {
     int device = 0;
     int num_cu = 0;                                            // compute units of the device (queried once)
     hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;                         // uploads of sit_upload_fill_fit (fill.hip)
+    hipStream_t copy_stream = nullptr, copy_stream2 = nullptr; // uploads of sit_upload_fill_fit (fill.hip): the pieces alternate between them
     hipEvent_t tev0[T_N] = {nullptr}, tev1[T_N] = {nullptr};   // per-stage event pairs
     bool tpending[T_N] = {false};                              // recorded, not yet read
     void *h_pinned = nullptr;                                  // small pinned read-back buffer (256 bytes)
