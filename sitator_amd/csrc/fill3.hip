@@ -50,7 +50,7 @@
 // loaded where they are used)
 struct Fill3Args {
     const uint4 *vh;                  // [D,Vp] 32-byte records {24 * static id (byte offset of the vertex in a frame),
-                                      //   static id, exact squared-distance threshold (+inf on padding), 1 / vcd (-inf on
+                                      //   static id, exact squared-distance threshold (+inf on padding), steepness / vcd (-inf on
                                       //   padding: the factor of a padded vertex is exactly 1), 8 bytes unused}
     const unsigned char *nvtab;       // [D]
     const uint4 *pack;                // list entries of the primary table, then of the fallback table, 16 bytes each:
@@ -127,17 +127,15 @@ __host__ __device__ inline F3Layout f3_layout(int fpb, int SM, int M, int nw, in
 
 // ---- arithmetic -----------------------------------------------------------------------------------------------------
 
-// sqrt for x in [1e-300, 1e300]: v_rsq_f64 seed (2^-23), two coupled Newton steps (error ~2^-89 before rounding); the
-// device library's final correctly-rounding step is left out (the value feeds a product that needs 1e-6)
+// sqrt for x in [1e-300, 1e300]: v_rsq_f64 seed (measured 5.2e-8 relative, scratch/rsq_acc.hip) and ONE coupled Newton
+// step: 4.2e-15 relative (measured; 1.5 seed^2).  The second step and the device library's correctly-rounding step
+// are left out: the value feeds a product that needs 1e-6 (round 4: the second step cost three instructions per lane)
 __device__ __forceinline__ double sqrt_nr(double x)
 {
     const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
+    const double g = x * y, h = 0.5 * y;
     const double r = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
-    const double d = __builtin_fma(-g, g, x);
-    return __builtin_fma(d, h, g);
+    return __builtin_fma(g, r, g);
 }
 
 // 1 / b for b in [1, 1e300): v_rcp_f64 seed and two Newton steps
@@ -153,7 +151,7 @@ __device__ __forceinline__ double rcp_nr(double b)
 // The constants of exp_tab / vertex_term, held in VECTOR registers: the kernel is short of scalar registers (every
 // constant the compiler parks there pushes another value into a spill lane and costs VALU instructions to move).
 struct ExpK {
-    double log2e_128, magic, ln2_128, c4, c3, mid, steep;
+    double log2e_128, magic, ln2_128, c4, c3, smid;
 };
 __device__ __forceinline__ double in_vgpr(double x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ ExpK expk_make(double mid, double steep)
@@ -163,7 +161,7 @@ __device__ __forceinline__ ExpK expk_make(double mid, double steep)
     k.magic = in_vgpr(6755399441055744.0);             // 1.5 * 2^52: the integer lands in the low mantissa bits
     k.ln2_128 = in_vgpr(0x1.62e42fefa39efp-8);         // ln 2 / 128 to 53 bits: |n| < 2^17, so n * (its error) < 1e-14
     k.c4 = in_vgpr(1.0 / 24); k.c3 = in_vgpr(1.0 / 6);
-    k.mid = in_vgpr(mid); k.steep = in_vgpr(steep);
+    k.smid = in_vgpr(steep * mid);
     return k;
 }
 
@@ -173,7 +171,8 @@ __device__ __forceinline__ ExpK expk_make(double mid, double steep)
 __device__ __forceinline__ double exp_tab(double x, const double *tab, const ExpK &k)
 {
     x = __builtin_fmax(x, -700.0);                     // exp(-700) ~ 1e-304: 1 + e == 1 all the same, no denormals
-    const double u = __builtin_fma(x, k.log2e_128, k.magic);
+    double u;                                          // (left to itself the compiler copies magic and uses v_fmac)
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(u) : "v"(x), "v"(k.log2e_128), "v"(k.magic));
     const double n = u - k.magic;
     const int ni = (int)(unsigned)__double_as_longlong(u);
     const double r = __builtin_fma(-n, k.ln2_128, x);
@@ -186,22 +185,21 @@ __device__ __forceinline__ double exp_tab(double x, const double *tab, const Exp
 }
 
 // 1 / (logistic factor) of helpers.pyx:186-205 = 1 + exp(steepness (t - midpoint)) from the squared distance of a vertex
-// that is inside the cut-off (rvcd = -inf on a padded vertex: t = -inf, e = exp(-700), the term exactly 1).  The
-// reciprocal is taken once per component, of the product of its terms (<= 1e4^8, no overflow).
-__device__ __forceinline__ double vertex_term(double d2, double rvcd, const ExpK &k, const double *tab)
+// that is inside the cut-off; srv = steepness / vcd from the vertex record (-inf on a padded vertex: the argument is
+// -inf, e = exp(-700), the term exactly 1), the argument as ONE fma, sqrt(d2) srv - steepness midpoint (round 4: the
+// reference's multiply, subtract, multiply differ from it by their own roundings, ~1e-14).  The reciprocal is taken
+// once per component, of the product of its terms (<= 1e4^8, no overflow).
+__device__ __forceinline__ double vertex_term(double d2, double srv, const ExpK &k, const double *tab)
 {
-    d2 = __builtin_fmax(d2, 1e-300);                   // an ion exactly on a static atom: t - midpoint is the same
-    const double tt = sqrt_nr(d2) * rvcd;
-    return 1.0 + exp_tab(k.steep * (tt - k.mid), tab, k);
+    d2 = __builtin_fmax(d2, 1e-300);                   // an ion exactly on a static atom: the argument is the same
+    return 1.0 + exp_tab(__builtin_fma(sqrt_nr(d2), srv, -k.smid), tab, k);
 }
 
-// 1 / sqrt(x): v_rsq_f64 seed and two Newton steps
+// 1 / sqrt(x): v_rsq_f64 seed and one Newton step (4e-15 relative)
 __device__ __forceinline__ double rsqrt_nr(double x)
 {
-    double y = __builtin_amdgcn_rsq(x);
-    double e = __builtin_fma(-x * y, y, 1.0);
-    y = __builtin_fma(0.5 * y, e, y);
-    e = __builtin_fma(-x * y, y, 1.0);
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x * y, y, 1.0);
     return __builtin_fma(0.5 * y, e, y);
 }
 
@@ -218,6 +216,14 @@ __device__ __forceinline__ double root_chain(double p, int nv)
 }
 
 // ---- wave helpers --------------------------------------------------------------------------------------------------
+
+// An LDS pointer from a byte offset.  The kernel has no static LDS, so its dynamic allocation starts at LDS address 0
+// (checked at the top of the kernel): `smem + off` would add the symbol's address - a vector add of zero per look-up.
+__device__ __forceinline__ const double *lds_f64(unsigned off)
+{
+    return (const double *)(const __attribute__((address_space(3))) double *)(size_t)off;
+}
+
 
 // inclusive maximum scan over the 64 lanes (values >= 0; 0 is the identity)
 __device__ __forceinline__ int wave_max_scan(int x)
@@ -319,8 +325,8 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
             }                                                                                                              \
             const double hk = __hiloint2double((int)r0.w, (int)r0.z);                                                      \
             rv_[u] = __hiloint2double((int)r1.y, (int)r1.x);                                                               \
-            const double *sp = (const double *)(smem + (statoff + voff));                                                  \
-            const double *op = (const double *)(smem + ionoff);                                                            \
+            const double *sp = lds_f64(statoff + voff);                                                                    \
+            const double *op = lds_f64(ionoff);                                                                            \
             double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];                                             \
             wrapc3<CELL>(P, qx, qy, qz);                                                                                   \
             const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];                                       \
@@ -512,6 +518,10 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     const u64 errw = (u64)(S + 1 + M);
     const Fill3Args __attribute__((address_space(4))) &g = *full;
 
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem != 0u) {      // lds_f64: never (no static LDS)
+        if (tid == 0) atomicMin(h.err, 0ull);
+        return;
+    }
     if (tid < fpb) fmax[tid] = 0ull;
     if (FUSE && tid < 2 * NW) garrive[tid] = 0u;
     double etv = 0.0;
@@ -707,8 +717,8 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                 unsigned voff = en.y;
                 if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)tfl) * S + (i64)(en.y / 24u)];
                 const double hk = __hiloint2double((int)en.w, (int)en.z);
-                const double *sp = (const double *)(smem + (statoff + voff));
-                const double *op = (const double *)(smem + ionoff);
+                const double *sp = lds_f64(statoff + voff);
+                const double *op = lds_f64(ionoff);
                 double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];
                 wrapc3<CELL>(P, qx, qy, qz);
                 const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
@@ -837,7 +847,7 @@ static int fill3_basis_tables(sit_ctx *c)
             const bool valid = hh < c->Vp && v[src] >= 0 && (i64)cnt == hh;    // vertices are a prefix (the reference breaks at -1)
             if (valid) cnt++;
             const double t2 = valid ? f3_exact_d2_threshold(vcd[src], c->rz) : INFINITY;
-            const double rv = valid ? 1.0 / vcd[src] : -INFINITY;              // -inf: the term of a padded vertex is exactly 1
+            const double rv = valid ? c->steepness / vcd[src] : -INFINITY;      // -inf: the term of a padded vertex is exactly 1
             const unsigned vi = valid ? (unsigned)v[src] : 0u;
             unsigned long long tb, rb;
             memcpy(&tb, &t2, 8);

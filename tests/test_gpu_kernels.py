@@ -35,7 +35,8 @@ def _setup(host, M, F, seed, kernel="3", mutate=None):
 def test_fill_generations_agree(cfg, M, F):
     """The first generation (the general fallback) evaluates the reference's expressions with the library's sqrt,
     division, exp and pow; the third decides the zero pattern with exact squared-distance thresholds and evaluates
-    the values with shortened Newton sequences and a table-driven exp: same sparsity pattern, values within ~1e-14."""
+    the values with one-step Newton sequences and a table-driven exp: same sparsity pattern, values within 1e-13 (measured
+    5e-14 at worst, 3e-15 on average: scratch/acc_fill.py; the contract is 1e-6)."""
     from sitator_amd import synth
     host = synth.config_host(cfg)
     out = []
@@ -47,7 +48,7 @@ def test_fill_generations_agree(cfg, M, F):
         out.append(ctx.rows_dense())
     for other in out[1:]:
         assert np.array_equal(out[0] != 0, other != 0)
-        np.testing.assert_allclose(other, out[0], rtol=2e-14, atol=0)
+        np.testing.assert_allclose(other, out[0], rtol=1e-13, atol=0)
 
 
 @pytest.mark.parametrize("cfg,M,F,dyn", [("C2", 64, 150, False), ("C2", 64, 60, True), ("C1b", 4, 400, True),
