@@ -66,6 +66,7 @@ struct Fill3Args {
     unsigned f_base;                  // first fallback entry in pack
     int check_zeros;
     double midpoint, steepness;
+    double x0lo, x0hi;                // CHEAP: the logistic argument at the cut-off, minus / plus the error bound of ours
     int nv_uniform;                   // > 0: every landmark has this many vertices (nvtab is not read)
     // ---- fused site assignment (FUSE = 1) ----
     int store;                        // rows are wanted in the row buffers as well
@@ -189,10 +190,20 @@ __device__ __forceinline__ double exp_tab(double x, const double *tab, const Exp
 // -inf, e = exp(-700), the term exactly 1), the argument as ONE fma, sqrt(d2) srv - steepness midpoint (round 4: the
 // reference's multiply, subtract, multiply differ from it by their own roundings, ~1e-14).  The reciprocal is taken
 // once per component, of the product of its terms (<= 1e4^8, no overflow).
-__device__ __forceinline__ double vertex_term(double d2, double srv, const ExpK &k, const double *tab)
+__device__ __forceinline__ double vertex_arg(double d2, double srv, const ExpK &k)
 {
     d2 = __builtin_fmax(d2, 1e-300);                   // an ion exactly on a static atom: the argument is the same
-    return 1.0 + exp_tab(__builtin_fma(sqrt_nr(d2), srv, -k.smid), tab, k);
+    return __builtin_fma(sqrt_nr(d2), srv, -k.smid);
+}
+__device__ __forceinline__ double vertex_term(double d2, double srv, const ExpK &k, const double *tab)
+{
+    return 1.0 + exp_tab(vertex_arg(d2, srv, k), tab, k);
+}
+
+// one component of the minimum-image vector in a diagonal cell: w - L rint(w / L)
+__device__ __forceinline__ double minimg1(double w, double ci, double cm)
+{
+    return __builtin_fma(-__builtin_rint(w * ci), cm, w);
 }
 
 // 1 / sqrt(x): v_rsq_f64 seed and one Newton step (4e-15 relative)
@@ -299,62 +310,108 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
     return (b0 * G1 + b1) * G2 + b2;
 }
 
+// The LDS byte offsets of the static vertex and of the ion of task TK (first word(s) of the vertex record in R0X / R0Y)
+#define F3_TASK_OFFSETS(TK, R0X, R0Y, VOFF, IONOFF, STATOFF)                                                               \
+    do {                                                                                                                   \
+        VOFF = (R0X); STATOFF = 0u;                                                                                        \
+        const unsigned ion_ = (TK) & ~KMASK;                                                                               \
+        if (FPB1) {                                                                                                        \
+            IONOFF = ionbase + 24u * ion_;                                                                                 \
+            if (DYN) VOFF = 24u * (unsigned)g.lattice_map[f0 * S + (i64)(R0Y)];                                            \
+        } else {                                                                                                           \
+            const uint4 ir = ((const uint4 *)ionrec)[ion_];                                                                \
+            IONOFF = ir.y; STATOFF = ir.z;                                                                                 \
+            if (DYN) VOFF = 24u * (unsigned)g.lattice_map[(f0 + (i64)ir.w) * S + (i64)(R0Y)];                              \
+        }                                                                                                                  \
+    } while (0)
+
 // NP passes of TPP tasks from the task table (cursor, cursor + 1): distances, thresholds, factors, products; the tasks
 // that keep all their lanes are appended to the survivors (prod, sv); cnt grows.  A macro: it lives inside the kernel's
 // locals (a lambda made the compiler spill its captures).
-#define F3_D1E_PASSES(NP)                                                                                                  \
+// CHEAP (a diagonal cell, round 4): the squared distance is that of the minimum-image vector static - ion (17
+// instructions where the reference's shift, wrap, subtract take 23) and the decision is made on the logistic argument
+// x = steepness (t - midpoint), which every lane needs anyway: x > x0hi is beyond the cut-off, x <= x0lo inside, and
+// a lane in the band between (the error bound of our x against the reference's, ~1e-11 wide: practically never)
+// sends the passes round again with EX = 1: the reference's own squared distance (util/PBCCalculator.pyx:64-103; the
+// ion's slot holds -ion, the offset is centroid - ion as in helpers.pyx:100) against the exact threshold.  The zero
+// pattern stays the reference's bit for bit.
+#define F3_D1E_BODY(NP, EX, REDO)                                                                                          \
     do {                                                                                                                   \
+        constexpr bool APPROX = CHEAP && !(EX);                                                                            \
         double d2_[NP], rv_[NP], f_[NP];                                                                                   \
         unsigned tk_[NP];                                                                                                  \
         unsigned long long bad_[NP];                                                                                       \
         _Pragma("unroll") for (int u = 0; u < NP; u++) {                                                                   \
             const int tb = TPP * (cursor + u);                                                                             \
             tk_[u] = ttab[tb + gi];                                                                                        \
-            const uint4 *rp = (const uint4 *)(vh + ((tk_[u] & KMASK) | hh32));                                             \
-            const uint4 r0 = rp[0];                                                                                        \
-            const uint2 r1 = *(const uint2 *)(rp + 1);                                                                     \
-            unsigned voff = r0.x, ionoff, statoff = 0u;                                                                    \
-            const unsigned ion_ = tk_[u] & ~KMASK;                                                                         \
-            if (FPB1) {                                                                                                    \
-                ionoff = ionbase + 24u * ion_;                                                                             \
-                if (DYN) voff = 24u * (unsigned)g.lattice_map[f0 * S + (i64)r0.y];                                         \
-            } else {                                                                                                       \
-                const uint4 ir = ((const uint4 *)ionrec)[ion_];                                                            \
-                ionoff = ir.y; statoff = ir.z;                                                                             \
-                if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)ir.w) * S + (i64)r0.y];                           \
-            }                                                                                                              \
-            const double hk = __hiloint2double((int)r0.w, (int)r0.z);                                                      \
+            const char *rp = vh + ((tk_[u] & KMASK) | hh32);                                                               \
+            uint4 r0 = make_uint4(0u, 0u, 0u, 0u);                                                                         \
+            if (!APPROX) r0 = *(const uint4 *)rp;                                                                          \
+            else if (DYN) { const uint2 t2 = *(const uint2 *)rp; r0.x = t2.x; r0.y = t2.y; }                               \
+            else r0.x = *(const unsigned *)rp;                                                                             \
+            const uint2 r1 = *(const uint2 *)(rp + 16);                                                                    \
+            unsigned voff, ionoff, statoff;                                                                                \
+            F3_TASK_OFFSETS(tk_[u], r0.x, r0.y, voff, ionoff, statoff);                                                    \
             rv_[u] = __hiloint2double((int)r1.y, (int)r1.x);                                                               \
             const double *sp = lds_f64(statoff + voff);                                                                    \
             const double *op = lds_f64(ionoff);                                                                            \
-            double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];                                             \
-            wrapc3<CELL>(P, qx, qy, qz);                                                                                   \
-            const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];                                       \
-            d2_[u] = (dx * dx + dy * dy) + dz * dz;                                                                        \
-            bad_[u] = __ballot(d2_[u] > hk) | ~first_lanes((t_end - tb) << LG);                                            \
+            if (APPROX) {                                                                                                  \
+                double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];                                         \
+                qx = minimg1(qx, P.ci[0], P.cm[0]); qy = minimg1(qy, P.ci[4], P.cm[4]); qz = minimg1(qz, P.ci[8], P.cm[8]); \
+                d2_[u] = (qx * qx + qy * qy) + qz * qz;                                                                    \
+                bad_[u] = 0ull;                                                                                            \
+            } else {                                                                                                       \
+                double ox = op[0], oy = op[1], oz = op[2];                                                                 \
+                if (CHEAP) { ox = P.cen[0] + ox; oy = P.cen[1] + oy; oz = P.cen[2] + oz; }                                 \
+                double qx = sp[0] + ox, qy = sp[1] + oy, qz = sp[2] + oz;                                                  \
+                wrapc3<CELL>(P, qx, qy, qz);                                                                               \
+                const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];                                   \
+                d2_[u] = (dx * dx + dy * dy) + dz * dz;                                                                    \
+                bad_[u] = __ballot(d2_[u] > __hiloint2double((int)r0.w, (int)r0.z)) | ~first_lanes((t_end - tb) << LG);   \
+            }                                                                                                              \
         }                                                                                                                  \
         if (!(DBG && dbg == 4)) {                                                                                          \
-            _Pragma("unroll") for (int u = 0; u < NP; u++) f_[u] = vertex_term(d2_[u], rv_[u], ek, etab);                \
-            _Pragma("unroll") for (int u = 0; u < NP; u++) {                                                               \
-                f_[u] *= dpp_row_shl<1>(f_[u]);                                                                            \
-                f_[u] *= dpp_row_shl<2>(f_[u]);                                                                            \
-                if (LG >= 3) f_[u] *= dpp_row_shl<4>(f_[u]);                                                               \
-                if (LG >= 4) f_[u] *= dpp_row_shl<8>(f_[u]);                                                               \
-            }                                                                                                              \
-            _Pragma("unroll") for (int u = 0; u < NP; u++) {                                                               \
-                /* scalar unit: the tasks whose lanes are all inside (bit 0 of every group of VP = the OR of the group) */  \
-                unsigned long long x = bad_[u];                                                                            \
-                if (LG >= 4) x |= x >> 8;                                                                                  \
-                if (LG >= 3) x |= x >> 4;                                                                                  \
-                x |= x >> 2; x |= x >> 1;                                                                                  \
-                const unsigned long long leads = ~x & LEADS;                                                               \
-                if (F3_LANES(leads)) {                                                                                     \
-                    const int q = mask_rank(leads, cnt);                     /* survivors before my task */                \
-                    prod[q] = f_[u]; sv[q] = tk_[u];                                                                       \
+            if (APPROX) {                                                                                                  \
+                _Pragma("unroll") for (int u = 0; u < NP; u++) d2_[u] = vertex_arg(d2_[u], rv_[u], ek);                    \
+                _Pragma("unroll") for (int u = 0; u < NP; u++) {                                                           \
+                    const unsigned long long out = __ballot(d2_[u] > x0lo);                                                \
+                    if (out) {                                                                                             \
+                        if (out & ~__ballot(d2_[u] > g.x0hi)) REDO = true;        /* (x0hi: a scalar load, here only) */   \
+                    }                                                                                                      \
+                    bad_[u] = out | ~first_lanes((t_end - TPP * (cursor + u)) << LG);                                      \
                 }                                                                                                          \
-                cnt += __popcll(leads);                                                                                    \
+                _Pragma("unroll") for (int u = 0; u < NP; u++) f_[u] = 1.0 + exp_tab(d2_[u], etab, ek);                    \
+            } else {                                                                                                       \
+                _Pragma("unroll") for (int u = 0; u < NP; u++) f_[u] = vertex_term(d2_[u], rv_[u], ek, etab);            \
+            }                                                                                                              \
+            if (!(REDO)) {                                                                                                 \
+                _Pragma("unroll") for (int u = 0; u < NP; u++) {                                                           \
+                    f_[u] *= dpp_row_shl<1>(f_[u]);                                                                        \
+                    f_[u] *= dpp_row_shl<2>(f_[u]);                                                                        \
+                    if (LG >= 3) f_[u] *= dpp_row_shl<4>(f_[u]);                                                           \
+                    if (LG >= 4) f_[u] *= dpp_row_shl<8>(f_[u]);                                                           \
+                }                                                                                                          \
+                _Pragma("unroll") for (int u = 0; u < NP; u++) {                                                           \
+                    /* scalar unit: the tasks whose lanes are all inside (bit 0 of every group of VP = the OR of the group) */ \
+                    unsigned long long x = bad_[u];                                                                        \
+                    if (LG >= 4) x |= x >> 8;                                                                              \
+                    if (LG >= 3) x |= x >> 4;                                                                              \
+                    x |= x >> 2; x |= x >> 1;                                                                              \
+                    const unsigned long long leads = ~x & LEADS;                                                           \
+                    if (F3_LANES(leads)) {                                                                                 \
+                        const int q = mask_rank(leads, cnt);                     /* survivors before my task */            \
+                        prod[q] = f_[u]; sv[q] = tk_[u];                                                                   \
+                    }                                                                                                      \
+                    cnt += __popcll(leads);                                                                                \
+                }                                                                                                          \
             }                                                                                                              \
         }                                                                                                                  \
+    } while (0)
+#define F3_D1E_PASSES(NP)                                                                                                  \
+    do {                                                                                                                   \
+        bool redo_ = false;                                          /* wave-uniform */                                    \
+        F3_D1E_BODY(NP, 0, redo_);                                                                                         \
+        if (CHEAP && redo_) { bool never_ = false; F3_D1E_BODY(NP, 1, never_); }                                           \
     } while (0)
 
 // T: the n-th root (helpers.pyx:212) of the product (:208), one lane per survivor of the wave's list; the row entry of a
@@ -487,6 +544,7 @@ template <int CELL, int LG, int NW, int DYN, int FPB1, int DBG, int FUSE>
 __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill3ArgsPtr full)
 {
     constexpr int VP = 1 << LG;
+    constexpr bool CHEAP = CELL == 1;                           // minimum-image distances, decisions on the logistic argument
     constexpr int NT = NW * 64;
     constexpr int TPP = 64 >> LG;                               // tasks per pass of 64 lanes
     constexpr int KSH = LG + 5;                                 // task = landmark << KSH | ion of the window
@@ -623,7 +681,8 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                 }
             }
         } else {
-            d[0] = P.cen[0] - x; d[1] = P.cen[1] - y; d[2] = P.cen[2] - z;
+            if (CHEAP) { d[0] = -x; d[1] = -y; d[2] = -z; }
+            else { d[0] = P.cen[0] - x; d[1] = P.cen[1] - y; d[2] = P.cen[2] - z; }
             // the ion's list in the primary table, and its bin in the fallback table (taken by the frames in which
             // a static atom moved beyond delta: that is known after the barrier)
             const int b = bin_of3<CELL>(P, x, y, z, g.pG0, g.pG1, g.pG2);
@@ -645,6 +704,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     const char *vh = (const char *)g.vh;
     const uint4 *pack = g.pack;
     const ExpK ek = expk_make(g.midpoint, g.steepness);
+    const double x0lo = g.x0lo;
     const int nvu = g.nv_uniform;
     const int hh = lane & (VP - 1), gi = lane >> LG;            // my vertex, my task of a pass
     const unsigned hh32 = (unsigned)hh << 5;
@@ -720,9 +780,17 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                 const double *sp = lds_f64(statoff + voff);
                 const double *op = lds_f64(ionoff);
                 double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];
-                wrapc3<CELL>(P, qx, qy, qz);
-                const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
-                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                double d2;
+                if (CHEAP) {
+                    // (the entry's threshold is the exact one plus the error bound of this distance: a candidate the
+                    // reference keeps is never dropped here, and D1 + E decides)
+                    qx = minimg1(qx, P.ci[0], P.cm[0]); qy = minimg1(qy, P.ci[4], P.cm[4]); qz = minimg1(qz, P.ci[8], P.cm[8]);
+                    d2 = (qx * qx + qy * qy) + qz * qz;
+                } else {
+                    wrapc3<CELL>(P, qx, qy, qz);
+                    const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
+                    d2 = (dx * dx + dy * dy) + dz * dz;
+                }
                 const unsigned long long km = __ballot(!(d2 > hk)) & vmask;
                 if (F3_LANES(km)) ttab[mask_rank(km, t_end)] = (en.x & KMASK) | (unsigned)ion;
                 t_end += __popcll(km);
@@ -788,6 +856,8 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     }
 }
 #undef F3_ASSIGN
+#undef F3_D1E_BODY
+#undef F3_TASK_OFFSETS
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 
@@ -840,6 +910,15 @@ static int fill3_basis_tables(sit_ctx *c)
     HIP_TRY(c, hipMemcpy(vcd.data(), c->d_vcd, (size_t)nsrc * 8, hipMemcpyDeviceToHost));
     std::vector<unsigned char> nv((size_t)c->D, 0);
     std::vector<unsigned> vh((size_t)(8 * n));
+    // CHEAP instantiations (diagonal cell): the error bounds of the minimum-image distance and of the logistic argument
+    // against the reference's arithmetic, u = 2^-53, L = the longest cell edge.  Per component the reference's shift,
+    // wrap and subtract make six roundings of at most L u each, ours two: |dd| <= 7.5 L u; on the squared distance
+    // |dd2| <= 2 sqrt(3) |d| 7.5 L u + 4 d2 u <= (26 L sqrt(d2) + 8 d2) u.  The bounds are applied four times over.
+    const double U53 = 0x1p-53;
+    double Lmax = 0.0;
+    for (int i = 0; i < 3; i++) Lmax = std::max(Lmax, std::fabs(c->pbc.cm[4 * i]));
+    double vcd_min = INFINITY, vcd_max = 0.0;
+    bool vcd_ok = true;
     for (i64 k = 0; k < c->D; k++) {
         int cnt = 0;
         for (i64 hh = 0; hh < vp3; hh++) {
@@ -849,14 +928,37 @@ static int fill3_basis_tables(sit_ctx *c)
             const double t2 = valid ? f3_exact_d2_threshold(vcd[src], c->rz) : INFINITY;
             const double rv = valid ? c->steepness / vcd[src] : -INFINITY;      // -inf: the term of a padded vertex is exactly 1
             const unsigned vi = valid ? (unsigned)v[src] : 0u;
-            unsigned long long tb, rb;
+            if (valid) {
+                if (!(vcd[src] > 0.0) || !std::isfinite(vcd[src])) vcd_ok = false;
+                else { vcd_min = std::min(vcd_min, vcd[src]); vcd_max = std::max(vcd_max, vcd[src]); }
+            }
+            // the threshold of the critical-vertex test on the cheap distance: nothing the reference keeps is dropped
+            double t2hi = t2;
+            if (std::isfinite(t2) && t2 > 0.0) t2hi = t2 + 4.0 * (26.0 * Lmax * std::sqrt(t2) + 8.0 * t2) * U53;
+            unsigned long long tb, rb, hb;
             memcpy(&tb, &t2, 8);
             memcpy(&rb, &rv, 8);
+            memcpy(&hb, &t2hi, 8);
             unsigned *r = &vh[8 * (size_t)(k * vp3 + hh)];
             r[0] = 24u * vi; r[1] = vi; r[2] = (unsigned)(tb & 0xffffffffull); r[3] = (unsigned)(tb >> 32);
-            r[4] = (unsigned)(rb & 0xffffffffull); r[5] = (unsigned)(rb >> 32); r[6] = 0u; r[7] = 0u;
+            r[4] = (unsigned)(rb & 0xffffffffull); r[5] = (unsigned)(rb >> 32);
+            r[6] = (unsigned)(hb & 0xffffffffull); r[7] = (unsigned)(hb >> 32);
         }
         nv[(size_t)k] = (unsigned char)cnt;
+    }
+    {
+        // x = steepness (t - midpoint) at the cut-off t = rz; our x = sqrt(d2') steepness / vcd - steepness midpoint:
+        // |d sqrt(d2)| = |dd2| / (2 sqrt(d2)) <= (13 L + 4 sqrt(d2)) u, times steepness / vcd; the one-step sqrt (4.2e-15),
+        // the rounding of steepness / vcd and the fma add 6e-15 of the product
+        const double x0 = c->steepness * (c->rz - c->midpoint), smid = c->steepness * c->midpoint;
+        c->f3_cheap_ok = c->cell_diagonal && vcd_ok && vcd_max > 0.0 && c->steepness > 0.0 && std::isfinite(c->steepness) &&
+                         std::isfinite(x0) && std::isfinite(smid) && Lmax > 0.0 && std::isfinite(Lmax);
+        if (c->f3_cheap_ok) {
+            const double srv_max = c->steepness / vcd_min, sd_max = 1.01 * std::fabs(c->rz) * vcd_max;
+            const double eps = 4.0 * (srv_max * (13.0 * Lmax + 4.0 * sd_max) * U53 + (std::fabs(x0) + std::fabs(smid) + 1.0) * 6e-15);
+            c->f3_x0lo = x0 - eps; c->f3_x0hi = x0 + eps;
+            if (!(eps < 1e-6 * (1.0 + std::fabs(x0)))) c->f3_cheap_ok = false;     // a wide band would send every pass the long way
+        }
     }
     c->nv_uniform = c->D > 0 ? (int)nv[0] : 0;                   // every landmark with the same number of vertices: no look-up
     for (i64 k = 1; k < c->D; k++) if (nv[(size_t)k] != nv[0]) { c->nv_uniform = 0; break; }
@@ -878,19 +980,20 @@ static int fill3_basis_tables(sit_ctx *c)
 
 // list entries as the kernel wants them, 16 bytes each: {landmark << ksh | critical vertex << 5 (the byte offset of that
 // vertex record in vh), 24 * its static id, its exact threshold} - a candidate test reads nothing else
-__global__ __launch_bounds__(256) void k_pack_lists(const i32 *list, const unsigned char *crit, i64 n, int ksh, const uint4 *vh, uint4 *out)
+// (hi: the threshold with the error bound of the cheap distance on top, from the record's last eight bytes)
+__global__ __launch_bounds__(256) void k_pack_lists(const i32 *list, const unsigned char *crit, i64 n, int ksh, const uint4 *vh, uint4 *out, int hi)
 {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const unsigned off = ((unsigned)list[i] << ksh) | ((unsigned)crit[i] << 5);
-    const uint4 r = vh[off >> 4];
-    out[i] = make_uint4(off, r.x, r.z, r.w);
+    const uint4 r = vh[off >> 4], r2 = vh[(off >> 4) + 1];
+    out[i] = hi ? make_uint4(off, r.x, r2.z, r2.w) : make_uint4(off, r.x, r.z, r.w);
 }
 
 // one array with the entries of the tight table (if there is one) followed by those of the loose table
-static int fill3_pack_lists(sit_ctx *c, bool have_tight)
+static int fill3_pack_lists(sit_ctx *c, bool have_tight, bool cheap)
 {
-    if (c->d_pack && c->pack_gen == c->table_gen && c->pack_tight == (have_tight ? 1 : 0)) return SIT_OK;
+    if (c->d_pack && c->pack_gen == c->table_gen && c->pack_tight == (have_tight ? 1 : 0) && c->pack_cheap == (cheap ? 1 : 0)) return SIT_OK;
     i32 nt = 0, nl = 0;
     const i64 nbl = (i64)c->G[0] * c->G[1] * c->G[2], nbt = (i64)c->tG[0] * c->tG[1] * c->tG[2];
     HIP_TRY(c, hipMemcpyAsync(&nl, c->d_bin_off + nbl, 4, hipMemcpyDeviceToHost, c->stream));
@@ -901,10 +1004,10 @@ static int fill3_pack_lists(sit_ctx *c, bool have_tight)
     if ((rc = dev_alloc(c, &c->d_pack, 4 * ((i64)nt + (i64)nl + 1)))) return rc;       // 16 bytes per entry
     uint4 *pk = (uint4 *)c->d_pack;
     const int ksh = (f3_vp(c) == 16 ? 4 : (f3_vp(c) == 8 ? 3 : 2)) + 5;
-    if (nt > 0) k_pack_lists<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_tbin_list, c->d_tbin_crit, nt, ksh, (const uint4 *)c->d_vh, pk);
-    if (nl > 0) k_pack_lists<<<dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_bin_list, c->d_bin_crit, nl, ksh, (const uint4 *)c->d_vh, pk + nt);
+    if (nt > 0) k_pack_lists<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_tbin_list, c->d_tbin_crit, nt, ksh, (const uint4 *)c->d_vh, pk, cheap ? 1 : 0);
+    if (nl > 0) k_pack_lists<<<dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_bin_list, c->d_bin_crit, nl, ksh, (const uint4 *)c->d_vh, pk + nt, cheap ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
-    c->pack_nt = nt; c->pack_gen = c->table_gen; c->pack_tight = have_tight ? 1 : 0;
+    c->pack_nt = nt; c->pack_gen = c->table_gen; c->pack_tight = have_tight ? 1 : 0; c->pack_cheap = cheap ? 1 : 0;
     return SIT_OK;
 }
 
@@ -981,7 +1084,9 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     int rc = fill3_prepare(c);
     if (rc) return rc;
     const bool have_tight = c->tight_delta >= 0;
-    if ((rc = fill3_pack_lists(c, have_tight))) return rc;
+    // the instantiations for a diagonal cell take the cheap distance (their list entries carry the widened threshold)
+    const bool diag = c->cell_diagonal && c->f3_cheap_ok && f3_env_int("SITATOR_F3_CHEAP", 1) != 0;
+    if ((rc = fill3_pack_lists(c, have_tight, diag))) return rc;
     // the fused assignment: narrow CSC columns only (the dense fall-back of the assignment has no merge), no dynamic
     // mapping, not an ablation run
     if (fuse && (p->dynamic_lattice_mapping || c->K <= 0 || !c->d_col_ptr || c->max_col > 24 || c->N >= (1LL << 31) ||
@@ -999,6 +1104,8 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     a.N = c->N; a.D = (int)c->D; a.W = (int)c->rows_W;
     a.check_zeros = p->check_for_zeros;
     a.midpoint = c->midpoint; a.steepness = c->steepness;
+    a.x0lo = c->f3_x0lo; a.x0hi = c->f3_x0hi;
+    if (f3_env_int("SITATOR_F3_FORCE_EXACT", 0)) { a.x0lo = -INFINITY; a.x0hi = INFINITY; }     // tests: every pass goes round again
     a.nv_uniform = f3_env_int("SITATOR_F3_NVU", 1) ? c->nv_uniform : 0;
 
     Fill3Head h;
@@ -1136,7 +1243,6 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
         HIP_TRY(c, hipMemcpyAsync(c->d_fill_args, c->fill_args_host.data(), sizeof(Fill3Args), hipMemcpyHostToDevice, c->stream));
     }
     const Fill3ArgsPtr full = (Fill3ArgsPtr)c->d_fill_args;
-    const bool diag = c->cell_diagonal;
     int contig = c->idx_contig ? 1 : 0;
     if (contig && c->idx_s0 == 0 && c->idx_m0 == S && c->A == S + M) contig = 2;
     { const int forced = f3_env_int("SITATOR_FILL_CONTIG", -1); if (forced >= 0 && forced < contig) contig = forced; }

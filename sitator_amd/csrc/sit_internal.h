@@ -73,12 +73,14 @@ struct sit_ctx {
     unsigned *d_pack = nullptr;       // list entries of the tight table, then of the loose table, as record offsets
     i64 pack_nt = 0;                  // entries of the tight part
     i64 table_gen = 0, pack_gen = -1; // pruning tables built so far (candidates.hip); the build d_pack was made from
-    int pack_tight = -1;
+    int pack_tight = -1, pack_cheap = -1;
     bool idx_contig = false;          // static_idx / mobile_idx are consecutive atom ranges
     i64 idx_s0 = 0, idx_m0 = 0;
     double hmin = 0;                  // smallest perpendicular height of the cell
     int last_kernel = 0, last_iw = 0, last_nw = 0, last_tt = 0;
     int nv_uniform = 0;               // > 0: every landmark has this many vertices
+    bool f3_cheap_ok = false;         // k_fill3 may decide on the logistic argument (diagonal cell, steepness > 0, vcd > 0)
+    double f3_x0lo = 0, f3_x0hi = 0;  // the argument at the cut-off -/+ the error bound of the kernel's
     bool last_fused = false;          // the last sit_fill assigned the narrow rows inside the fill kernel
     i32 *fuse_wlist = nullptr;        // ... and listed the others here (segments of the scratch buffer)
     unsigned *fuse_wcount = nullptr;

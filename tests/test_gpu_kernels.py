@@ -51,6 +51,31 @@ def test_fill_generations_agree(cfg, M, F):
         np.testing.assert_allclose(other, out[0], rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("cfg,M,F,dyn", [("C2", 64, 200, False), ("C5", 160, 40, False), ("C3", 448, 10, False),
+                                         ("C2", 64, 60, True)])
+def test_cheap_distance_and_reference_distance_agree(cfg, M, F, dyn, monkeypatch):
+    """Diagonal cells: k_fill3 takes the minimum-image distance and decides on the logistic argument; a lane inside the
+    error band of the cut-off sends its passes round again with the reference's arithmetic and the exact threshold.
+    SITATOR_F3_FORCE_EXACT=1 makes the band everything (every pass goes round again), SITATOR_F3_CHEAP=0 runs the
+    general-cell instantiation (the reference's arithmetic throughout): the same zero pattern, values within 1e-13."""
+    from sitator_amd import synth
+    host = synth.config_host(cfg)
+    ctx, *_ = _setup(host, M, F, seed=23, kernel="3")
+    out = []
+    for env in ({}, {"SITATOR_F3_FORCE_EXACT": "1"}, {"SITATOR_F3_CHEAP": "0"}):
+        for k in ("SITATOR_F3_FORCE_EXACT", "SITATOR_F3_CHEAP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rc, nz, err = ctx.fill(dynamic_lattice_mapping=dyn, check_for_zeros=False)
+        assert rc == 0 and ctx.info()["fill_kernel"] == 3
+        out.append((ctx.rows_dense(), nz))
+    for other, nz in out[1:]:
+        assert nz == out[0][1]
+        assert np.array_equal(out[0][0] != 0, other != 0)
+        np.testing.assert_allclose(other, out[0][0], rtol=1e-13, atol=0)
+
+
 @pytest.mark.parametrize("cfg,M,F,dyn", [("C2", 64, 150, False), ("C2", 64, 60, True), ("C1b", 4, 400, True),
                                          ("C5", 160, 30, False), ("C3", 448, 8, False)])
 def test_third_generation_rows_match_oracle(oracle, cfg, M, F, dyn):
