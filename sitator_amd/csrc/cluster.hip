@@ -926,6 +926,202 @@ __global__ __launch_bounds__(256) void k_gram(const i32 *nnz, const i32 *idx, co
     }
 }
 
+// ---- the same sums along the time axis (round 4) -------------------------------------------------------------------
+// The rows of a trajectory are frame-major (row = frame * M + ion), and an ion sits at one site for many frames: its
+// rows keep hitting the same handful of landmarks.  k_gram / k_weighted_row_sums pay one or two integer atomics per
+// term (C5: 2e8 and 1.4e8 of them on a few thousand addresses: 23 and 11 ms).  Here a thread follows ONE ion through a
+// chunk of RUN_R frames and keeps private 128-bit accumulators - in LDS, a column per thread - for the landmarks it
+// has met (RUN_S / WRS_S slots, found by comparing with the slot's landmark) and, for the Gram matrix, for every pair of
+// slots; they are flushed with the same integer atomics when the ion moves on to other landmarks (no free slot), at a
+// change of site (the row sums) and at the end of the chunk.  Integer sums: the result is the same bit for bit.
+#define RUN_S 12        // Gram: 66 pairs + 12 squares of 16 bytes per thread (C5 rows hold 6 landmarks on average, up to 13:
+                        // with 8 slots the ions' landmarks did not fit and every few rows flushed everything - no gain)
+#define WRS_S 16        // weighted row sums: a slot is 16 bytes
+#define RUN_R 64
+#define RUN_PAIRS (RUN_S * (RUN_S - 1) / 2)
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_gram_runs(const i32 *nnz, const i32 *idx, const double *val, i64 N, i64 M, i64 D,
+                                                  u64 *Ghi, u64 *Glo, u64 *seen)
+{
+    extern __shared__ __attribute__((aligned(16))) char kr_smem[];
+    // [RUN_PAIRS + RUN_S] accumulators of two words and RUN_S hit counts, a column per thread
+    u64 *ahi = (u64 *)kr_smem, *alo = ahi + (RUN_PAIRS + RUN_S) * NT;
+    unsigned *acnt = (unsigned *)(alo + (RUN_PAIRS + RUN_S) * NT);
+    const int t = threadIdx.x;
+    const i64 F = N / M, nch = (F + RUN_R - 1) / RUN_R;
+    const i64 gid = (i64)blockIdx.x * NT + t;
+    if (gid >= M * nch) return;                               // (no barrier in this kernel)
+    const i64 j = gid % M, f0 = (gid / M) * RUN_R, f1 = f0 + RUN_R < F ? f0 + RUN_R : F;
+    for (int q = 0; q < RUN_PAIRS + RUN_S; q++) { ahi[q * NT + t] = 0ull; alo[q * NT + t] = 0ull; }
+    for (int q = 0; q < RUN_S; q++) acnt[q * NT + t] = 0u;
+    i32 sd[RUN_S];
+#pragma unroll
+    for (int k = 0; k < RUN_S; k++) sd[k] = -1;
+    int nused = 0;
+    auto flush_all = [&]() {
+        for (int b = 0; b < nused; b++) {
+            i32 db = -1;
+#pragma unroll
+            for (int k = 0; k < RUN_S; k++) if (k == b) db = sd[k];
+            const unsigned cn = acnt[b * NT + t];
+            if (cn) { atomicAdd(&seen[db], (u64)cn); acnt[b * NT + t] = 0u; }
+            const int qd = RUN_PAIRS + b;
+            exact_flush(&Ghi[(i64)db * D + db], &Glo[(i64)db * D + db], ahi[qd * NT + t], alo[qd * NT + t]);
+            ahi[qd * NT + t] = 0ull; alo[qd * NT + t] = 0ull;
+            for (int a = 0; a < b; a++) {
+                i32 da = -1;
+#pragma unroll
+                for (int k = 0; k < RUN_S; k++) if (k == a) da = sd[k];
+                const int qp = b * (b - 1) / 2 + a;
+                const u64 h = ahi[qp * NT + t], l = alo[qp * NT + t];
+                if (h | l) {
+                    const i64 q = da < db ? (i64)da * D + db : (i64)db * D + da;      // the upper triangle
+                    exact_flush(&Ghi[q], &Glo[q], h, l);
+                    ahi[qp * NT + t] = 0ull; alo[qp * NT + t] = 0ull;
+                }
+            }
+        }
+        nused = 0;
+    };
+    for (i64 f = f0; f < f1; f++) {
+        const i64 row = f * M + j;
+        const int n = nnz[row];
+        const int ns = n < RUN_S ? n : RUN_S;
+        i32 de[RUN_S];
+        double ve[RUN_S];
+        int se[RUN_S];
+#pragma unroll
+        for (int e = 0; e < RUN_S; e++) {
+            de[e] = -1; ve[e] = 0.0; se[e] = 0;
+            if (e < ns) { de[e] = idx[(i64)e * N + row]; ve[e] = val[(i64)e * N + row]; }
+        }
+        // the slots of the row's landmarks; if they do not all fit beside what is held, everything held is flushed
+        for (int attempt = 0; attempt < 2; attempt++) {
+            bool over = false;
+#pragma unroll
+            for (int e = 0; e < RUN_S; e++) {
+                if (e < ns) {
+                    int sl = -1;
+#pragma unroll
+                    for (int k = 0; k < RUN_S; k++) if (k < nused && sd[k] == de[e]) sl = k;
+                    if (sl < 0) {
+                        if (nused < RUN_S) {
+                            sl = nused++;
+#pragma unroll
+                            for (int k = 0; k < RUN_S; k++) if (k == sl) sd[k] = de[e];
+                        } else over = true;
+                    }
+                    se[e] = sl;
+                }
+            }
+            if (!over) break;
+            flush_all();                                           // the second attempt starts from empty slots: ns <= RUN_S fit
+        }
+#pragma unroll
+        for (int e1 = 0; e1 < RUN_S; e1++) {
+            if (e1 < ns) {
+                const int s1 = se[e1];
+                acnt[s1 * NT + t] += 1u;
+                {
+                    u64 h = ahi[(RUN_PAIRS + s1) * NT + t], l = alo[(RUN_PAIRS + s1) * NT + t];
+                    exact_accumulate(h, l, ve[e1] * ve[e1]);
+                    ahi[(RUN_PAIRS + s1) * NT + t] = h; alo[(RUN_PAIRS + s1) * NT + t] = l;
+                }
+#pragma unroll
+                for (int e2 = e1 + 1; e2 < RUN_S; e2++) {
+                    if (e2 < ns) {
+                        const int s2 = se[e2];
+                        const int a = s1 < s2 ? s1 : s2, b = s1 < s2 ? s2 : s1;
+                        const int qp = b * (b - 1) / 2 + a;
+                        u64 h = ahi[qp * NT + t], l = alo[qp * NT + t];
+                        exact_accumulate(h, l, ve[e1] * ve[e2]);
+                        ahi[qp * NT + t] = h; alo[qp * NT + t] = l;
+                    }
+                }
+            }
+        }
+        // entries beyond the slots (rows wider than RUN_S): their terms go straight to the shared accumulators
+        for (int e2 = RUN_S; e2 < n; e2++) {
+            const i32 d2 = idx[(i64)e2 * N + row];
+            const double v2 = val[(i64)e2 * N + row];
+            atomicAdd(&seen[d2], 1ull);
+            for (int e1 = 0; e1 <= e2; e1++) {
+                const i32 d1 = idx[(i64)e1 * N + row];
+                exact_add(&Ghi[(i64)d1 * D + d2], &Glo[(i64)d1 * D + d2], val[(i64)e1 * N + row] * v2);
+            }
+        }
+    }
+    flush_all();
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_weighted_row_sums_runs(const i32 *nnz, const i32 *idx, const double *val, const i64 *labels,
+                                                               const double *confs, i64 N, i64 M, i64 D, i64 K, int weighted, u64 *hi, u64 *lo)
+{
+    extern __shared__ __attribute__((aligned(16))) char kr_smem[];
+    u64 *ahi = (u64 *)kr_smem, *alo = ahi + (WRS_S + 1) * NT;     // WRS_S slots and the weight, a column per thread
+    const int t = threadIdx.x;
+    const i64 F = N / M, nch = (F + RUN_R - 1) / RUN_R;
+    const i64 gid = (i64)blockIdx.x * NT + t;
+    if (gid >= M * nch) return;
+    const i64 j = gid % M, f0 = (gid / M) * RUN_R, f1 = f0 + RUN_R < F ? f0 + RUN_R : F;
+    for (int q = 0; q <= WRS_S; q++) { ahi[q * NT + t] = 0ull; alo[q * NT + t] = 0ull; }
+    i32 sd[WRS_S];
+#pragma unroll
+    for (int k = 0; k < WRS_S; k++) sd[k] = -1;
+    int nused = 0;
+    i64 cur = -1;
+    auto flush_slots = [&]() {
+        for (int b = 0; b < nused; b++) {
+            i32 db = -1;
+#pragma unroll
+            for (int k = 0; k < WRS_S; k++) if (k == b) db = sd[k];
+            exact_flush(&hi[cur * D + db], &lo[cur * D + db], ahi[b * NT + t], alo[b * NT + t]);
+            ahi[b * NT + t] = 0ull; alo[b * NT + t] = 0ull;
+        }
+        nused = 0;
+    };
+    auto flush_weight = [&]() {
+        exact_flush(&hi[K * D + cur], &lo[K * D + cur], ahi[WRS_S * NT + t], alo[WRS_S * NT + t]);
+        ahi[WRS_S * NT + t] = 0ull; alo[WRS_S * NT + t] = 0ull;
+    };
+    for (i64 f = f0; f < f1; f++) {
+        const i64 row = f * M + j;
+        const i64 l = labels[row];
+        if (l != cur) {
+            if (cur >= 0) { flush_slots(); flush_weight(); }
+            cur = (l < 0 || l >= K) ? -1 : l;
+            nused = 0;
+        }
+        if (cur < 0) continue;
+        const double w = weighted ? confs[row] : 1.0;
+        {
+            u64 h = ahi[WRS_S * NT + t], lw = alo[WRS_S * NT + t];
+            exact_accumulate(h, lw, w);
+            ahi[WRS_S * NT + t] = h; alo[WRS_S * NT + t] = lw;
+        }
+        const int n = nnz[row];
+        for (int e = 0; e < n; e++) {
+            const i32 d = idx[(i64)e * N + row];
+            const double x = w * val[(i64)e * N + row];
+            int sl = -1;
+#pragma unroll
+            for (int k = 0; k < WRS_S; k++) if (k < nused && sd[k] == d) sl = k;
+            if (sl < 0) {
+                if (nused == WRS_S) flush_slots();
+                sl = nused++;
+#pragma unroll
+                for (int k = 0; k < WRS_S; k++) if (k == sl) sd[k] = d;
+            }
+            u64 h = ahi[sl * NT + t], lw = alo[sl * NT + t];
+            exact_accumulate(h, lw, x);
+            ahi[sl * NT + t] = h; alo[sl * NT + t] = lw;
+        }
+    }
+    if (cur >= 0) { flush_slots(); flush_weight(); }
+}
+
 // copy 0 += copies 1 .. copies - 1 (128-bit integer sums, carries from the low word)
 __global__ void k_gram_fold(u64 *hi, u64 *lo, i64 n, int copies, i64 stride)
 {
@@ -975,7 +1171,18 @@ static int gram_impl(sit_ctx *c, double *G, u64 *hi, u64 *lo, i64 *seen)
     u64 *work = (u64 *)(dG + DD);
     HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(acc + D * 8), c->stream));
     StageTimer t(c, T_GRAM);
-    if (c->N > 0) {
+    const char *runs_env = getenv("SITATOR_RUNS");              // 0: the row-parallel kernels (tests compare the two)
+    const bool runs = !(runs_env && atoi(runs_env) == 0) && c->M > 0 && c->N % c->M == 0 && c->N / c->M >= 2;
+    if (c->N > 0 && runs) {
+        // along the time axis (above): one set of accumulators, far fewer atomics
+        constexpr int NT = 64;
+        const i64 nthreads = c->M * ((c->N / c->M + RUN_R - 1) / RUN_R);
+        const size_t lds = (size_t)NT * ((RUN_PAIRS + RUN_S) * 16 + RUN_S * 4);
+        HIP_TRY(c, lds_limit((const void *)k_gram_runs<NT>, lds, c->device));
+        k_gram_runs<NT><<<dim3((unsigned)((nthreads + NT - 1) / NT)), dim3(NT), lds, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, c->M, D, dhi, dlo, ds);
+        k_gram_mirror<<<dim3((unsigned)((DD + 255) / 256)), dim3(256), 0, c->stream>>>(dhi, dlo, D);
+        HIP_TRY(c, hipGetLastError());
+    } else if (c->N > 0) {
         if (D * 20 <= 60 * 1024)
             k_gram<true><<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), (size_t)D * 20, c->stream>>>(c->d_row_nnz, c->d_row_idx, c->d_row_val, c->N, D, dhi, dlo, ds, copies, DD);
         else
@@ -1114,7 +1321,10 @@ __global__ __launch_bounds__(256) void k_best_match_groups(const i32 *nnz, const
         }
         const double v = fabs(dot);
         const u64 key = isnan(v) ? ~0ull : (u64)__double_as_longlong(v);
-        if (pass == 0) atomicMax((unsigned long long *)&keymax[g], (unsigned long long)key);
+        // (a plain look first: the maximum only grows, so a key that does not beat what is already there - stale or
+        // not - can never become it; after the first rows of a group almost none does, and 3e7 contended atomics at
+        // C5 become a few thousand)
+        if (pass == 0) { if (key > __builtin_nontemporal_load(&keymax[g])) atomicMax((unsigned long long *)&keymax[g], (unsigned long long)key); }
         else if (key == keymax[g]) atomicMin((unsigned long long *)&rowmin[g], (unsigned long long)(row_offset + row));
     }
 }
@@ -1205,7 +1415,15 @@ static int weighted_row_sums_impl(sit_ctx *c, int weighted, i64 K, double *sums,
     double *dout = (double *)(dlo + n);
     u64 *work = (u64 *)(dout + n);
     HIP_TRY(c, hipMemsetAsync(c->d_scratch, 0, (size_t)(n * 16), c->stream));
-    if (c->N > 0) {
+    const char *runs_env = getenv("SITATOR_RUNS");
+    if (c->N > 0 && !(runs_env && atoi(runs_env) == 0) && c->M > 0 && c->N % c->M == 0 && c->N / c->M >= 2) {
+        constexpr int NT = 128;
+        const i64 nthreads = c->M * ((c->N / c->M + RUN_R - 1) / RUN_R);
+        HIP_TRY(c, lds_limit((const void *)k_weighted_row_sums_runs<NT>, (size_t)NT * (WRS_S + 1) * 16, c->device));
+        k_weighted_row_sums_runs<NT><<<dim3((unsigned)((nthreads + NT - 1) / NT)), dim3(NT), (size_t)NT * (WRS_S + 1) * 16, c->stream>>>(
+            c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs, c->N, c->M, D, K, weighted, dhi, dlo);
+        HIP_TRY(c, hipGetLastError());
+    } else if (c->N > 0) {
         k_weighted_row_sums<<<dim3((unsigned)((c->N + 255) / 256)), dim3(256), 0, c->stream>>>(
             c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs, c->N, D, K, weighted, dhi, dlo);
         HIP_TRY(c, hipGetLastError());

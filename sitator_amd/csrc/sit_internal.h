@@ -399,14 +399,15 @@ __device__ __forceinline__ void list_rows_by_class(bool ca, bool cb, i64 row, i3
 // value, so exactly the adder that wraps it carries one into the high word.  Integer addition commutes: the
 // result does not depend on scheduling, on the number of workgroups, or (added up across ranks) on the number of
 // GPUs.  Range |sum| < 2^47.
-__device__ __forceinline__ void exact_add(u64 *hi, u64 *lo, double v)
+// the 128-bit two's-complement fixed-point image of v (zero for 0 and NaN)
+__device__ __forceinline__ void exact_fixed(double v, u64 &xhi, u64 &xlo)
 {
+    xlo = 0; xhi = 0;
     if (v == 0.0 || !(v == v)) return;
     int e;
     const double m = frexp(fabs(v), &e);                  // |v| = m 2^e, m in [0.5, 1)
     const u64 mant = (u64)ldexp(m, 53);                   // 53-bit integer
     const int sh = e + 27;                                // |v| 2^80 = mant 2^sh
-    u64 xlo = 0, xhi = 0;
     if (sh >= 64) xhi = sh < 128 ? mant << (sh - 64) : 0;
     else if (sh > 0) { xlo = mant << sh; xhi = mant >> (64 - sh); }
     else if (sh == 0) xlo = mant;
@@ -415,9 +416,28 @@ __device__ __forceinline__ void exact_add(u64 *hi, u64 *lo, double v)
         xhi = ~xhi + (xlo == 0 ? 1ull : 0ull);
         xlo = ~xlo + 1ull;
     }
+}
+// (xhi, xlo) - one value's image or a locally accumulated sum of images - into the shared pair
+__device__ __forceinline__ void exact_flush(u64 *hi, u64 *lo, u64 xhi, u64 xlo)
+{
     u64 carry = 0;
     if (xlo) { const u64 old = atomicAdd(lo, xlo); carry = (old + xlo) < old ? 1ull : 0ull; }
     if (xhi + carry) atomicAdd(hi, xhi + carry);
+}
+// a private 128-bit accumulator += the image of v
+__device__ __forceinline__ void exact_accumulate(u64 &ahi, u64 &alo, double v)
+{
+    u64 xhi, xlo;
+    exact_fixed(v, xhi, xlo);
+    const u64 s = alo + xlo;
+    ahi += xhi + (s < alo ? 1ull : 0ull);
+    alo = s;
+}
+__device__ __forceinline__ void exact_add(u64 *hi, u64 *lo, double v)
+{
+    u64 xhi, xlo;
+    exact_fixed(v, xhi, xlo);
+    exact_flush(hi, lo, xhi, xlo);
 }
 
 // (hi, lo) of exact_add as a double: two roundings (the low word's conversion and the final sum), both deterministic

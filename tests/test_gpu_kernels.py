@@ -878,3 +878,27 @@ def test_stage_timer_totals_and_prefaulted_read_back():
     again = ctx.predict(0.8)
     assert len(again[0]) == ctx.N and all(np.array_equal(a, b) for a, b in zip(again, fresh))
     ctx.close()
+
+
+@pytest.mark.parametrize("cfg,M,F", [("C5", 160, 150), ("C1b", 4, 700), ("C2", 64, 130)])
+def test_mcl_reductions_along_the_time_axis_equal_the_row_parallel_ones(oracle, cfg, M, F, monkeypatch):
+    """k_gram_runs / k_weighted_row_sums_runs (a thread follows an ion through 64 frames with private accumulators,
+    flushed when its landmarks or its site change) against the row-parallel kernels (SITATOR_RUNS=0): the same exact
+    integers, limb for limb - on rows wider than the eight slots too (C5)."""
+    from sitator_amd import synth
+    host = synth.config_host(cfg)
+    ctx, frames, sm, mm, ref = _setup(host, M, F, seed=31)
+    assert ctx.fill()[0] == 0
+    X = ctx.rows_dense()
+    if cfg == "C5":
+        assert np.count_nonzero(X, axis=1).max() > 8, "no row wider than the slots"
+    cen = oracle.fit_centers(X[:4000], 0.45)
+    ctx.set_centers(cen / np.linalg.norm(cen, axis=1)[:, None], True)
+    ctx.predict(0.8)
+    out = []
+    for runs in ("0", "1"):
+        monkeypatch.setenv("SITATOR_RUNS", runs)
+        out.append((ctx.gram_limbs(), ctx.weighted_row_sums_limbs(len(cen)), ctx.weighted_row_sums_limbs(len(cen), weighted=False)))
+    for a, b in zip(out[0], out[1]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
