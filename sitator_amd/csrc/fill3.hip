@@ -66,6 +66,9 @@ struct Fill3Args {
     unsigned f_base;                  // first fallback entry in pack
     int check_zeros;
     double midpoint, steepness;
+    u64 *err, *scal;                  // error key, counters (here, not in the by-value head: kernel arguments are loaded
+    i64 frame0;                       //   at the top of the kernel and then sit in - or are spilled from - scalar registers)
+    double cen[3];                    // the cell's centroid for the instantiations that need it on rare paths only (CHEAP)
     double x0lo, x0hi;                // CHEAP: the logistic argument at the cut-off, minus / plus the error bound of ours
     int nv_uniform;                   // > 0: every landmark has this many vertices (nvtab is not read)
     // ---- fused site assignment (FUSE = 1) ----
@@ -88,8 +91,7 @@ struct Fill3Head {
     const double *ref_static;
     const double *frame_dmax;
     const double *exptab;
-    u64 *err, *scal;
-    i64 F, A, frame0, fbeg;           // the launch covers frames [fbeg, F)
+    i64 F, A, fbeg;                   // the launch covers frames [fbeg, F)
     int S, M, fpb, contig, debug_stop, rcap, iw, has_fallback, s0, m0, tt, mcap, frame_mod;
     double delta2, thr2_lo, thr2_hi, static_thr, safe2;
 };
@@ -362,10 +364,11 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
                 bad_[u] = 0ull;                                                                                            \
             } else {                                                                                                       \
                 double ox = op[0], oy = op[1], oz = op[2];                                                                 \
-                if (CHEAP) { ox = P.cen[0] + ox; oy = P.cen[1] + oy; oz = P.cen[2] + oz; }                                 \
+                const double c0_ = CHEAP ? g.cen[0] : P.cen[0], c1_ = CHEAP ? g.cen[1] : P.cen[1], c2_ = CHEAP ? g.cen[2] : P.cen[2]; \
+                if (CHEAP) { ox = c0_ + ox; oy = c1_ + oy; oz = c2_ + oz; }                                                \
                 double qx = sp[0] + ox, qy = sp[1] + oy, qz = sp[2] + oz;                                                  \
                 wrapc3<CELL>(P, qx, qy, qz);                                                                               \
-                const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];                                   \
+                const double dx = qx - c0_, dy = qy - c1_, dz = qz - c2_;                                                  \
                 d2_[u] = (dx * dx + dy * dy) + dz * dz;                                                                    \
                 bad_[u] = __ballot(d2_[u] > __hiloint2double((int)r0.w, (int)r0.z)) | ~first_lanes((t_end - tb) << LG);   \
             }                                                                                                              \
@@ -446,7 +449,7 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
             if (nz && to_rows) {                                                                                           \
                 const i64 row = f0 * M + ib0 + (i64)ion;                  /* rows are frame-major */                       \
                 if (e < g.W) { g.row_idx[(i64)e * g.N + row] = (i32)(kk >> KSH); g.row_val[(i64)e * g.N + row] = val; }  \
-                else atomicAdd(&h.scal[3], 1ull);                                                                          \
+                else atomicAdd(&g.scal[3], 1ull);                                                                          \
             }                                                                                                              \
             if (keep) prod[lane] = val;                                                                                    \
             if (next != ion) nzc[ion] = keep ? ((unsigned)start << 8) | (unsigned)(e + 1) : (unsigned)(e + (nz ? 1 : 0)); \
@@ -502,7 +505,7 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
         if (act && !wsp && n > 4 && !g.store) {                                                                            \
             for (int e = 0; e < n; e++) {                                                                                  \
                 if (e < g.W) { g.row_idx[(i64)e * g.N + row] = (i32)(svq[e] >> KSH); g.row_val[(i64)e * g.N + row] = pq[e]; } \
-                else atomicAdd(&h.scal[3], 1ull);                                                                          \
+                else atomicAdd(&g.scal[3], 1ull);                                                                          \
             }                                                                                                              \
             g.row_nnz[row] = n < g.W ? n : g.W;                                                                            \
         }                                                                                                                  \
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     const Fill3Args __attribute__((address_space(4))) &g = *full;
 
     if ((unsigned)(size_t)(__attribute__((address_space(3))) char *)smem != 0u) {      // lds_f64: never (no static LDS)
-        if (tid == 0) atomicMin(h.err, 0ull);
+        if (tid == 0) atomicMin(g.err, 0ull);
         return;
     }
     if (tid < fpb) fmax[tid] = 0ull;
@@ -669,14 +672,15 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                 if (!(e2 <= h.safe2)) {
                     // PBCCalculator.distances(ref, atom) (util/PBCCalculator.pyx:64-103), squared; the sqrt is
                     // taken only inside the rounding band around static_movement_threshold^2
-                    double qx = x + (P.cen[0] - rx), qy = y + (P.cen[1] - ry), qz = z + (P.cen[2] - rz_);
+                    const double c0 = CHEAP ? g.cen[0] : P.cen[0], c1 = CHEAP ? g.cen[1] : P.cen[1], c2 = CHEAP ? g.cen[2] : P.cen[2];
+                    double qx = x + (c0 - rx), qy = y + (c1 - ry), qz = z + (c2 - rz_);
                     wrapc3<CELL>(P, qx, qy, qz);
-                    const double dx = -qx + P.cen[0], dy = -qy + P.cen[1], dz = -qz + P.cen[2];
+                    const double dx = -qx + c0, dy = -qy + c1, dz = -qz + c2;
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
                     if (d2 > h.delta2) {
                         atomicOr(&fmax[fl], 1ull);
                         if (d2 > h.thr2_lo && (d2 > h.thr2_hi || sqrt(d2) > h.static_thr))
-                            atomicMin(h.err, (u64)(h.frame0 + f0 + fl) * errw + (u64)r);
+                            atomicMin(g.err, (u64)(g.frame0 + f0 + fl) * errw + (u64)r);
                     }
                 }
             }
@@ -696,7 +700,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     // fmax[fl] != 0: some static atom of frame fl moved beyond delta -> the frame takes the fallback table
     if (tid < nf && h.has_fallback) {
         const bool tight = DYN ? (h.frame_dmax[f0 + tid] * h.frame_dmax[f0 + tid] <= h.delta2) : (fmax[tid] == 0ull);
-        if (!tight) atomicAdd(&h.scal[2], 1ull);
+        if (!tight) atomicAdd(&g.scal[2], 1ull);
     }
     if (dbg == 1) return;
 
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
         }
         const int inL = wave_add_scan(nL), exL = inL - nL;
         const int nlt = __builtin_amdgcn_readlane(inL, 63);     // candidate tasks of the window
-        if (nlt > h.mcap) { if (lane == 0) atomicAdd(&h.scal[3], 1ull); break; }      // cannot happen (host sizes mcap)
+        if (nlt > h.mcap) { if (lane == 0) atomicAdd(&g.scal[3], 1ull); break; }      // cannot happen (host sizes mcap)
         for (int q = 4 * lane; q < nlt; q += 256) *(unsigned *)(mark + q) = 0u;
         if (lane < nib) {
             if (nL > 0) mark[exL] = (unsigned char)lane;
@@ -747,7 +751,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
             else ((uint4 *)ionrec)[lane] = make_uint4(lo - (unsigned)exL, 24u * (unsigned)(fl * SM + S + j), 24u * (unsigned)(fl * SM), (unsigned)fl);
             nzc[lane] = 0u;
         }
-        if (DBG && dbg == 9 && lane == 0) { atomicAdd(&h.scal[5], (u64)nlt); atomicAdd(&h.scal[7], 1ull); }
+        if (DBG && dbg == 9 && lane == 0) { atomicAdd(&g.scal[5], (u64)nlt); atomicAdd(&g.scal[7], 1ull); }
         const unsigned ionbase = xyz_s + 24u * (unsigned)ib0;   // FPB1: byte offset of the window's first offset vector
         int t_end = 0, carry = 0, cnt = 0;
         spilled = false;
@@ -796,7 +800,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                 t_end += __popcll(km);
             }
             if (t_end <= TT - 64 && base + 64 < nlt0) continue;         // room for another pass of candidates
-            if (DBG && dbg == 9 && lane == 0) atomicAdd(&h.scal[4], (u64)t_end);
+            if (DBG && dbg == 9 && lane == 0) atomicAdd(&g.scal[4], (u64)t_end);
             if (DBG && dbg == 3) t_end = 0;                     // ablation: stop after the critical-vertex test
             // ---- the task table is drained: passes of TPP tasks over [0, t_end) ----
             const int pend = (t_end + TPP - 1) / TPP;
@@ -816,7 +820,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                         cursor += 1;
                     }
                 }
-                if (DBG && dbg == 9 && lane == 0) atomicAdd(&h.scal[6], (u64)cnt);
+                if (DBG && dbg == 9 && lane == 0) atomicAdd(&g.scal[6], (u64)cnt);
                 if (cursor < pend) F3_T_ROUND(0);               // the list is full: its entries leave for the row buffers
             }
             t_end = 0;
@@ -830,8 +834,8 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
             const i64 row = (f0 + fl) * M + j;
             if (!FUSE || spilled || g.store) g.row_nnz[row] = nnz < g.W ? nnz : g.W;
             if (nnz == 0) {                                               // helpers.pyx:116-120
-                if (g.check_zeros) atomicMin(h.err, (u64)(h.frame0 + f0 + fl) * errw + (u64)(S + 1 + j));
-                else atomicAdd(&h.scal[0], 1ull);
+                if (g.check_zeros) atomicMin(g.err, (u64)(g.frame0 + f0 + fl) * errw + (u64)(S + 1 + j));
+                else atomicAdd(&g.scal[0], 1ull);
             }
         }
     }
@@ -1057,7 +1061,7 @@ struct F3Tuned { i64 key[8]; int rcap, tt; };
 static std::mutex g_f3_mutex;
 static std::vector<F3Tuned> g_f3_tuned;
 
-#define F3_ARGS_BYTES 1024          // the argument block; the counters of the trial launches sit behind it
+#define F3_ARGS_BYTES 1024          // the argument block; a copy for the trial launches and their counters sit behind it
 #define F3_TRIAL_WORDS 17
 
 // Everything fill3_launch allocates that does not depend on the pruning tables, ahead of time (the pipelined call:
@@ -1067,7 +1071,7 @@ int fill3_prepare(sit_ctx *c)
     int rc = fill3_basis_tables(c);
     if (rc) return rc;
     if (!c->d_fill_args) {
-        if ((rc = dev_alloc(c, &c->d_fill_args, (i64)(F3_ARGS_BYTES + F3_TRIAL_WORDS * 8)))) return rc;
+        if ((rc = dev_alloc(c, &c->d_fill_args, (i64)(2 * F3_ARGS_BYTES + F3_TRIAL_WORDS * 8)))) return rc;
         c->fill_args_host.clear();
     }
     return SIT_OK;
@@ -1105,6 +1109,8 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     a.check_zeros = p->check_for_zeros;
     a.midpoint = c->midpoint; a.steepness = c->steepness;
     a.x0lo = c->f3_x0lo; a.x0hi = c->f3_x0hi;
+    a.err = c->d_err; a.scal = c->d_scal; a.frame0 = c->frame0;
+    for (int i = 0; i < 3; i++) a.cen[i] = c->pbc.cen[i];
     if (f3_env_int("SITATOR_F3_FORCE_EXACT", 0)) { a.x0lo = -INFINITY; a.x0hi = INFINITY; }     // tests: every pass goes round again
     a.nv_uniform = f3_env_int("SITATOR_F3_NVU", 1) ? c->nv_uniform : 0;
 
@@ -1114,7 +1120,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     h.ref_static = c->d_ref_static;
     h.frame_dmax = p->dynamic_lattice_mapping ? c->d_frame_dmax : nullptr;
     h.exptab = c->d_exptab;
-    h.err = c->d_err; h.scal = c->d_scal; h.F = f_hi; h.fbeg = f_lo; h.A = c->A; h.frame0 = c->frame0;
+    h.F = f_hi; h.fbeg = f_lo; h.A = c->A;
     h.S = (int)S; h.M = (int)M;
     const bool dynmap = a.lattice_map != nullptr;
     h.debug_stop = dynmap ? 0 : f3_env_int("SITATOR_DEBUG_STOP", 0);
@@ -1280,8 +1286,11 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
             // the trial launches write the rows of the leading frames (the launch proper writes them again) but report
             // into words of their own: errors and counts of earlier launches of a pipelined call stay untouched
             Fill3Head ht = h;
-            ht.err = (u64 *)(c->d_fill_args + F3_ARGS_BYTES); ht.scal = ht.err + 1;
-            HIP_TRY(c, hipMemsetAsync(ht.err, 0, F3_TRIAL_WORDS * 8, c->stream));
+            Fill3Args at = a;                                      // (a pageable copy: the call returns when it is staged)
+            at.err = (u64 *)(c->d_fill_args + 2 * F3_ARGS_BYTES); at.scal = at.err + 1;
+            HIP_TRY(c, hipMemsetAsync(at.err, 0, F3_TRIAL_WORDS * 8, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->d_fill_args + F3_ARGS_BYTES, &at, sizeof(Fill3Args), hipMemcpyHostToDevice, c->stream));
+            const Fill3ArgsPtr full_t = (Fill3ArgsPtr)(c->d_fill_args + F3_ARGS_BYTES);
             ht.F = std::min<i64>(f_hi, f_lo + (i64)4096 * fpb);               // the leading frames: ~3 rounds of workgroups
             const unsigned gt = (unsigned)((ht.F - f_lo + fpb - 1) / fpb);
             float best = 1e30f;
@@ -1298,7 +1307,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
                 float tq = 1e30f;
                 for (int rep = 0; rep < 5; rep++) {                            // the first launch of a shape warms it up; best of four
                     HIP_TRY(c, hipEventRecord(e0, c->stream));
-                    HIP_TRY(c, f3_dispatch(c, ht, full, gt, ldq, nw, vp, diag, dynmap, false));
+                    HIP_TRY(c, f3_dispatch(c, ht, full_t, gt, ldq, nw, vp, diag, dynmap, false));
                     HIP_TRY(c, hipEventRecord(e1, c->stream));
                     HIP_TRY(c, hipEventSynchronize(e1));
                     float ms = 0;
