@@ -2,6 +2,7 @@
 # VALU / LDS / wave-cycle counters of the fill kernel per ablation stage: scratch/pmc_stages.sh <outdir> [frames] [config]
 out=$1; F=${2:-20000}; cfg=${3:-C2}
 cd /tmp && export TMPDIR=/tmp
+export SITATOR_FILL_AUTOTUNE=0      # the 60-us shape trials would be averaged in with the launches proper
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/$out
 for stop in 1 2 3 4 5 0; do
@@ -17,5 +18,7 @@ for stop in (1, 2, 3, 4, 5, 0):
             if "k_fill" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
         ions = $F * {"C2": 64, "C3": 448, "C4": 256, "C5": 160, "C1": 4}["$cfg"]
+        # (these passes see 0.05 waves per ion at C2 where 1 / 16 run: scale a row by 0.0625 / SQ_WAVES to compare it with
+        # the counter passes of bench.py)
         print("stop", stop, {c: round(x / n[c] / ions, 2) for c, x in agg.items()})
 PY

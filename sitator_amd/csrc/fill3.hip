@@ -535,11 +535,14 @@ __device__ __forceinline__ double dpp_row_shl(double x)
 // 0 = arbitrary index lists.
 // F3_WPE waves per SIMD: the register budget (the scalar registers are what binds: 96 allow seven waves per SIMD - the
 // LDS allows seven workgroups of four per CU - where the compiler, left alone, takes 106 and gets six)
+// Sixteen-wave workgroups (big frames: C3, C4 - two workgroups per CU by their LDS) are built for EIGHT waves per SIMD
+// (64 vector / 80 scalar registers, ~30 scalar spills): 2 x 16 waves are resident where 2 x 8 were, -6.5 % at C3 and
+// C4; the four- and eight-wave instantiations lose 4 % with that budget (C2: their seventh workgroup is there already).
 #ifndef F3_WPE
 #define F3_WPE 7
 #endif
 #if F3_WPE > 0
-#define F3_WPE_ATTR __attribute__((amdgpu_waves_per_eu(F3_WPE, F3_WPE)))
+#define F3_WPE_ATTR __attribute__((amdgpu_waves_per_eu(NW == 16 ? 8 : F3_WPE, NW == 16 ? 8 : F3_WPE)))
 #else
 #define F3_WPE_ATTR
 #endif
@@ -1180,17 +1183,24 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
         // C5 4 x 6.
         while (fpb > 1 && lds_bytes(4, fpb, rcap) > 53 * 1024) fpb--;
         auto per_wave = [&](int nwv) { const i64 v = ((i64)(nwv == 4 ? fpb : 1) * M + nwv - 1) / nwv; return v > 64 ? (i64)64 : v; };
-        const i64 want = std::min<i64>(32, per_wave(4));
         int best = 4;
         i64 best_waves = -1;
         for (int nwv : {4, 8, 16}) {
-            const size_t b = (lds_bytes(nwv, nwv == 4 ? fpb : 1, rcap) + 1535) / 1024 * 1024;
-            if (b > 160 * 1024) continue;
-            i64 wgs = (i64)((160 * 1024) / b);
-            if (wgs > 8) wgs = 8;
-            i64 waves = wgs * nwv;
-            if (waves > 32) waves = 32;
+            // windows of >= 32 ions (16 for sixteen waves), or what four waves would get if that is less
+            const i64 want = std::min<i64>(nwv == 16 ? 16 : 32, per_wave(4));
             if (per_wave(nwv) < want && nwv != 4) continue;
+            // resident waves: workgroups by their LDS (with fewer survivor slots if that admits one more, as below),
+            // whole workgroups within the register budget (seven waves per SIMD; eight for the sixteen-wave build)
+            i64 waves = -1;
+            for (int r : {rcap, 40, 32}) {
+                if (r != rcap && !(rcap_auto && r >= 64 / vp && r < rcap)) continue;
+                const size_t b = (lds_bytes(nwv, nwv == 4 ? fpb : 1, r) + 1535) / 1024 * 1024;
+                if (b > 160 * 1024) continue;
+                i64 wgs = (i64)((160 * 1024) / b);
+                if (wgs > 8) wgs = 8;
+                const i64 cap = (nwv == 16 ? 32 : 28) / nwv;
+                waves = std::max(waves, std::min(wgs, cap) * nwv);
+            }
             if (waves > best_waves) { best_waves = waves; best = nwv; }
         }
         if (best_waves < 0) best = 16;                              // not even one workgroup of four or eight waves fits
@@ -1200,7 +1210,11 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     if (rcap_auto) {
         // fewer survivor slots per wave when that admits one more workgroup per CU (a full region only costs a round)
         // (workgroups are admitted with some slack: 5 x 31.5 KB did not run five per CU, 5 x 29.5 KB did)
-        auto wg_per_cu = [&](int r) { const size_t b = (lds_bytes(nw, fpb, r) + 1535) / 1024 * 1024; size_t k = (160 * 1024) / b; return k > 8 ? (size_t)8 : k; };
+        auto wg_per_cu = [&](int r) {
+            const size_t b = (lds_bytes(nw, fpb, r) + 1535) / 1024 * 1024, cap = (size_t)((nw == 16 ? 32 : 28) / nw);   // LDS, registers
+            const size_t k = (160 * 1024) / b;
+            return k > cap ? cap : k;
+        };
         for (int r : {40, 32}) if (r >= 64 / vp && wg_per_cu(r) > wg_per_cu(rcap)) rcap = r;
     }
     if (tt_auto) {
