@@ -16,7 +16,7 @@ frames = gen.generate(F)
 sn = SiteNetwork(Structure(ref, host.cell), gen.static_mask, gen.mobile_mask); sn.centers = host.centers; sn.vertices = host.vertices
 kw = {"clustering_algorithm": "mcl", "max_mobile_per_site": 2} if cfg == "C5" and os.environ.get("SWEEP_MCL") else {}
 la = LandmarkAnalysis(verbose=False, **kw)
-la.run(sn, np.ascontiguousarray(frames[:min(F, 20000)]))
+la.run(sn, np.ascontiguousarray(frames[:min(F, int(os.environ.get("SWEEP_FIT_FRAMES", "20000")))]))
 centers = np.asarray(la.cluster_centers_)
 ctx = _lib.HipContext(host.cell)
 ref_static = ref[gen.static_mask]
