@@ -50,8 +50,10 @@
 // loaded where they are used)
 struct Fill3Args {
     const uint4 *vh;                  // [D,Vp] 32-byte records {24 * static id (byte offset of the vertex in a frame),
-                                      //   static id, exact squared-distance threshold (+inf on padding), steepness / vcd (-inf on
-                                      //   padding: the factor of a padded vertex is exactly 1), 8 bytes unused}
+                                      //   static id, steepness / vcd (-inf on padding: the factor of a padded vertex is
+                                      //   exactly 1) - what a (task, vertex) lane needs, one 16-byte gather -, the exact
+                                      //   squared-distance threshold (+inf on padding), the same plus the error bound of
+                                      //   the cheap distance}
     const unsigned char *nvtab;       // [D]
     const uint4 *pack;                // list entries of the primary table, then of the fallback table, 16 bytes each:
                                       // {landmark << (LG + 5) | critical vertex << 5 = byte offset of that record in vh,
@@ -347,14 +349,12 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
             const int tb = TPP * (cursor + u);                                                                             \
             tk_[u] = ttab[tb + gi];                                                                                        \
             const char *rp = vh + ((tk_[u] & KMASK) | hh32);                                                               \
-            uint4 r0 = make_uint4(0u, 0u, 0u, 0u);                                                                         \
-            if (!APPROX) r0 = *(const uint4 *)rp;                                                                          \
-            else if (DYN) { const uint2 t2 = *(const uint2 *)rp; r0.x = t2.x; r0.y = t2.y; }                               \
-            else r0.x = *(const unsigned *)rp;                                                                             \
-            const uint2 r1 = *(const uint2 *)(rp + 16);                                                                    \
+            const uint4 r0 = *(const uint4 *)rp;                     /* offset, static id, steepness / vcd: ONE gather */  \
+            uint2 r1 = make_uint2(0u, 0u);                                                                                 \
+            if (!APPROX) r1 = *(const uint2 *)(rp + 16);             /* the exact threshold */                             \
             unsigned voff, ionoff, statoff;                                                                                \
             F3_TASK_OFFSETS(tk_[u], r0.x, r0.y, voff, ionoff, statoff);                                                    \
-            rv_[u] = __hiloint2double((int)r1.y, (int)r1.x);                                                               \
+            rv_[u] = __hiloint2double((int)r0.w, (int)r0.z);                                                               \
             const double *sp = lds_f64(statoff + voff);                                                                    \
             const double *op = lds_f64(ionoff);                                                                            \
             if (APPROX) {                                                                                                  \
@@ -370,7 +370,7 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
                 wrapc3<CELL>(P, qx, qy, qz);                                                                               \
                 const double dx = qx - c0_, dy = qy - c1_, dz = qz - c2_;                                                  \
                 d2_[u] = (dx * dx + dy * dy) + dz * dz;                                                                    \
-                bad_[u] = __ballot(d2_[u] > __hiloint2double((int)r0.w, (int)r0.z)) | ~first_lanes((t_end - tb) << LG);   \
+                bad_[u] = __ballot(d2_[u] > __hiloint2double((int)r1.y, (int)r1.x)) | ~first_lanes((t_end - tb) << LG);   \
             }                                                                                                              \
         }                                                                                                                  \
         if (!(DBG && dbg == 4)) {                                                                                          \
@@ -947,8 +947,8 @@ static int fill3_basis_tables(sit_ctx *c)
             memcpy(&rb, &rv, 8);
             memcpy(&hb, &t2hi, 8);
             unsigned *r = &vh[8 * (size_t)(k * vp3 + hh)];
-            r[0] = 24u * vi; r[1] = vi; r[2] = (unsigned)(tb & 0xffffffffull); r[3] = (unsigned)(tb >> 32);
-            r[4] = (unsigned)(rb & 0xffffffffull); r[5] = (unsigned)(rb >> 32);
+            r[0] = 24u * vi; r[1] = vi; r[2] = (unsigned)(rb & 0xffffffffull); r[3] = (unsigned)(rb >> 32);
+            r[4] = (unsigned)(tb & 0xffffffffull); r[5] = (unsigned)(tb >> 32);
             r[6] = (unsigned)(hb & 0xffffffffull); r[7] = (unsigned)(hb >> 32);
         }
         nv[(size_t)k] = (unsigned char)cnt;
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256) void k_pack_lists(const i32 *list, const unsig
     if (i >= n) return;
     const unsigned off = ((unsigned)list[i] << ksh) | ((unsigned)crit[i] << 5);
     const uint4 r = vh[off >> 4], r2 = vh[(off >> 4) + 1];
-    out[i] = hi ? make_uint4(off, r.x, r2.z, r2.w) : make_uint4(off, r.x, r.z, r.w);
+    out[i] = hi ? make_uint4(off, r.x, r2.z, r2.w) : make_uint4(off, r.x, r2.x, r2.y);
 }
 
 // one array with the entries of the tight table (if there is one) followed by those of the loose table
