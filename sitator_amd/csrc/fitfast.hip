@@ -116,6 +116,14 @@ struct FS {
     int newcap;               // new rows k_fs_found takes per step (SITATOR_FF_NEWCAP)
 };
 
+// The kernels read the state block and the row arrays through scalar loads from a device copy (FSArgs) instead of
+// taking the structs by value: kernel arguments are loaded at the top of a kernel and then sit in - or are spilled
+// from - scalar registers all the way (round 4: k_fs_found had 197 scalar spills and 17 vector ones, k_fs_walk 138).
+struct FSArgs { FS s; FSRows r; double threshold; };
+typedef const FS __attribute__((address_space(4))) &FSRef;
+typedef const FSRows __attribute__((address_space(4))) &FSRowsRef;
+typedef const FSArgs __attribute__((address_space(4))) *FSArgsPtr;
+
 #define OV(s, j, p) (s).ov_id[(i64)(p) * FS_BMAX + (j)]     // slot-major: coalesced across rows
 
 // ---- small wave helpers ---------------------------------------------------------------------------------
@@ -253,7 +261,7 @@ struct Row {
 };
 
 template <int NR>
-__device__ __forceinline__ void row_load(Row<NR> &R, const FSRows &r, i64 row)
+__device__ __forceinline__ void row_load(Row<NR> &R, FSRowsRef r, i64 row)
 {
     R.n = r.nnz[row];
 #pragma unroll
@@ -264,7 +272,7 @@ __device__ __forceinline__ void row_load(Row<NR> &R, const FSRows &r, i64 row)
 }
 
 template <int NR>
-__device__ __forceinline__ i32 row_dim(const Row<NR> &R, const FSRows &r, i64 row, int e)
+__device__ __forceinline__ i32 row_dim(const Row<NR> &R, FSRowsRef r, i64 row, int e)
 {
     i32 d = R.i[0];
 #pragma unroll
@@ -274,7 +282,7 @@ __device__ __forceinline__ i32 row_dim(const Row<NR> &R, const FSRows &r, i64 ro
 }
 
 template <int NR>
-__device__ __forceinline__ bool row_has(const Row<NR> &R, const FSRows &r, i64 row, i32 d)
+__device__ __forceinline__ bool row_has(const Row<NR> &R, FSRowsRef r, i64 row, i32 d)
 {
     bool has = false;
 #pragma unroll
@@ -284,7 +292,7 @@ __device__ __forceinline__ bool row_has(const Row<NR> &R, const FSRows &r, i64 r
 }
 
 template <int NR>
-__device__ __forceinline__ double row_norm(const Row<NR> &R, const FSRows &r, i64 row)
+__device__ __forceinline__ double row_norm(const Row<NR> &R, FSRowsRef r, i64 row)
 {
     double x2 = 0.0;
 #pragma unroll
@@ -296,7 +304,7 @@ __device__ __forceinline__ double row_norm(const Row<NR> &R, const FSRows &r, i6
 // cos numerator: dot of the row with a support, ascending dimension order (:238); first = first row entry the
 // support holds (-1: none)
 template <int NR, int NS>
-__device__ __forceinline__ double row_dot(const Row<NR> &R, const FSRows &r, i64 row, const Sup<NS> &S, int &first)
+__device__ __forceinline__ double row_dot(const Row<NR> &R, FSRowsRef r, i64 row, const Sup<NS> &S, int &first)
 {
     double dot = 0.0;
     first = -1;
@@ -333,7 +341,7 @@ __device__ __forceinline__ i32 group_mex(const i32 *ovl, int m, int gl)
 // dimension)); the candidates go to ovl[0, min(nov, FS_OC)) (LDS, private to the group).  Returns the centre joined,
 // FS_NEW or FS_BREAK, uniform over the group.
 template <int NR, int NS, int G>
-__device__ __forceinline__ int fs_decide(const FS &s, const FSRows &r, i64 row, int K, double threshold, i32 *ovl,
+__device__ __forceinline__ int fs_decide(FSRef s, FSRowsRef r, i64 row, int K, double threshold, i32 *ovl,
                                          unsigned *seen, int gl, int &nov_out, double &xn_out)
 {
     Row<NR> R;
@@ -416,7 +424,7 @@ __device__ __forceinline__ int fs_decide(const FS &s, const FSRows &r, i64 row, 
 
 // ---- A: speculate ---------------------------------------------------------------------------------
 template <int NR, int NS, int G>
-__device__ __forceinline__ void fs_speculate(const FS &s, const FSRows &r, FSCtl *ctl, int nb, int K, i64 pos,
+__device__ __forceinline__ void fs_speculate(FSRef s, FSRowsRef r, FSCtl *ctl, int nb, int K, i64 pos,
                                              double threshold, i32 *ovl, unsigned *seen)
 {
     const int gl = threadIdx.x & (G - 1);
@@ -441,8 +449,9 @@ __device__ __forceinline__ void fs_speculate(const FS &s, const FSRows &r, FSCtl
 }
 
 template <int NR, int NS>
-__global__ __launch_bounds__(256) void k_fs_speculate(FS s, FSRows r, int par, double threshold)
+__global__ __launch_bounds__(256) void k_fs_speculate(FSArgsPtr ap, int par)
 {
+    FSRef s = ap->s; FSRowsRef r = ap->r; const double threshold = ap->threshold;
     __shared__ i32 ovl[16 * FS_OC];
     __shared__ unsigned seen[16 * FS_BMW];
     FSCtl *ctl = s.ctl + par;
@@ -472,8 +481,9 @@ __global__ __launch_bounds__(256) void k_fs_speculate(FS s, FSRows r, int par, d
 // batch ends before the first row that is left (ctl->first_new).  Nothing here is trusted: founders are scored as
 // their rows, not as they will have evolved, and k_fs_verify re-decides every one of these rows against the versions.
 template <int NR, int NS>
-__global__ __launch_bounds__(1024) void k_fs_found(FS s, FSRows r, int par, double threshold)
+__global__ __launch_bounds__(1024) void k_fs_found(FSArgsPtr ap, int par)
 {
+    FSRef s = ap->s; FSRowsRef r = ap->r; const double threshold = ap->threshold;
     constexpr int UC = NR <= 4 ? 12 : 6;                          // listed rows per thread: three registers each
     __shared__ int part[16];
     __shared__ int owner[32];
@@ -744,7 +754,7 @@ __global__ __launch_bounds__(1024) void k_fs_found(FS s, FSRows r, int par, doub
 // ---- the join lists: bitmaps --------------------------------------------------------------------------------
 // last batch row < cut that was speculated to join centre k (-1: none).  l1 = this lane's level-1 word (lanes
 // < FS_W1, else 0).  Wave-uniform result.
-__device__ __forceinline__ int last_join_below(const FS &s, int k, int cut, u64 l1, int lane)
+__device__ __forceinline__ int last_join_below(FSRef s, int k, int cut, u64 l1, int lane)
 {
     if (cut <= 0) return -1;
     const int wcut = (cut - 1) >> 6;                            // last word holding rows < cut
@@ -767,7 +777,7 @@ __device__ __forceinline__ int last_join_below(const FS &s, int k, int cut, u64 
 }
 
 // one lane's version of the same question, for row j of the verify step: rows strictly below j
-__device__ __forceinline__ int lane_last_join_below(const FS &s, i32 k, int j)
+__device__ __forceinline__ int lane_last_join_below(FSRef s, i32 k, int j)
 {
     const u64 *b0 = s.bm0 + (i64)k * FS_W0, *b1 = s.bm1 + (i64)k * FS_W1;
     const int w = j >> 6;
@@ -789,7 +799,7 @@ struct Walker {
     int sn, k, lane;
     double cnt;            // sample count, exact in a double (< 2^53)
 
-    __device__ __forceinline__ void load_state(const FS &s, int k_, int lane_)
+    __device__ __forceinline__ void load_state(FSRef s, int k_, int lane_)
     {
         k = k_; lane = lane_;
         sn = s.cs_n[k];
@@ -797,7 +807,7 @@ struct Walker {
         val = lane < sn ? s.cs_val[(i64)k * FS_CS + lane] : 0.0;
         cnt = (double)s.c_cnt[k];
     }
-    __device__ __forceinline__ void load_version(const FS &s, int k_, int lane_, int pj)
+    __device__ __forceinline__ void load_version(FSRef s, int k_, int lane_, int pj)
     {
         k = k_; lane = lane_;
         const VsEnt e = s.vs_ent[(i64)pj * FS_CS + lane];
@@ -806,7 +816,7 @@ struct Walker {
         idx = lane < sn ? e.idx : 0x7fffffff;
         val = lane < sn ? e.val : 0.0;
     }
-    __device__ __forceinline__ void store_state(const FS &s)
+    __device__ __forceinline__ void store_state(FSRef s)
     {
         double s2 = 0.0;                                        // norm of the state (:288), ascending sum
         for (int i = 0; i < sn; i++) { const double vi = bc_d(val, i); s2 += vi * vi; }
@@ -815,14 +825,14 @@ struct Walker {
     }
     // Every lane stores (the slots beyond the support hold an out-of-range index and are not read: one instruction
     // without an execution mask around it).
-    __device__ __forceinline__ void publish(const FS &s, int jj)
+    __device__ __forceinline__ void publish(FSRef s, int jj)
     {
         VsEnt e;
         e.idx = idx; e.sn = sn; e.val = lane == sn ? cnt : val;
         (s.vs_ent + (size_t)jj * FS_CS)[lane] = e;               // jj is uniform: scalar base, lane offset
     }
     // the same with the version's byte offset (jj * FS_CS * 16, below 2^32) in a register: scalar base + 32-bit offset
-    __device__ __forceinline__ void publish_at(const FS &s, unsigned off)
+    __device__ __forceinline__ void publish_at(FSRef s, unsigned off)
     {
         VsEnt e;
         e.idx = idx; e.sn = sn; e.val = lane == sn ? cnt : val;
@@ -833,7 +843,7 @@ struct Walker {
     // commit); otherwise straight into the per-dimension lists.  false = a capacity was hit and the centre is
     // unchanged (the walk is void from jj on / the stream stops before this row).
     template <bool LOGGED>
-    __device__ __forceinline__ bool join_general(const FS &s, const FSRows &r, FSCtl *ctl, i64 row, int jj, int n,
+    __device__ __forceinline__ bool join_general(FSRef s, FSRowsRef r, FSCtl *ctl, i64 row, int jj, int n,
                                                  double fo, double fn, const i32 *ri, const double *rv, int rs = 1)
     {
         int extra = 0;                                          // capacity first: how many dimensions are new?
@@ -928,7 +938,7 @@ struct JoinRows {
     double v[FS_NP];
 };
 
-__device__ __forceinline__ void join_rows_load(JoinRows &J, const FSRows &r, i64 row, bool isj)
+__device__ __forceinline__ void join_rows_load(JoinRows &J, FSRowsRef r, i64 row, bool isj)
 {
     J.n = 0; J.wd = 0.0;
 #pragma unroll
@@ -945,7 +955,7 @@ __device__ __forceinline__ void join_rows_load(JoinRows &J, const FSRows &r, i64
 // The joins of centre k among batch rows [0, jlim), in order.  The wave lists them from the centre's bitmap (lane l
 // takes WPL consecutive words; at most FS_LCAP joins are listed at a time), then applies them in groups of 64: the
 // rows of a group are fetched by a lane each while the previous group is being applied.
-__device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSCtl *ctl, WalkLds &L, int k, int jlim, i64 pos, int lane)
+__device__ __forceinline__ void fs_walk_centre(FSRef s, FSRowsRef r, FSCtl *ctl, WalkLds &L, int k, int jlim, i64 pos, int lane)
 {
     unsigned short *lst = L.lst;
     double *addm = L.addm, *rowv = L.rowv;
@@ -1119,8 +1129,9 @@ __device__ __forceinline__ void fs_walk_centre(const FS &s, const FSRows &r, FSC
 #endif
 }
 
-__global__ __launch_bounds__(64) void k_fs_walk(FS s, FSRows r, int par)
+__global__ __launch_bounds__(64) void k_fs_walk(FSArgsPtr ap, int par)
 {
+    FSRef s = ap->s; FSRowsRef r = ap->r;
     __shared__ WalkLds L;
     FSCtl *ctl = s.ctl + par;
     if (ctl->halt) return;
@@ -1140,7 +1151,7 @@ __global__ __launch_bounds__(64) void k_fs_walk(FS s, FSRows r, int par)
 // ---- C: verify ---------------------------------------------------------------------------------------
 // score of centre cc as row j sees it: against the version left by cc's last join before j, or the batch-start state
 template <int NR, int NS>
-__device__ __forceinline__ Best fs_score_seen(const FS &s, const FSRows &r, const Row<NR> &R, i64 row, int j, i32 cc, double xn)
+__device__ __forceinline__ Best fs_score_seen(FSRef s, FSRowsRef r, const Row<NR> &R, i64 row, int j, i32 cc, double xn)
 {
     const int pj = lane_last_join_below(s, cc, j);
     Sup<NS> S;
@@ -1160,7 +1171,7 @@ __device__ __forceinline__ Best fs_score_seen(const FS &s, const FSRows &r, cons
 }
 
 template <int NR, int NS, int G>
-__device__ __forceinline__ void fs_verify(const FS &s, const FSRows &r, FSCtl *ctl, int jlast, int K, i64 pos,
+__device__ __forceinline__ void fs_verify(FSRef s, FSRowsRef r, FSCtl *ctl, int jlast, int K, i64 pos,
                                           double threshold, i32 *ovl, const i32 *lgp, int nlg, const unsigned *dimbits)
 {
     const int gl = threadIdx.x & (G - 1);
@@ -1226,8 +1237,9 @@ __device__ __forceinline__ void fs_verify(const FS &s, const FSRows &r, FSCtl *c
 }
 
 template <int NR, int NS>
-__global__ __launch_bounds__(256) void k_fs_verify(FS s, FSRows r, int par, double threshold)
+__global__ __launch_bounds__(256) void k_fs_verify(FSArgsPtr ap, int par)
 {
+    FSRef s = ap->s; FSRowsRef r = ap->r; const double threshold = ap->threshold;
     __shared__ i32 ovl[16 * FS_OC];
     __shared__ i32 lg[3 * FS_LGS];                               // the growth records, staged: every row of the block scans them
     __shared__ unsigned lgdim[FS_LGD / 32];                      // ... but first asks whether any of them names one of its dimensions
@@ -1257,7 +1269,7 @@ __global__ __launch_bounds__(256) void k_fs_verify(FS s, FSRows r, int par, doub
 }
 
 // ---- D: commit -----------------------------------------------------------------------------------------
-__device__ __forceinline__ void fs_clear_bitmaps(const FS &s, int k, int nb, int lane)
+__device__ __forceinline__ void fs_clear_bitmaps(FSRef s, int k, int nb, int lane)
 {
     const int nwords = (nb + 63) >> 6;
     for (int w = lane; w < nwords; w += 64) s.bm0[(i64)k * FS_W0 + w] = 0ull;
@@ -1266,7 +1278,7 @@ __device__ __forceinline__ void fs_clear_bitmaps(const FS &s, int k, int nb, int
 
 // Applies one row with its exact decision to the live state (the wave that ends the step).  pj: the version the
 // joined centre is at (-1: its stored state).  Returns false when a capacity stopped it (flags are set).
-__device__ __forceinline__ bool fs_apply_row(const FS &s, const FSRows &r, FSCtl *ctl, i64 row, int jj, int dec, int pj,
+__device__ __forceinline__ bool fs_apply_row(FSRef s, FSRowsRef r, FSCtl *ctl, i64 row, int jj, int dec, int pj,
                                              double xn, int &K, i32 *ri, double *rv, int lane)
 {
     const int n = r.nnz[row];
@@ -1309,7 +1321,7 @@ __device__ __forceinline__ bool fs_apply_row(const FS &s, const FSRows &r, FSCtl
 // fs_decide per row, a chain of memory round trips each.  Conservative: a row that is not certainly a founding
 // row ends the run and is decided the general way.
 template <int NR, int NS>
-__device__ __forceinline__ u64 fs_founding_run(const FS &s, const FSRows &r, i64 pos, int nb, i64 left, double threshold,
+__device__ __forceinline__ u64 fs_founding_run(FSRef s, FSRowsRef r, i64 pos, int nb, i64 left, double threshold,
                                                 i32 *t_ri, double *t_rv, int lane)
 {
     int lim = nb < 64 ? nb : 64;
@@ -1356,8 +1368,9 @@ __device__ __forceinline__ u64 fs_founding_run(const FS &s, const FSRows &r, i64
 }
 
 template <int NR, int NS>
-__global__ __launch_bounds__(64) void k_fs_commit(FS s, FSRows r, int par, double threshold)
+__global__ __launch_bounds__(64) void k_fs_commit(FSArgsPtr ap, int par)
 {
+    FSRef s = ap->s; FSRowsRef r = ap->r; const double threshold = ap->threshold;
     __shared__ i32 ri[FS_NP];
     __shared__ double rv[FS_NP];
     __shared__ i32 ovl[FS_OC];
@@ -1488,6 +1501,9 @@ struct FitFast {
     FSCtl *h_ctl = nullptr;   // pinned: read-back of a control block
     void *blob = nullptr;
     i64 *d_trace = nullptr;
+    FSArgs *d_args = nullptr; // what the kernels read: state block, row arrays, threshold (uploaded when they change)
+    FSArgs h_args;            // ... as last uploaded
+    bool args_set = false;
     int B_keep = 256;         // batch size the last chain ended with: the next stream over this state starts there
 };
 
@@ -1503,6 +1519,7 @@ void fitfast_free(sit_ctx *c)
     FitFast *f = (FitFast *)c->fitfast;
     if (f->blob) sit_dfree(c, f->blob);                       // the arena is 85 MB and more: recycled between contexts
     if (f->d_trace) (void)hipFree(f->d_trace);
+    if (f->d_args) (void)hipFree(f->d_args);
     if (f->h_ctl) (void)hipHostFree(f->h_ctl);
     delete f;
     c->fitfast = nullptr;
@@ -1687,6 +1704,17 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         FSRows rb;                                            // the row arrays, addressed from `base`
         rb.nnz = nnz + base; rb.idx = idx + base; rb.val = val + base; rb.weights = weights ? weights + base : nullptr;
         rb.stride = stride; rb.width = width;
+        {
+            FSArgs a;
+            memset(&a, 0, sizeof(a));
+            a.s = s; a.r = rb; a.threshold = threshold;
+            if (!f->d_args) HIP_TRY(c, hipMalloc((void **)&f->d_args, sizeof(FSArgs)));
+            if (!f->args_set || memcmp(&f->h_args, &a, sizeof(FSArgs)) != 0) {
+                f->h_args = a; f->args_set = true;
+                HIP_TRY(c, hipMemcpyAsync(f->d_args, &f->h_args, sizeof(FSArgs), hipMemcpyHostToDevice, c->stream));
+            }
+        }
+        const FSArgsPtr ap = (FSArgsPtr)f->d_args;
         int par = 0, chunk = 8;
         FSCtl st = z;
         while (!st.halt) {
@@ -1701,17 +1729,17 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         if (hipGetLastError() != hipSuccess) { c->msg = "fit: launch of " name " failed"; return SIT_ERR_HIP; } \
     } while (0)
                 if (wide) {
-                    FS_LAUNCH("speculate", (k_fs_speculate<8, 16>), grows, 256, s, rb, par, threshold);
-                    FS_LAUNCH("found", (k_fs_found<8, 16>), 1, 1024, s, rb, par, threshold);
-                    FS_LAUNCH("walk", k_fs_walk, gk, 64, s, rb, par);
-                    FS_LAUNCH("verify", (k_fs_verify<8, 16>), grows, 256, s, rb, par, threshold);
-                    FS_LAUNCH("commit", (k_fs_commit<8, 16>), gk + 1, 64, s, rb, par, threshold);
+                    FS_LAUNCH("speculate", (k_fs_speculate<8, 16>), grows, 256, ap, par);
+                    FS_LAUNCH("found", (k_fs_found<8, 16>), 1, 1024, ap, par);
+                    FS_LAUNCH("walk", k_fs_walk, gk, 64, ap, par);
+                    FS_LAUNCH("verify", (k_fs_verify<8, 16>), grows, 256, ap, par);
+                    FS_LAUNCH("commit", (k_fs_commit<8, 16>), gk + 1, 64, ap, par);
                 } else {
-                    FS_LAUNCH("speculate", (k_fs_speculate<4, 8>), grows, 256, s, rb, par, threshold);
-                    FS_LAUNCH("found", (k_fs_found<4, 8>), 1, 1024, s, rb, par, threshold);
-                    FS_LAUNCH("walk", k_fs_walk, gk, 64, s, rb, par);
-                    FS_LAUNCH("verify", (k_fs_verify<4, 8>), grows, 256, s, rb, par, threshold);
-                    FS_LAUNCH("commit", (k_fs_commit<4, 8>), gk + 1, 64, s, rb, par, threshold);
+                    FS_LAUNCH("speculate", (k_fs_speculate<4, 8>), grows, 256, ap, par);
+                    FS_LAUNCH("found", (k_fs_found<4, 8>), 1, 1024, ap, par);
+                    FS_LAUNCH("walk", k_fs_walk, gk, 64, ap, par);
+                    FS_LAUNCH("verify", (k_fs_verify<4, 8>), grows, 256, ap, par);
+                    FS_LAUNCH("commit", (k_fs_commit<4, 8>), gk + 1, 64, ap, par);
                 }
 #undef FS_LAUNCH
                 par ^= 1;
