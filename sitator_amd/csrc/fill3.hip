@@ -2,9 +2,12 @@
 // with the narrow-row site assignment fused behind it (FUSE = 1: `sit_fill` with assign = 1).
 //
 // landmark/helpers.pyx:12-212.  The ZERO PATTERN is the reference's bit for bit: squared distances are computed in the
-// reference's operation order (FP64, no contraction) and compared with exact per-(landmark, vertex) thresholds (below).
-// The VALUES are accurate, not bit-identical: Newton sequences without their final correctly-rounding step and a
-// table-driven exp put them within ~1e-14 relative of the reference's (the contract is 1e-6).
+// reference's operation order (FP64, no contraction) and compared with exact per-(landmark, vertex) thresholds (below) -
+// on general cells always; on DIAGONAL cells (CHEAP) the distance is the minimum-image one and the decision is taken on
+// the logistic argument, and only a lane within the error bound of the cut-off (practically never) sends its passes
+// round again through the reference's arithmetic and the exact threshold (F3_D1E_BODY).
+// The VALUES are accurate, not bit-identical: one-step Newton roots and a table-driven exp put them within 5e-14
+// relative of the reference's, 3e-15 on average (scratch/acc_fill.py; the contract is 1e-6).
 // On gfx950 every vector instruction of this kernel costs 4-5 cycles of a SIMD whatever it computes (an FP64 multiply
 // 5.0, a 32-bit shift-add 4.3, a compare 4.3; only plain 32-bit add / and / mov are cheaper, `scratch/issue_cost.hip`)
 // and scalar instructions are nearly free, so the design rule is: few vector instructions, full lanes, masks and loop
