@@ -330,6 +330,8 @@ def make_trajectory(host, n_mobile, n_frames, seed=0, **kw):
 def config_host(name):
     if name == "C1":
         return sc_grid((3, 3, 3), cell=hexagonal_cell(12.0, 12.0))
+    if name == "C1d":       # the C1 host on a DIAGONAL cell (k_fill3's minimum-image arithmetic; C1 and C1b take the general one)
+        return sc_grid((3, 3, 3), cell=np.diag([12.0, 13.2, 14.4]))
     if name == "C1b":
         shear = np.array([[1, 0, 0], [-0.15, 1, 0], [0.1, -0.08, 1.0]])
         return bcc_tet(3, 4.2, shape=shear)
@@ -349,12 +351,13 @@ def config_host(name):
     raise KeyError(name)
 
 
-CONFIG_MOBILE = {"C1": 4, "C1b": 4, "C2": 64, "C3": 448, "C4": 256, "C5": 160, "C2h": 64, "C2t": 64}
-CONFIG_FRAMES = {"C1": 2000, "C1b": 1000, "C2": 100000, "C3": 250000, "C4": 1000000, "C5": 500000, "C2h": 100000,
+CONFIG_MOBILE = {"C1": 4, "C1d": 4, "C1b": 4, "C2": 64, "C3": 448, "C4": 256, "C5": 160, "C2h": 64, "C2t": 64}
+CONFIG_FRAMES = {"C1": 2000, "C1d": 2000, "C1b": 1000, "C2": 100000, "C3": 250000, "C4": 1000000, "C5": 500000, "C2h": 100000,
                  "C2t": 100000}
-CONFIG_SEED = {"C1": 1, "C1b": 11, "C2": 2, "C3": 3, "C4": 4, "C5": 5, "C2h": 12, "C2t": 13}
+CONFIG_SEED = {"C1": 1, "C1d": 21, "C1b": 11, "C2": 2, "C3": 3, "C4": 4, "C5": 5, "C2h": 12, "C2t": 13}
 CONFIG_TEXT = {
     "C1": "C1: LiAlSiO4-like hexagonal cell a=b=12 A, c=12 A, SCgrid(3,3,3), S=D=27 (V=8), M=4 (BASELINE configs[0])",
+    "C1d": "C1d: SCgrid(3,3,3) on an orthorhombic cell 12.0x13.2x14.4 A, S=D=27 (V=8), M=4 (the C1 host on a diagonal cell)",
     "C1b": "C1b: triclinic BCCtet(3, 4.2 A), S=54, D=324 (V=4), M=4 (the rich-overlap parity host)",
     "C2": "C2: SCgrid(8,8,8) orthorhombic 32.0x35.2x38.4 A, S=D=512 (V=8), M=64, A=576 (BASELINE configs[1])",
     "C3": "C3: LLZO-like SCgrid(8,8,17) 26.0x26.0x55.25 A, S=D=1088 (V=8), M=448, A=1536 (BASELINE configs[2])",

@@ -9,7 +9,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 bad = 0; kinds = {}
 t0 = time.time()
 for i in range(n):
-    cfg = "C1" if i % 3 else "C1b"
+    cfg = ("C1", "C1d", "C1b")[i % 3]
     seed = int(os.environ.get("FUZZ_BASE", "5000")) + i
     try:
         exp, exp_err, st, got_err, la = _run_both(oracle, cfg, seed)

@@ -12,6 +12,8 @@ for seed in range(14):
     CASES.append(("C1", seed))
 for seed in range(8):
     CASES.append(("C1b", 100 + seed))
+for seed in range(10):
+    CASES.append(("C1d", 200 + seed))       # a diagonal cell: k_fill3's minimum-image distances and their exact fall-back
 
 
 def _run_both(oracle, cfg, seed):
