@@ -97,7 +97,7 @@ struct Fill3Head {
     const double *frame_dmax;
     const double *exptab;
     i64 F, A, fbeg;                   // the launch covers frames [fbeg, F)
-    int S, M, fpb, contig, debug_stop, rcap, iw, has_fallback, s0, m0, tt, mcap, frame_mod;
+    int S, M, fpb, contig, debug_stop, rcap, iw, has_fallback, s0, m0, tt, mcap, frame_mod, prio;
     double delta2, thr2_lo, thr2_hi, static_thr, safe2;
 };
 typedef const Fill3Args __attribute__((address_space(4))) *Fill3ArgsPtr;
@@ -589,6 +589,10 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
         if (tid == 0) atomicMin(g.err, 0ull);
         return;
     }
+    // phase 1 at a raised issue priority: a new workgroup gets its frame requested and wrapped ahead of the arithmetic of
+    // the six others on its CU - they have plenty to overlap with, it has nothing (round 4: 0.667 -> 0.655 ms at C2; the
+    // other way round, or the priority kept through the window set-up or raised again for T: no gain)
+    if (h.prio) __builtin_amdgcn_s_setprio(3);
     if (tid < fpb) fmax[tid] = 0ull;
     if (FUSE && tid < 2 * NW) garrive[tid] = 0u;
     double etv = 0.0;
@@ -709,6 +713,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
         if (!tight) atomicAdd(&g.scal[2], 1ull);
     }
     if (dbg == 1) return;
+    if (h.prio) __builtin_amdgcn_s_setprio(0);
 
     // phase-2 constants
     const char *vh = (const char *)g.vh;
@@ -1280,6 +1285,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     }
     h.contig = contig;
     h.frame_mod = f3_env_int("SITATOR_F3_FRAME_MOD", 0);
+    h.prio = f3_env_int("SITATOR_F3_PRIO", 1);
 
     // ---- survivor slots / task-table size: measured once per kind of fill ----
     if (rcap_auto && tt_auto && !fuse && h.debug_stop == 0 && f3_env_int("SITATOR_FILL_AUTOTUNE", 1) && (f_hi - f_lo) * M >= (1 << 18)) {
