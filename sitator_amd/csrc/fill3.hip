@@ -611,8 +611,9 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
             const char *src = (const char *)fbase;
             for (int e0 = wave * 64; e0 < n2; e0 += NT) {       // wave-uniform
                 if (e0 + lane < n2)
+                    // (nt: a frame is read once, by this workgroup; -1 % at C2 against the default policy)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 16 * (size_t)(e0 + lane)),
-                                                     (__attribute__((address_space(3))) void *)(smem + 16 * e0), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void *)(smem + 16 * e0), 16, 0, 2);
             }
         } else if (h.contig == 3) {
             // the same run as 16-byte pieces (the frame group starts on a 16-byte boundary and holds an even number
