@@ -57,7 +57,20 @@ class LandmarkAnalysis(object):
                  site_centers_method=SITE_CENTERS_REAL_WEIGHTED, check_for_zero_landmarks=True,
                  static_movement_threshold=1.0, dynamic_lattice_mapping=False,
                  relaxed_lattice_checks=False, max_mobile_per_site=1, force_no_memmap=False,
-                 verbose=True, comm=None, device=None, recenter_masses=None, fit_mode="exact"):
+                 verbose=True, comm=None, device=None, recenter_masses=None, fit_mode="exact", devices=None):
+        # Not in the reference: `devices=[0, 1, ...]` - ONE process drives several GPUs, a thread per GPU, the frames in
+        # contiguous blocks in device order (the single-process form of the frame sharding; `comm` / `device` are the
+        # process-per-GPU form).  The result is one SiteTrajectory over all frames.
+        self._devices = None if devices is None else [int(d) for d in devices]
+        if self._devices is not None and comm is not None:
+            raise ValueError("devices=[...] and comm= are two ways to shard the frames: give one")
+        self._init_kwargs = dict(
+            clustering_algorithm=clustering_algorithm, clustering_params=clustering_params, cutoff_midpoint=cutoff_midpoint,
+            cutoff_steepness=cutoff_steepness, minimum_site_occupancy=minimum_site_occupancy,
+            site_centers_method=site_centers_method, check_for_zero_landmarks=check_for_zero_landmarks,
+            static_movement_threshold=static_movement_threshold, dynamic_lattice_mapping=dynamic_lattice_mapping,
+            relaxed_lattice_checks=relaxed_lattice_checks, max_mobile_per_site=max_mobile_per_site,
+            force_no_memmap=force_no_memmap, verbose=verbose, recenter_masses=recenter_masses, fit_mode=fit_mode)
         self._cutoff_midpoint = cutoff_midpoint
         self._cutoff_steepness = cutoff_steepness
         self._minimum_site_occupancy = minimum_site_occupancy
@@ -125,6 +138,10 @@ class LandmarkAnalysis(object):
             raise ValueError("Input SiteNetwork must have vertices")
         if frames.dtype != np.float64:
             raise ValueError("Buffer dtype mismatch, expected 'double' but got '%s'" % frames.dtype)
+        if self._devices is not None and len(self._devices) > 1:
+            return self._run_on_devices(sn, frames)
+        if self._devices is not None and len(self._devices) == 1:
+            self._device = self._devices[0]
         comm = self._comm
         n_frames = len(frames)
         logger.info("--- Running Landmark Analysis ---")
@@ -247,6 +264,52 @@ class LandmarkAnalysis(object):
         self._has_run = True
         return out_st
 
+    def _run_on_devices(self, sn, frames):
+        """``devices=[...]``: a thread per GPU runs the sharded analysis on its block of frames (``ThreadComm``); the blocks'
+        assignments are joined into one trajectory.  An exception the reference would raise is raised by every shard alike
+        (the shards agree on the first offender): the first one is passed on."""
+        import threading
+        from .sharding import ThreadComm, shard_frames
+        n = len(self._devices)
+        comms = ThreadComm.group(n)
+        done = [None] * n
+        failed = [None] * n
+
+        def work(r):
+            try:
+                lo, hi = shard_frames(len(frames), r, n)
+                la = LandmarkAnalysis(comm=comms[r], device=self._devices[r], **self._init_kwargs)
+                done[r] = (la, la.run(sn, frames[lo:hi]))
+            except BaseException as e:          # noqa: the others must not wait for a thread that has left
+                failed[r] = e
+                comms[r].abort()
+
+        threads = [threading.Thread(target=work, args=(r,), name="sitator-gpu%d" % self._devices[r]) for r in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        real = [e for e in failed if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+        if real:
+            raise real[0]
+        for e in failed:
+            if e is not None:
+                raise e
+        las = [d[0] for d in done]
+        sts = [d[1] for d in done]
+        first = las[0]
+        self._children = las
+        self._landmark_dimension = first._landmark_dimension
+        self._landmark_vectors = _StackedLandmarkVectors([la._landmark_vectors for la in las])
+        for name in ("n_all_zero_lvecs", "n_multiple_assignments", "avg_mobile_per_site", "cluster_centers_", "timings",
+                     "wall_timings", "fit_timings"):
+            setattr(self, name, getattr(first, name, None))
+        out_st = SiteTrajectory(sts[0].site_network, np.concatenate([st.traj for st in sts]),
+                                np.concatenate([st.confidences for st in sts]), _adopt=True)
+        out_st.set_real_traj(frames)
+        self._has_run = True
+        return out_st
+
     # -- helpers -----------------------------------------------------------------------------------
     def _raise_fill_error(self, ctx, comm, rc, err):
         """Map the first offender (in the reference's frame/index order, across ranks) to the
@@ -312,3 +375,14 @@ class LandmarkAnalysis(object):
                 centers[site] = self._pbcc.average(np.asarray(sn.centers)[nonzero], weights=rep_lvecs[site, nonzero])
             return centers
         raise ValueError("Invalid site centers method '%s'" % method)
+
+
+class _StackedLandmarkVectors(object):
+    """``landmark_vectors`` of a ``devices=[...]`` run: the shards' rows one after the other, densified on demand."""
+
+    def __init__(self, parts):
+        self.parts = parts
+
+    def __array__(self, dtype=None, copy=None):
+        out = np.concatenate([np.asarray(p) for p in self.parts])
+        return out if dtype is None else out.astype(dtype, copy=False)

@@ -237,6 +237,56 @@ class TcpComm(Comm):
         self.ctl.close()
 
 
+class ThreadComm(Comm):
+    """The ``Comm`` interface between the threads of ONE process, a thread per GPU: ``LandmarkAnalysis(devices=[...])``
+    (SURVEY.md section 8e's single-process mode).  The exchanges are the same small statistics as between processes;
+    they meet in host memory behind a barrier.  ``ThreadComm.group(n)`` makes the n ends; ``abort()`` releases the
+    others when a thread leaves with an exception of its own (they then raise ``threading.BrokenBarrierError``)."""
+
+    class _Shared(object):
+        def __init__(self, size):
+            self.size = size
+            self.barrier = threading.Barrier(size)
+            self.slots = [None] * size
+
+    def __init__(self, shared, rank):
+        self._s = shared
+        self.rank, self.size = rank, shared.size
+
+    @classmethod
+    def group(cls, size):
+        shared = cls._Shared(size)
+        return [cls(shared, r) for r in range(size)]
+
+    def _exchange(self, value):
+        s = self._s
+        s.slots[self.rank] = value
+        s.barrier.wait()
+        out = list(s.slots)
+        s.barrier.wait()                       # nobody overwrites a slot another thread is still reading
+        return out
+
+    def allgather(self, arr):
+        return np.stack(self._exchange(np.array(arr, copy=True)))
+
+    def allreduce_sum(self, arr):
+        arr = np.asarray(arr)
+        with np.errstate(over="ignore"):
+            return self.allgather(arr).sum(axis=0, dtype=arr.dtype).reshape(arr.shape)
+
+    def allreduce_max(self, arr):
+        return self.allgather(np.asarray(arr)).max(axis=0)
+
+    def bcast(self, arr, root=0):
+        return np.array(self._exchange(np.asarray(arr) if self.rank == root else None)[root], copy=True)
+
+    def barrier(self):
+        self._s.barrier.wait()
+
+    def abort(self):
+        self._s.barrier.abort()
+
+
 class RcclComm(Comm):
     """RCCL over xGMI through the C-ABI of libsitator_hip.so; one instance per process / GPU / context."""
 

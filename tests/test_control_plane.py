@@ -86,3 +86,45 @@ def test_every_rank_learns_that_no_communicator_can_be_formed():
         p.join(60)
     assert got[0] == got[1]
     assert got[0].startswith("RCCL communicator not created: rank 0:") and "rank 1:" in got[0]
+
+
+def test_thread_comm_between_the_threads_of_one_process():
+    """``ThreadComm`` (the exchanges of ``LandmarkAnalysis(devices=[...])``): gather, sums, broadcast from any root, and
+    ``abort()`` releasing the threads that wait for one that has left."""
+    import threading
+    import numpy as np
+    from sitator_amd.sharding import ThreadComm
+    n = 4
+    comms = ThreadComm.group(n)
+    out = [None] * n
+
+    def work(r):
+        c = comms[r]
+        g = c.allgather(np.array([r, 10 * r], dtype=np.int64))
+        s = c.allreduce_sum(np.array([1.0, float(r)]))
+        m = c.allreduce_max(np.array([r]))
+        b = c.bcast(np.arange(3) + r if r == 2 else np.zeros(0), root=2)
+        c.barrier()
+        out[r] = (g, s, m, b)
+
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for r in range(n):
+        g, s, m, b = out[r]
+        assert g.tolist() == [[q, 10 * q] for q in range(n)] and s.tolist() == [4.0, 6.0] and m.tolist() == [3]
+        assert b.tolist() == [2, 3, 4]
+    comms = ThreadComm.group(2)
+    seen = []
+
+    def waits():
+        try:
+            comms[0].barrier()
+        except threading.BrokenBarrierError:
+            seen.append("released")
+
+    t = threading.Thread(target=waits)
+    t.start()
+    comms[1].abort()
+    t.join(10)
+    assert seen == ["released"]

@@ -55,3 +55,41 @@ def test_two_ranks_on_one_gpu(name, tag):
         assert int(o["n_multi"]) == int(exp["n_multiple_assignments"])
     jumps = np.concatenate([o["jumps"] for o in outs])              # global frame numbers
     assert np.array_equal(jumps, exp["jumps"])
+
+
+@pytest.mark.parametrize("name,tag,n", [("c1_hex_scgrid", "dotprod", 2), ("c1b_tri_bcctet", "mcl", 2), ("c1_hex_scgrid", "dotprod", 3)])
+def test_devices_mode_one_process_several_contexts(name, tag, n):
+    """``LandmarkAnalysis(devices=[...])``: one process, a thread and a context per entry (here all on GPU 0), the frames
+    in contiguous blocks, the exchanges through ``ThreadComm``: the joined trajectory equals the reference's golden run."""
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure
+    c = G.Case(name)
+    sn = SiteNetwork(Structure(c.ref_positions, c.cell), c.static_mask, c.mobile_mask)
+    sn.centers = c.centers
+    sn.vertices = c.vertices
+    la = LandmarkAnalysis(verbose=False, devices=[0] * n, **c.kwargs(tag))
+    st = la.run(sn, np.ascontiguousarray(c.frames))
+    exp = c.out(tag)
+    assert np.array_equal(st.traj, exp["labels"])
+    m = exp["labels"] >= 0
+    np.testing.assert_allclose(st.confidences[m], exp["confs"][m], rtol=1e-6)
+    np.testing.assert_allclose(np.asarray(st.site_network.centers), exp["site_centers"], rtol=1e-6, atol=1e-8)
+    assert int(la.n_multiple_assignments) == int(exp["n_multiple_assignments"])
+    assert np.array_equal(np.array(list(st.jumps()), dtype=np.int64).reshape(-1, 4), exp["jumps"])
+    lv = np.asarray(la.landmark_vectors)
+    assert lv.shape == exp["lvecs"].shape and np.array_equal(lv != 0, exp["lvecs"] != 0)
+
+
+def test_devices_mode_passes_the_reference_error_on():
+    """A frame whose static atom has left the lattice: every shard agrees on the first offender and raises; the caller
+    sees the reference's exception once."""
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, errors
+    c = G.Case("c1_hex_scgrid")
+    sn = SiteNetwork(Structure(c.ref_positions, c.cell), c.static_mask, c.mobile_mask)
+    sn.centers = c.centers
+    sn.vertices = c.vertices
+    frames = np.array(c.frames, copy=True)
+    bad = len(frames) - 7
+    frames[bad, np.where(c.static_mask)[0][3]] += 2.5
+    with pytest.raises(errors.StaticLatticeError) as ei:
+        LandmarkAnalysis(verbose=False, devices=[0, 0], **c.kwargs("dotprod")).run(sn, frames)
+    assert ei.value.frame == bad
