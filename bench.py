@@ -3,10 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W [--config C2|C3|C4|C5|C2h|C2t] [--frames F] [--algo dotprod|mcl]
 
-Workload: one GPU - BASELINE.json configs[1], "C2": synthetic 64-mobile / 512-landmark orthorhombic cell
-(SCgrid(8,8,8), 32.0 x 35.2 x 38.4 A, A = 576 atoms), 100 000 frames; several GPUs - configs[3], "C4": 256-mobile /
-2 048-landmark cell, 1 000 000 frames frame-sharded over 8 GPUs = 125 000 frames PER GPU (weak scaling: rank r holds
-frames [r*F, (r+1)*F) of an N*F-frame trajectory).  `--config` picks any other (C3: 448 mobile, 250 000 frames;
+Workload: BASELINE.json configs[1], "C2": synthetic 64-mobile / 512-landmark orthorhombic cell (SCgrid(8,8,8), 32.0 x
+35.2 x 38.4 A, A = 576 atoms), 100 000 frames PER GPU at every N (weak scaling: rank r holds frames [r*F, (r+1)*F) of
+an N*F-frame trajectory, so that a 1 -> 8 series compares like with like).  `--config C4` times BASELINE configs[3]
+instead (256-mobile / 2 048-landmark cell, 1 000 000 frames over 8 GPUs = 125 000 per GPU; the N = 1 line carries that
+share as `scale_ref`); `--config` picks any other (C3: 448 mobile, 250 000 frames;
 C5: the ragged FCC host, 62 500 frames per GPU, end-to-end run with the mcl plugin and jump detection; C2h / C2t: the
 C2 shape on a hexagonal / triclinic cell).  One "step" = one pass of the hot path over the resident trajectory: wrap +
 static-lattice check + landmark vector of every (frame, mobile ion) + cosine assignment to the fitted site centres ->
@@ -50,10 +51,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default: the configuration's own, below)")
-    ap.add_argument("--config", default=None, help="C2 on one GPU, C4 on several (BASELINE.json configs[1] / configs[3])")
+    ap.add_argument("--config", default=None, help="C2 (BASELINE.json configs[1]) at every N; C4 = configs[3]'s per-GPU share")
     ap.add_argument("--algo", default=None, help="clustering plugin of the end-to-end run: dotprod, or mcl (the default of C5)")
     ap.add_argument("--cpu-frames", type=int, default=1000, help="frames per core of the CPU-baseline cut (0 = skip)")
-    ap.add_argument("--no-scale-ref", action="store_true", help="N = 1, default workload: skip the C4-share pass that anchors the N > 1 series")
+    ap.add_argument("--no-scale-ref", action="store_true", help="N = 1, default workload: skip the extra pass over one GPU's share of configs[3] (C4)")
     return ap.parse_args()
 
 
@@ -126,7 +127,9 @@ def main():
             print("[rank %d/%d] RCCL communicator up on GPU %d" % (rank, world, local), file=sys.stderr, flush=True)
 
     if args.config is None:
-        args.config = "C2" if world == 1 else "C4"
+        # the same workload at every N (weak scaling: every GPU takes configs[1]'s 100 000 frames), so that a 1 -> 8
+        # series compares like with like; `--config C4` times BASELINE configs[3]'s per-GPU share instead
+        args.config = "C2"
     if args.frames is None:
         args.frames = FRAMES_PER_GPU.get(args.config, 100000)
     if args.algo is None:
@@ -308,8 +311,8 @@ def main():
         if args.cpu_frames > 0 and world == 1:          # a reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(host, gen, frames, ref, fit_ctx_centers, M, args.cpu_frames, ncpu)
         if world == 1 and args.config == "C2" and F == FRAMES_PER_GPU["C2"] and not args.no_scale_ref:
-            # The N > 1 runs time configs[3] (C4: 125 000 frames per GPU, weak scaling).  So that a 1 -> 8 series compares
-            # like with like, the N = 1 line also carries the same pass over ONE GPU's share of C4.
+            # BASELINE configs[3] (C4: 1e6 frames over 8 GPUs) is the configuration named for the multi-GPU runs: the N = 1
+            # line also carries the same pass over ONE GPU's share of it (`--gpus N --config C4` times it on N GPUs).
             del frames, ctx, la, st_full
             out["scale_ref"] = scale_reference(args, local)
         sys.stdout.flush()
