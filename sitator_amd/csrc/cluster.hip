@@ -51,8 +51,8 @@ __device__ __forceinline__ i64 finish_predict(const PredArgs &a, i64 row, Best b
 {
     i64 to; double conf;
     finish_assignment(b, a.threshold, to, conf);                      // :184-186
-    a.labels[row] = to;
-    a.confs[row] = conf;
+    __builtin_nontemporal_store(to, &a.labels[row]);
+    __builtin_nontemporal_store(conf, &a.confs[row]);
     return to;
 }
 
@@ -153,8 +153,8 @@ __device__ __forceinline__ i64 predict_row_merge_wide(const PredArgs &a, i64 row
 
 __device__ __forceinline__ bool predict_row_head(const PredArgs &a, i64 row, int &n, double &xn)
 {
-    n = a.row_nnz[row];
-    if (n == 0) { a.labels[row] = -1; a.confs[row] = 0.0; return false; }   // :168-172 (conf uninitialised there)
+    n = __builtin_nontemporal_load(&a.row_nnz[row]);
+    if (n == 0) { __builtin_nontemporal_store((i64)-1, &a.labels[row]); __builtin_nontemporal_store(0.0, &a.confs[row]); return false; }   // :168-172 (conf uninitialised there)
     double x2 = 0.0;
     for (int e = 0; e < n; e++) { const double v = a.row_val[(i64)e * a.N + row]; x2 += v * v; }
     xn = sqrt(x2);
