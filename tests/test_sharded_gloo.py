@@ -155,3 +155,25 @@ def test_shard_frames_partition():
             spans = [shard_frames(n, r, size) for r in range(size)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+@pytest.mark.parametrize("name,tag,n", [("c1_hex_scgrid", "dotprod", 2), ("c1_hex_scgrid", "mcl", 3), ("c1b_tri_bcctet", "dotprod", 2)])
+def test_devices_mode_threads_reproduce_the_reference(name, tag, n, monkeypatch):
+    """``LandmarkAnalysis(devices=[...])`` on the CPU: the device context replaced by the oracle-backed double, a thread
+    per listed device, the exchanges through ``ThreadComm``: the joined trajectory equals the reference's golden run."""
+    from sitator_amd import _lib, LandmarkAnalysis, SiteNetwork, Structure
+    from tests.fake_ctx import FakeContext
+    monkeypatch.setattr(_lib, "HipContext", FakeContext)
+    c = G.Case(name)
+    sn = SiteNetwork(Structure(c.ref_positions, c.cell), c.static_mask, c.mobile_mask)
+    sn.centers = c.centers
+    sn.vertices = c.vertices
+    la = LandmarkAnalysis(verbose=False, devices=list(range(n)), **c.kwargs(tag))
+    st = la.run(sn, np.ascontiguousarray(c.frames))
+    exp = c.out(tag)
+    assert np.array_equal(st.traj, exp["labels"])
+    m = exp["labels"] >= 0
+    np.testing.assert_allclose(st.confidences[m], exp["confs"][m], rtol=1e-6)
+    np.testing.assert_allclose(np.asarray(st.site_network.centers), exp["site_centers"], rtol=1e-6, atol=1e-8)
+    assert int(la.n_multiple_assignments) == int(exp["n_multiple_assignments"])
+    assert la.n_all_zero_lvecs == int(exp["n_all_zero_lvecs"])
