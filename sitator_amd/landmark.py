@@ -178,7 +178,7 @@ class LandmarkAnalysis(object):
         mobile_idx = np.where(sn.mobile_mask)[0]
         prefit = None
         self._pipelined = False
-        if hasattr(ctx, "prefault_assignments"):
+        if hasattr(ctx, "prefault_assignments") and os.environ.get("SITATOR_PREFAULT", "1") != "0":
             ctx.prefault_assignments(n_frames * len(mobile_idx))   # the label / confidence arrays of the last predict pass
         if (comm.size == 1 and self._cluster_algo == "dotprod" and not self.dynamic_lattice_mapping and self._pipeline
                 and self._recenter_masses is None and hasattr(ctx, "upload_fill_fit")):
