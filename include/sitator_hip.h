@@ -64,6 +64,13 @@ int sit_device_count(int *count);
 int sit_create(const double *cell, const double *cell_inv, int device, sit_ctx **out);
 void sit_destroy(sit_ctx *ctx);
 const char *sit_last_message(sit_ctx *ctx);
+/* Layout of this boundary as the LIBRARY was built: out[0] = SIT_ABI_VERSION, out[1] = sizeof(sit_error),
+ * out[2] = sizeof(sit_fill_params), out[3] = offsetof(sit_fill_params, predict_threshold), out[4] = offsetof(sit_error,
+ * frame), out[5] = bytes of a communicator id (sit_comm_unique_id).  Writes min(n, 6) words and returns 6.  A binding
+ * checks its own struct declarations against these once, at import (tests/test_abi.py does it for the ctypes stubs of
+ * INTEGRATION.md and sitator_amd/_lib.py).  No context, no GPU needed.                                        */
+#define SIT_ABI_VERSION 5
+int sit_abi(int32_t *out, int n);
 /* Device buffers of 1 MB and more (the trajectory, the landmark rows, labels, the fit's arena) are kept by the process
  * when a context lets go of them, up to as much as its contexts have held at once, and handed to the next context that asks for a similar size: a process
  * that analyses one trajectory after another (the reference allocates its landmark matrix anew per run,
@@ -112,6 +119,9 @@ int sit_frames_device_ptr(sit_ctx *ctx, void **ptr);
 /* ---- landmark vectors: helpers._fill_landmark_vectors (landmark/helpers.pyx:12-124) --- */
 
 typedef struct sit_fill_params {
+    uint32_t struct_size;              /* sizeof(sit_fill_params) as the CALLER declares it.  The library refuses any other
+                                          value with SIT_ERR_INVALID instead of reading past a shorter struct (a binding
+                                          written against an older header fails loudly: its first word is 0 or 1) */
     int32_t dynamic_lattice_mapping;   /* helpers.pyx:60-64,83 */
     int32_t relaxed_lattice_checks;    /* helpers.pyx:87       */
     int32_t check_for_zeros;           /* helpers.pyx:116-120  */
@@ -120,10 +130,9 @@ typedef struct sit_fill_params {
                                           rows of up to four entries are assigned inside the fill kernel and never leave
                                           the chip, wider ones by a second kernel (needs centres: sit_set_centers)        */
     int32_t predict_normed;            /* util/DotProdClassifier.pyx:155-161               */
-    double  predict_threshold;         /* util/DotProdClassifier.pyx:184                   */
     int32_t defer;                     /* 1: enqueue only - no host synchronisation; status, n_all_zero and the error of
                                           this pass come from sit_fill_result (or a later sit_fill / sit_synchronize)  */
-    int32_t reserved_;
+    double  predict_threshold;         /* util/DotProdClassifier.pyx:184                   */
 } sit_fill_params;
 
 /* One streaming pass over the resident frames: wrap, static-lattice check, landmark vector
@@ -132,8 +141,14 @@ typedef struct sit_fill_params {
  * On a domain error returns its status and fills *err.
  * With `defer` the call returns SIT_OK as soon as the pass is enqueued (*n_all_zero = -1); up to four such passes may be in
  * flight.  The reference raises from inside its frame loop (helpers.pyx:76-92,116-118); a deferred pass raises when
- * its result is collected: sit_fill_result waits for every pass in flight and returns the first failure (with *err),
- * a later sit_fill returns a failure that has landed meanwhile INSTEAD of running, sit_synchronize returns it too.
+ * its result is collected: sit_fill_result waits for every pass in flight and returns the first failure (with *err) -
+ * once; a later sit_fill returns a failure that has landed meanwhile INSTEAD of running - once; and every entry point
+ * that READS what a pass produces (rows, labels, counts: sit_predict, sit_get_assignments, sit_get_rows_*, sit_gram*,
+ * sit_weighted_row_sums*, sit_best_match*, sit_fit_push_stored_rows, sit_site_*, sit_check_occupancy, sit_jump_*,
+ * sit_assign_last_known, sit_running_mode, sit_count_zero_rows) first waits for the passes in flight and returns their
+ * first failure instead of the output of a failed pass (the failure stays until sit_fill_result or sit_fill has
+ * reported it).  sit_synchronize waits and decodes but returns the HIP status only.  sit_set_frames /
+ * sit_upload_fill_fit wait for and DROP the results of passes over the old frames.
  * SIT_RETRY: a row was wider than the buffers of the pass (measured on the leading frames) - call sit_fill again.  */
 int sit_fill(sit_ctx *ctx, const sit_fill_params *p, int64_t *n_all_zero, sit_error *err);
 int sit_fill_result(sit_ctx *ctx, int64_t *n_all_zero, sit_error *err);
@@ -287,6 +302,9 @@ int sit_recenter_resident(sit_ctx *ctx, const double *masses, const double *fact
 int sit_comm_unique_id(uint8_t *id128);                 /* ncclGetUniqueId: rank 0 makes it, every rank gets it */
 int sit_comm_create(sit_ctx *ctx, const uint8_t *id128, int rank, int world);
 int sit_comm_destroy(sit_ctx *ctx);
+/* What the communicator says about itself: out6 = {ncclCommCount, ncclCommUserRank, ncclCommCuDevice, ncclGetVersion,
+ * the world size and the rank sit_comm_create was given}.  bench.py prints it from every rank.            */
+int sit_comm_info(sit_ctx *ctx, int32_t *out6);
 /* In place on buf[count]; dtype 0 = float64, 1 = int64, 2 = uint64; op 0 = sum, 1 = min, 2 = max.       */
 int sit_comm_allreduce(sit_ctx *ctx, void *buf, int64_t count, int dtype, int op);
 /* recv[world * nbytes] = every rank's send[nbytes] in rank order.                                        */

@@ -28,10 +28,19 @@ class SitError(C.Structure):
 
 
 class FillParams(C.Structure):
-    _fields_ = [("dynamic_lattice_mapping", C.c_int32), ("relaxed_lattice_checks", C.c_int32),
+    """``sit_fill_params``; ``struct_size`` is filled in by ``make`` (the library refuses any other size)."""
+    _fields_ = [("struct_size", C.c_uint32), ("dynamic_lattice_mapping", C.c_int32), ("relaxed_lattice_checks", C.c_int32),
                 ("check_for_zeros", C.c_int32), ("store_rows", C.c_int32), ("assign", C.c_int32),
-                ("predict_normed", C.c_int32), ("predict_threshold", C.c_double), ("defer", C.c_int32),
-                ("reserved_", C.c_int32)]
+                ("predict_normed", C.c_int32), ("defer", C.c_int32), ("predict_threshold", C.c_double)]
+
+    @classmethod
+    def make(cls, dynamic_lattice_mapping=0, relaxed_lattice_checks=0, check_for_zeros=1, store_rows=1, assign=0,
+             predict_normed=1, predict_threshold=0.0, defer=0):
+        return cls(C.sizeof(cls), int(dynamic_lattice_mapping), int(relaxed_lattice_checks), int(check_for_zeros),
+                   int(store_rows), int(assign), int(predict_normed), int(defer), float(predict_threshold))
+
+
+ABI_VERSION = 5          # SIT_ABI_VERSION of include/sitator_hip.h this table was written against
 
 
 # every symbol include/sitator_hip.h declares: (restype, argtypes)
@@ -41,6 +50,7 @@ SIGNATURES = {
     "sit_destroy": (None, [_vp]),
     "sit_release_cached_memory": (None, []),
     "sit_last_message": (C.c_char_p, [_vp]),
+    "sit_abi": (C.c_int, [_i32p, C.c_int]),
     "sit_wrap_points": (C.c_int, [_vp, _dp, i64]),
     "sit_distances": (C.c_int, [_vp, _dp, _dp, i64, _dp]),
     "sit_average": (C.c_int, [_vp, _dp, _dp, i64, _dp]),
@@ -88,6 +98,7 @@ SIGNATURES = {
     "sit_comm_unique_id": (C.c_int, [_u8p]),
     "sit_comm_create": (C.c_int, [_vp, _u8p, C.c_int, C.c_int]),
     "sit_comm_destroy": (C.c_int, [_vp]),
+    "sit_comm_info": (C.c_int, [_vp, _i32p]),
     "sit_comm_allreduce": (C.c_int, [_vp, C.c_void_p, i64, C.c_int, C.c_int]),
     "sit_comm_allgather": (C.c_int, [_vp, C.c_void_p, C.c_void_p, i64]),
     "sit_comm_broadcast": (C.c_int, [_vp, C.c_void_p, i64, C.c_int]),
@@ -114,6 +125,14 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        # the struct declarations above against the library's own layout (sit_abi): a stale binding fails at import
+        abi = (C.c_int32 * 6)()
+        lib.sit_abi(abi, 6)
+        mine = (ABI_VERSION, C.sizeof(SitError), C.sizeof(FillParams), FillParams.predict_threshold.offset,
+                SitError.frame.offset, 128)
+        if tuple(abi) != mine:
+            raise ImportError("%s was built from another include/sitator_hip.h: its layout %r, this binding's %r "
+                              "(rebuild with `make -C sitator_amd/csrc`)" % (LIB_PATH, tuple(abi), mine))
         _lib = lib
     return _lib
 
@@ -179,6 +198,8 @@ class HipContext(object):
         # looked, (version, content digest) of what is there
         self.labels_version = 0
         self.labels_digest = None
+        self._deferred = 0                # sit_fill passes enqueued with defer and not collected yet
+        self._last_fill = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -198,6 +219,10 @@ class HipContext(object):
     def _check(self, rc, err=None):
         if rc == OK:
             return
+        if rc == RETRY:
+            # (the methods below collect deferred passes - and repeat one that outgrew its row buffers - before they
+            # read its output: _settling)
+            raise RuntimeError("libsitator_hip: a deferred fill asked to be repeated (SIT_RETRY); call fill_result()")
         if rc == E_INVALID:
             raise ValueError(self.message())
         if rc == E_NOT_CONVERGED:
@@ -273,10 +298,11 @@ class HipContext(object):
         self.M = len(mobile_idx)
         self.N = self.F * self.M
         self.frame0 = int(frame0)
-        p = FillParams(int(dynamic_lattice_mapping), int(relaxed_lattice_checks), int(check_for_zeros), 1, 0, 1, 0.0)
+        p = FillParams.make(dynamic_lattice_mapping, relaxed_lattice_checks, check_for_zeros, 1, 0, 1, 0.0)
         nz = i64(0)
         err = SitError()
         fitted = C.c_int(0)
+        self._deferred = 0
         rc = self.lib.sit_upload_fill_fit(self._h, _d(frames), self.F, self.A, _i(static_idx), len(static_idx),
                                           _i(mobile_idx), self.M, self.frame0, C.byref(p), float(fit_threshold),
                                           C.byref(nz), C.byref(err), C.byref(fitted))
@@ -293,8 +319,8 @@ class HipContext(object):
         """One pass over the resident frames (``sit_fill``).  ``assign``: the site assignment in the same pass (rows of up
         to four entries inside the fill kernel).  ``defer``: enqueue only; status, ``n_all_zero`` and the error come from
         ``fill_result()`` (or a later ``fill`` / ``synchronize``)."""
-        p = FillParams(int(dynamic_lattice_mapping), int(relaxed_lattice_checks), int(check_for_zeros),
-                       int(store_rows), int(assign), 1, float(predict_threshold), int(defer), 0)
+        p = FillParams.make(dynamic_lattice_mapping, relaxed_lattice_checks, check_for_zeros, store_rows, assign, 1,
+                            predict_threshold, defer)
         nz = i64(0)
         err = SitError()
         if assign:
@@ -302,6 +328,7 @@ class HipContext(object):
             self.labels_digest = None
         self._last_fill = p
         rc = self.lib.sit_fill(self._h, C.byref(p), C.byref(nz), C.byref(err))
+        self._deferred = self._deferred + 1 if (defer and rc == OK) else 0
         return rc, nz.value, err
 
     def fill_result(self):
@@ -310,6 +337,7 @@ class HipContext(object):
         nz = i64(0)
         err = SitError()
         rc = self.lib.sit_fill_result(self._h, C.byref(nz), C.byref(err))
+        self._deferred = 0
         if rc == RETRY:
             p = self._last_fill
             p.defer = 0
@@ -602,6 +630,13 @@ class HipContext(object):
     def comm_destroy(self):
         self.lib.sit_comm_destroy(self._h)
 
+    def comm_info(self):
+        """What the RCCL communicator reports about itself (``sit_comm_info``)."""
+        v = np.zeros(6, dtype=np.int32)
+        self._check(self.lib.sit_comm_info(self._h, v.ctypes.data_as(_i32p)))
+        return {"ranks": int(v[0]), "rank": int(v[1]), "device": int(v[2]), "rccl_version": int(v[3]),
+                "asked_ranks": int(v[4]), "asked_rank": int(v[5])}
+
     def comm_allreduce(self, arr, op="sum"):
         """In place on a contiguous float64 / int64 / uint64 array."""
         code = {np.dtype(np.float64): 0, np.dtype(np.int64): 1, np.dtype(np.uint64): 2}[arr.dtype]
@@ -661,3 +696,26 @@ class HipContext(object):
 
     def synchronize(self):
         self._check(self.lib.sit_synchronize(self._h))
+
+
+def _settling(fn):
+    """Deferred ``fill`` passes are collected before their output is read: a failed pass raises here (as the reference
+    raises from inside its frame loop, landmark/helpers.pyx:76-92,116-118), a pass that outgrew its row buffers is run
+    again at the rigorous width (``fill_result``)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        if self._deferred:
+            rc, _, err = self.fill_result()
+            self._check(rc, err)
+        return fn(self, *args, **kwargs)
+    return wrapper
+
+
+for _name in ("rows_dense", "rows_sparse", "fit_push_stored_rows", "predict", "assignments", "count_zero_rows", "gram",
+              "gram_limbs", "weighted_row_sums", "weighted_row_sums_limbs", "best_match", "best_match_groups",
+              "site_anchors", "site_sums", "check_occupancy", "site_counts", "jump_sources", "jump_list",
+              "jump_analysis", "assign_last_known", "running_mode", "set_centers"):
+    setattr(HipContext, _name, _settling(getattr(HipContext, _name)))
+del _name

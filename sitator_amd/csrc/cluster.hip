@@ -313,6 +313,9 @@ extern "C" int sit_set_centers(sit_ctx *c, const double *centers, i64 K, int nor
     if (!c || !centers) return SIT_ERR_INVALID;
     SIT_REQUIRE(c, c->D > 0 && K > 0, "sit_set_centers: basis must be set and K > 0");
     HIP_TRY(c, hipSetDevice(c->device));
+    // deferred passes assign against the centres in place: they are waited for (their failure, if any, stays to be
+    // collected) before the arrays they read are replaced
+    if (c->fill_ring) { const int rcd = fill_results_wait(c); if (rcd) return rcd; }
     const i64 D = c->D;
     // CSC (per landmark the centres holding it, ascending centre id) in two row-major passes over the dense matrix:
     // walking it column by column strides through K x D doubles (15 ms per call at C4: 1 585 x 2 048)
@@ -498,6 +501,7 @@ int sit_predict_internal(sit_ctx *c, double threshold, bool words_reset) { retur
 extern "C" int sit_get_assignments(sit_ctx *c, i64 *labels, double *confs, i64 *counts)
 {
     if (!c) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->assign_valid, "no assignments on the device");
     HIP_TRY(c, hipSetDevice(c->device));
     static const size_t staged_min = [] { const char *v = getenv("SITATOR_STAGED_D2H_MB"); const long long n = v ? atoll(v) : -1; return (size_t)(n >= 0 ? n : 64) << 20; }();
@@ -533,6 +537,7 @@ __global__ __launch_bounds__(256) void k_count_zero_rows(const i32 *nnz, i64 N, 
 extern "C" int sit_count_zero_rows(sit_ctx *c, i64 *n_zero, i64 *first_row)
 {
     if (!c || !n_zero || !first_row) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->rows_valid, "sit_count_zero_rows: no landmark rows on the device");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, sizeof(u64), c->stream));
@@ -554,6 +559,7 @@ extern "C" int sit_predict(sit_ctx *c, double threshold, i64 *labels, double *co
 {
     if (!c) return SIT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    SIT_SETTLE(c);
     int rc = run_predict(c, threshold);
     if (rc) return rc;
     return sit_get_assignments(c, labels, confs, counts);
@@ -829,6 +835,7 @@ int fit_stream_rows(sit_ctx *c, i64 row_lo, i64 nrows, double threshold)
 extern "C" int sit_fit_push_stored_rows(sit_ctx *c, double threshold)
 {
     if (!c) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->rows_valid, "sit_fit_push_stored_rows: no landmark rows on the device");
     HIP_TRY(c, hipSetDevice(c->device));
     StageTimer t(c, T_FIT);
@@ -1154,6 +1161,7 @@ __global__ void k_limbs_to_double(const u64 *hi, const u64 *lo, i64 n, double *o
 // limbs: hi[D*D], lo[D*D] (may be null: then G[D*D] doubles are produced instead)
 static int gram_impl(sit_ctx *c, double *G, u64 *hi, u64 *lo, i64 *seen)
 {
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->rows_valid, "sit_gram: no landmark rows on the device");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 D = c->D, DD = D * D;
@@ -1258,6 +1266,7 @@ __global__ void k_row_dot_norm(const i32 *nnz, const i32 *idx, const double *val
 extern "C" int sit_best_match(sit_ctx *c, const double *cvec, i64 *row_out, double *dot, double *norm)
 {
     if (!c || !cvec || !row_out || !dot || !norm) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->rows_valid && c->N > 0, "sit_best_match: no landmark rows on the device");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 nb = (c->N + 255) / 256;
@@ -1355,6 +1364,7 @@ extern "C" int sit_best_match_groups(sit_ctx *c, const int32_t *group_of_dim, co
                                      double *dots, double *norms)
 {
     if (!c || !group_of_dim || !cvec || !rows || !dots || !norms) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->rows_valid && G > 0, "sit_best_match_groups: no landmark rows on the device");
     HIP_TRY(c, hipSetDevice(c->device));
     for (i64 d = 0; d < c->D; d++)
@@ -1406,6 +1416,7 @@ __global__ void k_weighted_row_sums(const i32 *nnz, const i32 *idx, const double
 // out: [K*D + K] doubles (sums then weights), or the raw limbs
 static int weighted_row_sums_impl(sit_ctx *c, int weighted, i64 K, double *sums, double *wsum, u64 *hi, u64 *lo)
 {
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->rows_valid && c->assign_valid && K > 0, "sit_weighted_row_sums: rows and assignments needed");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 D = c->D, n = K * D + K;

@@ -23,6 +23,10 @@ struct RcclApi {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     std::string err;
 };
 
@@ -47,6 +51,10 @@ RcclApi *rccl()
     SIT_SYM(AllGather, "ncclAllGather");
     SIT_SYM(Broadcast, "ncclBroadcast");
     SIT_SYM(GetErrorString, "ncclGetErrorString");
+    SIT_SYM(CommCount, "ncclCommCount");
+    SIT_SYM(CommUserRank, "ncclCommUserRank");
+    SIT_SYM(CommCuDevice, "ncclCommCuDevice");
+    SIT_SYM(GetVersion, "ncclGetVersion");
 #undef SIT_SYM
     return &api;
 }
@@ -94,6 +102,25 @@ extern "C" int sit_comm_create(sit_ctx *c, const uint8_t *id128, int rank, int w
     ncclComm_t comm = nullptr;
     RCCL_TRY(c, api, api->CommInitRank(&comm, world, id, rank));
     c->comm = comm; c->comm_rank = rank; c->comm_size = world;
+    return SIT_OK;
+}
+
+// What the COMMUNICATOR says about itself (not what sit_comm_create was told): out[0] = ncclCommCount, out[1] =
+// ncclCommUserRank, out[2] = ncclCommCuDevice, out[3] = ncclGetVersion, out[4] / out[5] = the world size / rank passed to
+// sit_comm_create.  A bench line that prints these from every rank proves its own rank count.
+extern "C" int sit_comm_info(sit_ctx *c, int32_t *out6)
+{
+    if (!c || !out6) return SIT_ERR_INVALID;
+    RcclApi *api;
+    int rc = need_comm(c, &api);
+    if (rc) return rc;
+    int v[4] = {-1, -1, -1, -1};
+    RCCL_TRY(c, api, api->CommCount((ncclComm_t)c->comm, &v[0]));
+    RCCL_TRY(c, api, api->CommUserRank((ncclComm_t)c->comm, &v[1]));
+    RCCL_TRY(c, api, api->CommCuDevice((ncclComm_t)c->comm, &v[2]));
+    RCCL_TRY(c, api, api->GetVersion(&v[3]));
+    for (int i = 0; i < 4; i++) out6[i] = v[i];
+    out6[4] = c->comm_size; out6[5] = c->comm_rank;
     return SIT_OK;
 }
 

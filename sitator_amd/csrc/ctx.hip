@@ -6,6 +6,7 @@
 #include <mutex>
 #include <vector>
 
+#include <cstddef>
 #include "sit_internal.h"
 
 // ---- the process-wide pool of large device buffers (see sit_internal.h) ---------------------------------------------
@@ -254,6 +255,15 @@ extern "C" void sit_destroy(sit_ctx *c)
 
 extern "C" const char *sit_last_message(sit_ctx *c) { return c ? c->msg.c_str() : "null context"; }
 
+// the layout of the boundary as this library was built (include/sitator_hip.h)
+extern "C" int sit_abi(int32_t *out, int n)
+{
+    const int32_t v[6] = {SIT_ABI_VERSION, (int32_t)sizeof(sit_error), (int32_t)sizeof(sit_fill_params),
+                          (int32_t)offsetof(sit_fill_params, predict_threshold), (int32_t)offsetof(sit_error, frame), 128};
+    if (out) for (int i = 0; i < n && i < 6; i++) out[i] = v[i];
+    return 6;
+}
+
 extern "C" int sit_timers(sit_ctx *c, double *ms, int n)
 {
     if (!c || !ms) return SIT_ERR_INVALID;
@@ -282,8 +292,9 @@ extern "C" int sit_synchronize(sit_ctx *c)
     if (!c) return SIT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // deferred fills: their results have landed now; a failure among them is this call's status (sit_fill_result has
-    // the details and clears it)
+    // deferred fills: their results have landed now and are decoded (the flags of the rows / assignments follow); a
+    // failure among them is reported - once - by sit_fill_result, the next sit_fill, or whatever reads their output
+    // first (fill_settle), not here: this call has no way to hand out the details and would keep failing
     return fill_results_landed(c);
 }
 
@@ -473,6 +484,7 @@ int set_frame_meta(sit_ctx *c, i64 F, i64 A, const i64 *static_idx, i64 S, const
     SIT_REQUIRE(c, F >= 0 && A > 0 && M > 0 && S == c->S && static_idx && mobile_idx,
                 "sit_set_frames: bad arguments (S must match the basis)");
     SIT_REQUIRE(c, F * M < (1LL << 40), "sit_set_frames: too many rows");
+    { const int rcd = fill_ring_discard(c); if (rcd) return rcd; }     // deferred passes over the old frames: waited for, dropped
     std::vector<i32> s32((size_t)S), m32((size_t)M);
     for (i64 i = 0; i < S; i++) {
         SIT_REQUIRE(c, static_idx[i] >= 0 && static_idx[i] < A, "static index out of range");

@@ -128,6 +128,7 @@ extern "C" int sit_jump_analysis(sit_ctx *c, i64 K, const i64 *last_known_in, co
                                  i64 *n_problems, i64 *last_known_out, i64 *time_at_current_out)
 {
     if (!c || !n_ij || !time_sum || !time_n || !total_time || !n_problems) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->assign_valid && K > 0, "sit_jump_analysis: assignments needed");
     SIT_REQUIRE(c, (last_known_in == nullptr) == (time_at_current_in == nullptr), "sit_jump_analysis: halo arrays come in pairs");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -256,6 +257,7 @@ extern "C" int sit_assign_last_known(sit_ctx *c, i64 frame_threshold, const i64 
                                      i64 *labels_out, i32 *frame_max, i64 *stats3, i64 *last_known_out, i64 *time_unknown_out)
 {
     if (!c || !stats3 || !frame_max) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->assign_valid, "sit_assign_last_known: assignments needed");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 M = c->M, F = c->F, N = c->N;
@@ -324,6 +326,7 @@ extern "C" int sit_running_mode(sit_ctx *c, i64 wleft, i64 wright, i64 threshold
                                 i64 *counts)
 {
     if (!c || !out) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->assign_valid && wleft >= 0 && wright >= 0, "sit_running_mode: assignments needed");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 N = c->N;

@@ -405,6 +405,7 @@ int label_counts_of(sit_ctx *c, const i64 *d_labels, i64 N, i64 K, i64 *counts_h
 extern "C" int sit_site_counts(sit_ctx *c, i64 K, i64 *counts)
 {
     if (!c || !counts) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->assign_valid && K > 0, "sit_site_counts: no assignments on the device");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = ensure_scratch(c, K * 8);
@@ -484,6 +485,7 @@ struct FillPending {
     u64 *host = nullptr;              // 9 words in the pinned buffer
     bool v3 = false, rows_measured = false;
     bool live = false;
+    u64 seq = 0;                      // order of enqueueing
 };
 #define FILL_RING 4
 struct FillRing {
@@ -492,6 +494,7 @@ struct FillRing {
     int rc_first = SIT_OK;            // first failure among the decoded results not yet reported
     sit_error err_first = {0, -1, -1, 0};
     i64 n_all_zero_last = 0;
+    u64 seq = 0, last_rigorous_seq = 0;   // passes enqueued so far; the latest of them that ran at the rigorous row width
 };
 
 static FillRing *fill_ring(sit_ctx *c)
@@ -510,7 +513,9 @@ void fill_ring_free(sit_ctx *c)
 }
 
 // decode one landed result; returns its status
-static int fill_decode(sit_ctx *c, const FillPending &s, i64 *n_all_zero, sit_error *err)
+// (superseded: a pass at the rigorous row width has been enqueued behind this one - its overflow has been served already and
+// the flags belong to the later pass)
+static int fill_decode(sit_ctx *c, const FillPending &s, i64 *n_all_zero, sit_error *err, bool superseded)
 {
     const u64 *hb = s.host;
     const u64 hkey = hb[0], hs[4] = {hb[1], hb[2], hb[3], hb[4]};
@@ -520,6 +525,7 @@ static int fill_decode(sit_ctx *c, const FillPending &s, i64 *n_all_zero, sit_er
     const int kind = decode_error(c, hkey, err);
     if (kind != SIT_OK) { c->assign_valid = false; return kind; }
     if (s.v3 && hs[3]) {
+        if (s.rows_measured && superseded) return SIT_OK;
         c->assign_valid = false; c->rows_valid = false;
         if (s.rows_measured) { c->rows_overflowed = true; return SIT_RETRY; }       // a row beyond the measured width: once more at the rigorous one
         c->msg = "landmark row wider than the pruning bound (internal error)";
@@ -542,7 +548,7 @@ static int fill_drain(sit_ctx *c, bool wait)
         }
         sit_error e = {0, -1, -1, 0};
         i64 nz = 0;
-        const int rc = fill_decode(c, s, &nz, &e);
+        const int rc = fill_decode(c, s, &nz, &e, r->last_rigorous_seq > s.seq);
         r->n_all_zero_last = nz;
         if (rc != SIT_OK && r->rc_first == SIT_OK) { r->rc_first = rc; r->err_first = e; }
         s.live = false;
@@ -554,8 +560,32 @@ static int fill_drain(sit_ctx *c, bool wait)
 int fill_results_landed(sit_ctx *c)
 {
     if (!c->fill_ring) return SIT_OK;
-    const int rc = fill_drain(c, false);
-    return rc ? rc : ((FillRing *)c->fill_ring)->rc_first;
+    return fill_drain(c, false);
+}
+
+int fill_results_wait(sit_ctx *c)
+{
+    FillRing *r = (FillRing *)c->fill_ring;
+    return r && r->count > 0 ? fill_drain(c, true) : SIT_OK;
+}
+
+int fill_settle(sit_ctx *c)
+{
+    FillRing *r = (FillRing *)c->fill_ring;
+    if (!r) return SIT_OK;
+    if (r->count > 0) { const int rc = fill_drain(c, true); if (rc) return rc; }
+    if (r->rc_first != SIT_OK && r->rc_first != SIT_RETRY) c->msg = "a deferred sit_fill failed; sit_fill_result has the details";
+    if (r->rc_first == SIT_RETRY) c->msg = "a deferred sit_fill met a row wider than its buffers: call sit_fill again (SIT_RETRY)";
+    return r->rc_first;
+}
+
+int fill_ring_discard(sit_ctx *c)
+{
+    FillRing *r = (FillRing *)c->fill_ring;
+    if (!r) return SIT_OK;
+    const int rc = r->count > 0 ? fill_drain(c, true) : SIT_OK;
+    r->rc_first = SIT_OK; r->err_first = {0, -1, -1, 0};
+    return rc;
 }
 
 extern "C" int sit_fill_result(sit_ctx *c, i64 *n_all_zero, sit_error *err)
@@ -575,6 +605,7 @@ extern "C" int sit_fill_result(sit_ctx *c, i64 *n_all_zero, sit_error *err)
 extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, sit_error *err)
 {
     if (!c || !p) return SIT_ERR_INVALID;
+    SIT_REQUIRE(c, p->struct_size == sizeof(sit_fill_params), "sit_fill: sit_fill_params.struct_size is not this library's sizeof(sit_fill_params) - the binding was written against another include/sitator_hip.h");
     SIT_REQUIRE(c, c->D > 0 && c->d_frames && c->M > 0, "sit_fill: basis and frames must be set first");
     HIP_TRY(c, hipSetDevice(c->device));
     if (err) { err->kind = 0; err->frame = -1; err->index = -1; err->aux = 0; }
@@ -667,6 +698,8 @@ extern "C" int sit_fill(sit_ctx *c, const sit_fill_params *p, i64 *n_all_zero, s
         if (!s.ev) HIP_TRY(c, hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
         s.host = (u64 *)((char *)c->h_pinned + 512) + 9 * ((ring->head + ring->count) % FILL_RING);
         s.v3 = v3; s.rows_measured = rows_measured; s.live = true;
+        s.seq = ++ring->seq;
+        if (!rows_measured) ring->last_rigorous_seq = s.seq;
         HIP_TRY(c, hipMemcpyAsync(s.host, c->d_err, 72, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipEventRecord(s.ev, c->stream));
         ring->count++;
@@ -809,6 +842,7 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
 {
     if (!c || !frames || !p || !fitted) return SIT_ERR_INVALID;
     *fitted = 0;
+    SIT_REQUIRE(c, p->struct_size == sizeof(sit_fill_params), "sit_upload_fill_fit: sit_fill_params.struct_size is not this library's sizeof(sit_fill_params) - the binding was written against another include/sitator_hip.h");
     HIP_TRY(c, hipSetDevice(c->device));
     // frames per chunk, at least: SITATOR_PIPE_CHUNK_FRAMES (4096) - tests lower it so that short trajectories (the
     // reference's goldens) take this path, chunked
@@ -1021,6 +1055,7 @@ extern "C" int sit_row_width(sit_ctx *c, i64 *w)
 extern "C" int sit_get_rows_dense(sit_ctx *c, i64 row0, i64 nrows, double *out)
 {
     if (!c || !out) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->rows_valid && row0 >= 0 && nrows >= 0 && row0 + nrows <= c->N, "sit_get_rows_dense: bad range or no rows");
     if (nrows == 0) return SIT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1038,6 +1073,7 @@ extern "C" int sit_get_rows_dense(sit_ctx *c, i64 row0, i64 nrows, double *out)
 extern "C" int sit_get_rows_sparse(sit_ctx *c, i64 row0, i64 nrows, i32 *nnz, i32 *idx, double *val)
 {
     if (!c || !nnz || !idx || !val) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->rows_valid && row0 >= 0 && nrows >= 0 && row0 + nrows <= c->N, "sit_get_rows_sparse: bad range or no rows");
     if (nrows == 0) return SIT_OK;
     HIP_TRY(c, hipSetDevice(c->device));

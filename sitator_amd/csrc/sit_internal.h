@@ -471,7 +471,20 @@ int predict_listed_rows(sit_ctx *c, double threshold, i32 *wlist, unsigned *wcou
 int download_staged(sit_ctx *c, hipStream_t stream, void *dst, const void *src, size_t bytes);   // fill.hip: large read-backs
 int reset_fill_words(sit_ctx *c);                                  // ctx.hip: error key and counters in one launch
 void fill_ring_free(sit_ctx *c);                                   // fill.hip
-int fill_results_landed(sit_ctx *c);                               // fill.hip: decode what has landed, report the first failure
+int fill_results_landed(sit_ctx *c);                               // fill.hip: decode the deferred results that have landed
+// Deferred sit_fill passes (sit_fill_params.defer) mark their rows / assignments as present when they are ENQUEUED; their
+// error word is decoded later.  Whatever reads rows, labels or counts first waits for the passes in flight and returns
+// their first failure instead of handing out the output of a pass that ended in a domain error or asked for a retry
+// (ADVICE r4).  The failure stays with the ring: sit_fill_result has the details and clears it.
+int fill_settle(sit_ctx *c);
+#define SIT_SETTLE(ctx)                                                                 \
+    do {                                                                                \
+        const int rc_settle_ = fill_settle(ctx);                                        \
+        if (rc_settle_ != SIT_OK) return rc_settle_;                                    \
+    } while (0)
+// new frames / centres: results of passes over the old ones are waited for and dropped
+int fill_ring_discard(sit_ctx *c);
+int fill_results_wait(sit_ctx *c);                                 // wait for and decode every pass in flight (failures stay to be collected)
 // comm.hip: n exact accumulators (hi, lo) and nseen counters summed over the ranks of c->comm_peer, on c->stream;
 // work = 3 n words of device scratch
 int comm_allreduce_limbs_device(sit_ctx *c, u64 *dhi, u64 *dlo, i64 n, u64 *dseen, i64 nseen, u64 *work);

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256) void k_site_sums_final(const double *partials,
 extern "C" int sit_site_anchors(sit_ctx *c, int weighted, i64 K, double *wmax, i64 *first_row, double *anchor_pts)
 {
     if (!c || !wmax || !first_row || !anchor_pts) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->assign_valid && c->d_frames && K > 0, "sit_site_anchors: assignments and frames needed");
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = ensure_scratch(c, K * (8 + 8 + 24));
@@ -191,6 +192,7 @@ extern "C" int sit_site_anchors(sit_ctx *c, int weighted, i64 K, double *wmax, i
 extern "C" int sit_site_sums(sit_ctx *c, int weighted, i64 K, const double *anchor_pts, double *sums)
 {
     if (!c || !anchor_pts || !sums) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->assign_valid && c->d_frames && K > 0, "sit_site_sums: assignments and frames needed");
     SIT_REQUIRE(c, K * 36 <= 150 * 1024, "sit_site_sums: too many sites for the LDS-private partial sums");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -265,6 +267,7 @@ extern "C" int sit_check_occupancy(sit_ctx *c, i64 K, i64 max_per_site, i64 *n_m
                                    sit_error *err)
 {
     if (!c || !n_multi || !total || !nsites) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->assign_valid && K > 0, "sit_check_occupancy: assignments needed");
     SIT_REQUIRE(c, K * 4 <= 150 * 1024, "sit_check_occupancy: too many sites for the LDS histogram");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -398,6 +401,7 @@ static int jump_scan(sit_ctx *c, int unknown_as_jump, const i64 *last_known_in, 
 extern "C" int sit_jump_sources(sit_ctx *c, int unknown_as_jump, const i64 *last_known_in, i64 *from, i64 *last_known_out)
 {
     if (!c || !from) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->assign_valid, "sit_jump_sources: assignments needed");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 N = c->N, M = c->M, nch = (c->F + JCH - 1) / JCH;
@@ -415,6 +419,7 @@ extern "C" int sit_jump_list(sit_ctx *c, int unknown_as_jump, const i64 *last_kn
                              i64 *n_records, i64 *last_known_out)
 {
     if (!c || !n_records || (max_records > 0 && !records)) return SIT_ERR_INVALID;
+    SIT_SETTLE(c);
     SIT_REQUIRE(c, c->assign_valid && max_records >= 0, "sit_jump_list: assignments needed");
     HIP_TRY(c, hipSetDevice(c->device));
     const i64 M = c->M, nch = (c->F + JCH - 1) / JCH;

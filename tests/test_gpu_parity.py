@@ -374,3 +374,55 @@ def test_pipelined_call_keeps_what_chunk_zero_reported_through_a_later_shape_tri
         assert la_p._pipelined and not la_s._pipelined
         assert la_p.n_all_zero_lvecs == la_s.n_all_zero_lvecs == 2
         assert np.array_equal(st_p.traj, st_s.traj)
+
+
+def test_integration_md_binding_fills_the_reference_golden(monkeypatch):
+    """INTEGRATION.md section B, executed: the ctypes stub a reference maintainer would paste, its
+    `fill_landmark_vectors` run on the C1 golden and compared with the landmark vectors of the true reference
+    (`landmark/helpers.pyx:12`, called at `landmark/LandmarkAnalysis.py:220`) - and a binding with the struct of an
+    older header is refused instead of read past."""
+    import ctypes as C
+    import sys
+    import types
+    from tests.test_abi import exec_integration_md
+    from sitator_amd import errors
+    # the stub imports the reference's exception classes; here they are the package's mirror of them
+    for name in ("sitator", "sitator.landmark"):
+        monkeypatch.setitem(sys.modules, name, types.ModuleType(name))
+    monkeypatch.setitem(sys.modules, "sitator.landmark.errors", errors)
+    ns = exec_integration_md(monkeypatch)
+    c = case("c1_hex_scgrid")
+    exp = c.out("dotprod")
+
+    class Analysis(object):                       # the attributes of LandmarkAnalysis the replaced function reads
+        _cutoff_midpoint, _cutoff_steepness, static_movement_threshold = 1.5, 30, 1.0
+        dynamic_lattice_mapping = relaxed_lattice_checks = False
+
+    la = Analysis()
+    la._landmark_vectors = np.zeros(exp["lvecs"].shape)
+    ns["fill_landmark_vectors"](la, make_sn(c), c.verts_np, c.site_vert_dists, c.frames)
+    assert_lvecs(la._landmark_vectors, exp["lvecs"])
+    assert la.n_all_zero_lvecs == int(exp["n_all_zero_lvecs"])
+    # a zero landmark vector raises the reference's exception with its attributes
+    z = case("c1_zero_lvecs")
+    kw, want = z.kwargs("raise"), z.out("raise")
+    la2 = Analysis()
+    la2._cutoff_midpoint, la2._cutoff_steepness = kw["cutoff_midpoint"], kw["cutoff_steepness"]
+    la2._landmark_vectors = np.zeros((len(z.frames) * int(z.mobile_mask.sum()), len(z.verts_np)))
+    with pytest.raises(errors.ZeroLandmarkError) as ei:
+        ns["fill_landmark_vectors"](la2, make_sn(z), z.verts_np, z.site_vert_dists, z.frames)
+    assert (ei.value.frame, ei.value.mobile_index) == (int(want["error_frame"]), int(want["error_mobile_index"]))
+    # the round-4 stub (seven fields, no struct_size): refused with SIT_ERR_INVALID, nothing is read past it
+    lib, h = ns["_lib"], la._hip
+
+    class old_params(C.Structure):
+        _fields_ = [("dynamic_lattice_mapping", C.c_int32), ("relaxed_lattice_checks", C.c_int32),
+                    ("check_for_zeros", C.c_int32), ("store_rows", C.c_int32), ("assign", C.c_int32),
+                    ("predict_normed", C.c_int32), ("predict_threshold", C.c_double)]
+
+    p = old_params(0, 0, 1, 1, 0, 1, 0.0)
+    nz, err = C.c_int64(0), ns["sit_error"]()
+    lib.sit_fill.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]
+    assert lib.sit_fill(h, C.byref(p), C.byref(nz), C.byref(err)) == 1
+    assert b"struct_size" in lib.sit_last_message(h)
+    lib.sit_destroy(h)
