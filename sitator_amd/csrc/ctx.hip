@@ -240,7 +240,7 @@ extern "C" void sit_destroy(sit_ctx *c)
                     c->frames_owned ? c->d_frames : nullptr, c->d_static_idx, c->d_mobile_idx,
                     c->d_lattice_map, c->d_tbin_off, c->d_tbin_list, c->d_fill_args, c->d_frame_dmax, c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs,
                     c->d_counts, c->d_col_ptr, c->d_col_k, c->d_col_val, c->d_cen_dense, c->d_fit_centers,
-                    c->d_vh, c->d_nv, c->d_exptab, c->d_pack, c->d_bin_crit, c->d_tbin_crit,
+                    c->d_vh, c->d_vh16, c->d_ref_soa, c->d_nv, c->d_exptab, c->d_pack, c->d_bin_crit, c->d_tbin_crit,
                     c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scratch};
     for (void *p : ptrs) if (p) sit_dfree(c, p);
     fitfast_free(c);
@@ -469,7 +469,7 @@ extern "C" int sit_set_basis(sit_ctx *c, const double *ref_static, i64 S, const 
             if (i != j && (c->pbc.cm[3 * i + j] != 0.0 || c->pbc.ci[3 * i + j] != 0.0)) c->cell_diagonal = false;
     const char *fk = getenv("SITATOR_FILL_KERNEL");
     c->fill_kernel = (fk && fk[0] == '1') ? 1 : 3;
-    for (void **q : {(void **)&c->d_vh, (void **)&c->d_nv}) if (*q) { sit_dfree(c, *q); *q = nullptr; }
+    for (void **q : {(void **)&c->d_vh, (void **)&c->d_vh16, (void **)&c->d_ref_soa, (void **)&c->d_nv}) if (*q) { sit_dfree(c, *q); *q = nullptr; }
     c->tight_valid = false;
     c->rows_valid = false; c->assign_valid = false; c->map_valid = false;
     return SIT_OK;

@@ -57,6 +57,9 @@ struct Fill3Args {
                                       //   exactly 1) - what a (task, vertex) lane needs, one 16-byte gather -, the exact
                                       //   squared-distance threshold (+inf on padding), the same plus the error bound of
                                       //   the cheap distance}
+    const uint4 *vh16;                // [D,Vp] the first 16 bytes of the vh records, packed (CHEAP: a task's eight records are one
+                                      //   128-byte line; the 32-byte records put them on two - the L1 serves a line per cycle and
+                                      //   this kernel's gathers keep it busy two cycles in three, round 5)
     const unsigned char *nvtab;       // [D]
     const uint4 *pack;                // list entries of the primary table, then of the fallback table, 16 bytes each:
                                       // {landmark << (LG + 5) | critical vertex << 5 = byte offset of that record in vh,
@@ -93,11 +96,12 @@ struct Fill3Head {
     Pbc P;
     const double *frames;
     const i32 *static_idx, *mobile_idx;
-    const double *ref_static;
+    const double *ref_static;         // [3,S]: x of every static atom, then y, then z (a wave's loads are three runs of 512 bytes)
     const double *frame_dmax;
     const double *exptab;
     i64 F, A, fbeg;                   // the launch covers frames [fbeg, F)
     int S, M, fpb, contig, debug_stop, rcap, iw, has_fallback, s0, m0, tt, mcap, frame_mod, prio;
+    int skipw;                        // CHEAP: static atoms stay as loaded (unwrapped) in LDS, see phase 1b
     double delta2, thr2_lo, thr2_hi, static_thr, safe2;
 };
 typedef const Fill3Args __attribute__((address_space(4))) *Fill3ArgsPtr;
@@ -123,11 +127,14 @@ __host__ __device__ inline F3Layout f3_layout(int fpb, int SM, int M, int nw, in
     L.wave0 = o;
     int w = rcap * 8;                                    // prod: the product of the terms 1 + e of every survivor
     w = (w + 15) & ~15;
-    L.o_ionrec = w; w += iw * (fpb1 ? 4 : 16);           // per ion of the window: first entry - first task (and LDS offsets)
+    // FPB1: per NON-EMPTY list of the window, in ion order, {first entry - first task, ion} (one more than ions: an idle
+    // lane may look at the entry behind the last); else per ion {first entry - first task, LDS offsets, frame} and, behind
+    // them, the ion of every non-empty list
+    L.o_ionrec = w; w += fpb1 ? (iw + 1) * 8 : iw * 16 + ((iw + 1 + 15) & ~15);
     L.o_ttab = w; w += tt * 4;                           // landmark << (LG + 5) | ion of the window
     L.o_sv = w; w += rcap * 4;                           // the task of every survivor
     L.o_nzc = w; w += iw * 4;                            // entries written per ion
-    L.o_mark = w; w += mcap;                             // the ion that starts at a candidate task (0 elsewhere)
+    L.o_mark = w; w += mcap / 8 + 8;                     // a bit per candidate task of the window: set on the LAST task of every list
     L.wbytes = (w + 15) & ~15;
     L.total = L.wave0 + nw * L.wbytes;
     return L;
@@ -354,7 +361,8 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
             const char *rp = vh + ((tk_[u] & KMASK) | hh32);                                                               \
             const uint4 r0 = *(const uint4 *)rp;                     /* offset, static id, steepness / vcd: ONE gather */  \
             uint2 r1 = make_uint2(0u, 0u);                                                                                 \
-            if (!APPROX) r1 = *(const uint2 *)(rp + 16);             /* the exact threshold */                             \
+            if (!APPROX) r1 = CHEAP ? *(const uint2 *)((const char *)g.vh + 2u * ((tk_[u] & KMASK) | hh32) + 16)           \
+                                    : *(const uint2 *)(rp + 16);     /* the exact threshold (32-byte records) */             \
             unsigned voff, ionoff, statoff;                                                                                \
             F3_TASK_OFFSETS(tk_[u], r0.x, r0.y, voff, ionoff, statoff);                                                    \
             rv_[u] = __hiloint2double((int)r0.w, (int)r0.z);                                                               \
@@ -363,13 +371,15 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
             if (APPROX) {                                                                                                  \
                 double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];                                         \
                 qx = minimg1(qx, P.ci[0], P.cm[0]); qy = minimg1(qy, P.ci[4], P.cm[4]); qz = minimg1(qz, P.ci[8], P.cm[8]); \
-                d2_[u] = (qx * qx + qy * qy) + qz * qz;                                                                    \
+                d2_[u] = __builtin_fma(qz, qz, __builtin_fma(qy, qy, qx * qx));   /* (not the reference's order: the band decides) */ \
                 bad_[u] = 0ull;                                                                                            \
             } else {                                                                                                       \
                 double ox = op[0], oy = op[1], oz = op[2];                                                                 \
                 const double c0_ = CHEAP ? g.cen[0] : P.cen[0], c1_ = CHEAP ? g.cen[1] : P.cen[1], c2_ = CHEAP ? g.cen[2] : P.cen[2]; \
                 if (CHEAP) { ox = c0_ + ox; oy = c1_ + oy; oz = c2_ + oz; }                                                \
-                double qx = sp[0] + ox, qy = sp[1] + oy, qz = sp[2] + oz;                                                  \
+                double sx_ = sp[0], sy_ = sp[1], sz_ = sp[2];                                                              \
+                if (CHEAP && !DYN && h.skipw) wrapc3<CELL>(P, sx_, sy_, sz_);        /* LDS holds the atom as loaded */     \
+                double qx = sx_ + ox, qy = sy_ + oy, qz = sz_ + oz;                                                        \
                 wrapc3<CELL>(P, qx, qy, qz);                                                                               \
                 const double dx = qx - c0_, dy = qy - c1_, dz = qz - c2_;                                                  \
                 d2_[u] = (dx * dx + dy * dy) + dz * dz;                                                                    \
@@ -556,7 +566,10 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     constexpr bool CHEAP = CELL == 1;                           // minimum-image distances, decisions on the logistic argument
     constexpr int NT = NW * 64;
     constexpr int TPP = 64 >> LG;                               // tasks per pass of 64 lanes
-    constexpr int KSH = LG + 5;                                 // task = landmark << KSH | ion of the window
+    // task = landmark << KSH | ion of the window; landmark << KSH | vertex << (KSH - LG) is the byte offset of a vertex record:
+    // 32-byte records, or (CHEAP) the packed 16-byte ones
+    constexpr int KSH = CELL == 1 ? LG + 4 : LG + 5;
+    constexpr int RSH = KSH - LG;                               // log2 of a record's bytes
     constexpr unsigned KMASK = ~((1u << KSH) - 1u);
     constexpr unsigned long long LEADS = LG == 4 ? 0x0001000100010001ull : (LG == 3 ? 0x0101010101010101ull : 0x1111111111111111ull);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -578,7 +591,8 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     unsigned *ttab = (unsigned *)(wp + L.o_ttab);
     unsigned *sv = (unsigned *)(wp + L.o_sv);
     unsigned *nzc = (unsigned *)(wp + L.o_nzc);
-    unsigned char *mark = (unsigned char *)(wp + L.o_mark);
+    unsigned *mark = (unsigned *)(wp + L.o_mark);                // (+ 8 bytes: a pass reads two words)
+    unsigned char *rk2ion = (unsigned char *)(wp + L.o_ionrec) + 16 * IW;      // !FPB1
     const Pbc &P = h.P;
     const i64 f0 = h.fbeg + (i64)blockIdx.x * fpb;
     const int nf = FPB1 ? 1 : (int)((h.F - f0) < fpb ? (h.F - f0) : fpb);
@@ -598,7 +612,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     double etv = 0.0;
     if (tid < F3_EXPN) etv = h.exptab[tid];                    // in flight beside the frame loads; parked below
     for (int q = lane; q < TT; q += 64) ttab[q] = 0u;          // stale entries must stay valid tasks (landmark 0, ion 0)
-    for (int q = lane; q < (FPB1 ? IW : 4 * IW); q += 64) ionrec[q] = 0u;      // stale tasks look their ion up
+    for (int q = lane; q < (FPB1 ? 2 * (IW + 1) : 4 * IW + (IW + 4) / 4); q += 64) ionrec[q] = 0u;      // stale tasks look their ion up
     // ---- phase 1a: copy this workgroup's atoms into LDS ----
     {
         // (h.frame_mod > 0, an experiment: the workgroups read the first frame_mod frames over and over - the frames then
@@ -663,18 +677,25 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     __syncthreads();
     // ---- phase 1b: wrap in place (Step 0), static-lattice check (helpers.pyx:57-80); a mobile ion becomes its
     //      offset vector centroid - ion (helpers.pyx:100) and leaves its candidate list behind ----
+    // SKIPW (diagonal cells with the minimum-image distance; round 5): a static atom that lies within `safe` of its
+    // reference position as it was LOADED is left alone - no wrap, no store (8 of 9 atoms at C2: -15 vector
+    // instructions each).  The minimum-image vector of phase 2 does not care which periodic image the static atom is;
+    // what the wrap would have changed is rounding (an atom inside the cell) or a lattice translation, both inside
+    // the error bound of the cheap decision (fill3_basis_tables: the reference positions lie within [-0.25, 1.25) of
+    // the cell, so |coordinate| <= 1.7 L).  The paths that reproduce the reference's arithmetic (the static check
+    // beyond `safe`, the exact pass EX = 1) wrap the atom where they use it.
+    const bool skipw = CHEAP && !DYN && h.skipw != 0;
     for (int a = tid; a < nf * SM; a += NT) {
         int fl = 0;
         if (!FPB1) for (int q = 1; q < nf; q++) fl += a >= q * SM;
         const int r = a - fl * SM;
         double *d = xyz + 3 * a;
         double x = d[0], y = d[1], z = d[2];
-        wrapc3<CELL>(P, x, y, z);
         if (r < S) {
-            d[0] = x; d[1] = y; d[2] = z;
+            bool need_store = !skipw;
+            if (!skipw) wrapc3<CELL>(P, x, y, z);
             if (!DYN) {
-                const double *rp = h.ref_static + 3 * r;
-                const double rx = rp[0], ry = rp[1], rz_ = rp[2];
+                const double rx = h.ref_static[r], ry = h.ref_static[S + r], rz_ = h.ref_static[2 * S + r];
                 // plain displacement: it bounds the periodic one, and while it is shorter than 0.45 cell heights
                 // the shifted atom is inside the cell, where the reference's wrap changes it by rounding only -
                 // no error, no beyond-delta flag (safe2 is below both bounds)
@@ -683,6 +704,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                 if (!(e2 <= h.safe2)) {
                     // PBCCalculator.distances(ref, atom) (util/PBCCalculator.pyx:64-103), squared; the sqrt is
                     // taken only inside the rounding band around static_movement_threshold^2
+                    if (skipw) wrapc3<CELL>(P, x, y, z);            // (the reference's wrapped atom; LDS keeps the raw one)
                     const double c0 = CHEAP ? g.cen[0] : P.cen[0], c1 = CHEAP ? g.cen[1] : P.cen[1], c2 = CHEAP ? g.cen[2] : P.cen[2];
                     double qx = x + (c0 - rx), qy = y + (c1 - ry), qz = z + (c2 - rz_);
                     wrapc3<CELL>(P, qx, qy, qz);
@@ -695,13 +717,16 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                     }
                 }
             }
+            if (need_store) { d[0] = x; d[1] = y; d[2] = z; }
         } else {
+            wrapc3<CELL>(P, x, y, z);
             if (CHEAP) { d[0] = -x; d[1] = -y; d[2] = -z; }
             else { d[0] = P.cen[0] - x; d[1] = P.cen[1] - y; d[2] = P.cen[2] - z; }
             // the ion's list in the primary table, and its bin in the fallback table (taken by the frames in which
             // a static atom moved beyond delta: that is known after the barrier)
             const int b = bin_of3<CELL>(P, x, y, z, g.pG0, g.pG1, g.pG2);
-            const i32 lo = g.p_off[b], hi = g.p_off[b + 1];
+            i32 lo, hi;                                              // one 8-byte load (two loads take the L1 twice)
+            { uint2 pr; __builtin_memcpy(&pr, g.p_off + b, 8); lo = (i32)pr.x; hi = (i32)pr.y; }
             unsigned fb = 0u;
             if (h.has_fallback) fb = (unsigned)bin_of3<CELL>(P, x, y, z, g.fG0, g.fG1, g.fG2);
             ioninfo[fl * M + (r - S)] = make_uint2((unsigned)lo, (unsigned)(hi - lo) | (fb << 8));
@@ -717,13 +742,13 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     if (h.prio) __builtin_amdgcn_s_setprio(0);
 
     // phase-2 constants
-    const char *vh = (const char *)g.vh;
+    const char *vh = CHEAP ? (const char *)g.vh16 : (const char *)g.vh;
     const uint4 *pack = g.pack;
     const ExpK ek = expk_make(g.midpoint, g.steepness);
     const double x0lo = g.x0lo;
     const int nvu = g.nv_uniform;
     const int hh = lane & (VP - 1), gi = lane >> LG;            // my vertex, my task of a pass
-    const unsigned hh32 = (unsigned)hh << 5;
+    const unsigned hh32 = (unsigned)hh << RSH;
     const unsigned long long ltmask = (1ull << lane) - 1ull;
     const unsigned xyz_s = 24u * (unsigned)S;                   // byte offset of the first mobile ion in a frame of xyz[]
     // FUSE: the windows of GW waves (64 ions or fewer) are assigned together, by the last of them to finish; a wave has
@@ -748,20 +773,31 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                 const bool tight = DYN ? (h.frame_dmax[f0 + fl] * h.frame_dmax[f0 + fl] <= h.delta2) : (fmax[fl] == 0ull);
                 if (!tight) {
                     const unsigned fb = ii.y >> 8;
-                    const i32 flo = g.f_off[fb];
-                    nL = g.f_off[fb + 1] - flo; lo = g.f_base + (unsigned)flo;
+                    uint2 pr;
+                    __builtin_memcpy(&pr, g.f_off + fb, 8);
+                    nL = (int)(pr.y - pr.x); lo = g.f_base + pr.x;
                 }
             }
         }
         const int inL = wave_add_scan(nL), exL = inL - nL;
         const int nlt = __builtin_amdgcn_readlane(inL, 63);     // candidate tasks of the window
         if (nlt > h.mcap) { if (lane == 0) atomicAdd(&g.scal[3], 1ull); break; }      // cannot happen (host sizes mcap)
-        for (int q = 4 * lane; q < nlt; q += 256) *(unsigned *)(mark + q) = 0u;
-        if (lane < nib) {
-            if (nL > 0) mark[exL] = (unsigned char)lane;
-            if (FPB1) ionrec[lane] = lo - (unsigned)exL;
-            else ((uint4 *)ionrec)[lane] = make_uint4(lo - (unsigned)exL, 24u * (unsigned)(fl * SM + S + j), 24u * (unsigned)(fl * SM), (unsigned)fl);
-            nzc[lane] = 0u;
+        // the ion of a candidate task (round 5): a bit on the LAST task of every non-empty list; a task's list is then the
+        // r-th non-empty one, r = the number of bits below the task - two mbcnt on a scalar mask per pass, where a byte
+        // marker per task took a maximum scan over the lanes (6 DPP steps + 6 max)
+        for (int q = lane; q < 2 * ((nlt + 63) >> 6); q += 64) mark[q] = 0u;
+        {
+            const unsigned long long nem = __ballot(nL > 0);
+            if (lane < nib) {
+                if (nL > 0) {
+                    const int rk = mask_rank(nem, 0);
+                    atomicOr(&mark[(inL - 1) >> 5], 1u << ((inL - 1) & 31));
+                    if (FPB1) ((uint2 *)ionrec)[rk] = make_uint2(lo - (unsigned)exL, (unsigned)lane);
+                    else rk2ion[rk] = (unsigned char)lane;
+                }
+                if (!FPB1) ((uint4 *)ionrec)[lane] = make_uint4(lo - (unsigned)exL, 24u * (unsigned)(fl * SM + S + j), 24u * (unsigned)(fl * SM), (unsigned)fl);
+                nzc[lane] = 0u;
+            }
         }
         if (DBG && dbg == 9 && lane == 0) { atomicAdd(&g.scal[5], (u64)nlt); atomicAdd(&g.scal[7], 1ull); }
         const unsigned ionbase = xyz_s + 24u * (unsigned)ib0;   // FPB1: byte offset of the window's first offset vector
@@ -774,18 +810,20 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
             {
                 const int t = base + lane;
                 const unsigned long long vmask = first_lanes(nlt0 - base);
-                int mk = 0;
-                if (F3_LANES(vmask)) mk = (int)mark[t];
-                int ion = wave_max_scan(mk);
-                ion = ion > carry ? ion : carry;
-                carry = __builtin_amdgcn_readlane(ion, 63);
+                const uint2 mw = *(const uint2 *)(mark + (base >> 5));            // (one address for the wave)
+                const unsigned m_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)mw.x), m_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)mw.y);
+                const unsigned rk = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, (unsigned)carry));
+                carry += __builtin_popcount(m_lo) + __builtin_popcount(m_hi);
                 uint4 en = make_uint4(0u, 0u, 0u, 0x7ff00000u);   // an idle lane: landmark 0, static 0, threshold +inf
                 unsigned ionoff, statoff = 0u, tfl = 0u;
+                int ion;
                 if (FPB1) {
-                    const unsigned l0 = ionrec[ion];
-                    if (F3_LANES(vmask)) en = pack[l0 + (unsigned)t];
+                    const uint2 rr = ((const uint2 *)ionrec)[rk];
+                    ion = (int)rr.y;
+                    if (F3_LANES(vmask)) en = pack[rr.x + (unsigned)t];
                     ionoff = ionbase + 24u * (unsigned)ion;
                 } else {
+                    ion = (int)rk2ion[rk];
                     const uint4 ir = ((const uint4 *)ionrec)[ion];
                     if (F3_LANES(vmask)) en = pack[ir.x + (unsigned)t];
                     ionoff = ir.y; statoff = ir.z; tfl = ir.w;
@@ -801,7 +839,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                     // (the entry's threshold is the exact one plus the error bound of this distance: a candidate the
                     // reference keeps is never dropped here, and D1 + E decides)
                     qx = minimg1(qx, P.ci[0], P.cm[0]); qy = minimg1(qy, P.ci[4], P.cm[4]); qz = minimg1(qz, P.ci[8], P.cm[8]);
-                    d2 = (qx * qx + qy * qy) + qz * qz;
+                    d2 = __builtin_fma(qz, qz, __builtin_fma(qy, qy, qx * qx));
                 } else {
                     wrapc3<CELL>(P, qx, qy, qz);
                     const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
@@ -928,8 +966,11 @@ static int fill3_basis_tables(sit_ctx *c)
     std::vector<unsigned> vh((size_t)(8 * n));
     // CHEAP instantiations (diagonal cell): the error bounds of the minimum-image distance and of the logistic argument
     // against the reference's arithmetic, u = 2^-53, L = the longest cell edge.  Per component the reference's shift,
-    // wrap and subtract make six roundings of at most L u each, ours two: |dd| <= 7.5 L u; on the squared distance
-    // |dd2| <= 2 sqrt(3) |d| 7.5 L u + 4 d2 u <= (26 L sqrt(d2) + 8 d2) u.  The bounds are applied four times over.
+    // wrap and subtract make six roundings of at most L u each; ours (round 5: the static atom is used as loaded,
+    // |coordinate| <= 1.7 L, where the reference wraps it: two roundings of L u, or an exact lattice translation) the
+    // two of the omitted wrap, the sum static + offset (|w| <= 2.7 L: 2.7 L u) and the fma of the minimum image (L u / 2):
+    // |dd| <= 12 L u; on the squared distance |dd2| <= 2 sqrt(3) |d| 12 L u + 4 d2 u <= (42 L sqrt(d2) + 8 d2) u.
+    // The bounds are applied four times over.
     const double U53 = 0x1p-53;
     double Lmax = 0.0;
     for (int i = 0; i < 3; i++) Lmax = std::max(Lmax, std::fabs(c->pbc.cm[4 * i]));
@@ -950,7 +991,7 @@ static int fill3_basis_tables(sit_ctx *c)
             }
             // the threshold of the critical-vertex test on the cheap distance: nothing the reference keeps is dropped
             double t2hi = t2;
-            if (std::isfinite(t2) && t2 > 0.0) t2hi = t2 + 4.0 * (26.0 * Lmax * std::sqrt(t2) + 8.0 * t2) * U53;
+            if (std::isfinite(t2) && t2 > 0.0) t2hi = t2 + 4.0 * (42.0 * Lmax * std::sqrt(t2) + 8.0 * t2) * U53;
             unsigned long long tb, rb, hb;
             memcpy(&tb, &t2, 8);
             memcpy(&rb, &rv, 8);
@@ -964,14 +1005,14 @@ static int fill3_basis_tables(sit_ctx *c)
     }
     {
         // x = steepness (t - midpoint) at the cut-off t = rz; our x = sqrt(d2') steepness / vcd - steepness midpoint:
-        // |d sqrt(d2)| = |dd2| / (2 sqrt(d2)) <= (13 L + 4 sqrt(d2)) u, times steepness / vcd; the one-step sqrt (4.2e-15),
+        // |d sqrt(d2)| = |dd2| / (2 sqrt(d2)) <= (21 L + 4 sqrt(d2)) u, times steepness / vcd; the one-step sqrt (4.2e-15),
         // the rounding of steepness / vcd and the fma add 6e-15 of the product
         const double x0 = c->steepness * (c->rz - c->midpoint), smid = c->steepness * c->midpoint;
         c->f3_cheap_ok = c->cell_diagonal && vcd_ok && vcd_max > 0.0 && c->steepness > 0.0 && std::isfinite(c->steepness) &&
                          std::isfinite(x0) && std::isfinite(smid) && Lmax > 0.0 && std::isfinite(Lmax);
         if (c->f3_cheap_ok) {
             const double srv_max = c->steepness / vcd_min, sd_max = 1.01 * std::fabs(c->rz) * vcd_max;
-            const double eps = 4.0 * (srv_max * (13.0 * Lmax + 4.0 * sd_max) * U53 + (std::fabs(x0) + std::fabs(smid) + 1.0) * 6e-15);
+            const double eps = 4.0 * (srv_max * (21.0 * Lmax + 4.0 * sd_max) * U53 + (std::fabs(x0) + std::fabs(smid) + 1.0) * 6e-15);
             c->f3_x0lo = x0 - eps; c->f3_x0hi = x0 + eps;
             if (!(eps < 1e-6 * (1.0 + std::fabs(x0)))) c->f3_cheap_ok = false;     // a wide band would send every pass the long way
         }
@@ -990,6 +1031,29 @@ static int fill3_basis_tables(sit_ctx *c)
         if (hgt < hm) hm = hgt;
     }
     c->hmin = hm;
+    {
+        // the reference positions in fractions of the cell: phase 1b may leave a static atom unwrapped only if "within
+        // 0.45 cell heights of its reference position" bounds its coordinates (|coordinate| <= 1.7 L)
+        std::vector<double> ref((size_t)(3 * c->S));
+        HIP_TRY(c, hipMemcpy(ref.data(), c->d_ref_static, (size_t)(3 * c->S) * 8, hipMemcpyDeviceToHost));
+        bool ok = true;
+        for (i64 i = 0; i < c->S && ok; i++)
+            for (int q = 0; q < 3; q++) {
+                const double *r = c->pbc.ci + 3 * q;
+                const double f = r[0] * ref[(size_t)(3 * i)] + r[1] * ref[(size_t)(3 * i + 1)] + r[2] * ref[(size_t)(3 * i + 2)];
+                if (!(f >= -0.25 && f < 1.25)) ok = false;
+            }
+        c->f3_ref_in_cell = ok;
+        std::vector<double> soa((size_t)(3 * c->S));
+        for (i64 i = 0; i < c->S; i++) for (int q = 0; q < 3; q++) soa[(size_t)(q * c->S + i)] = ref[(size_t)(3 * i + q)];
+        int rcs;
+        if ((rcs = dev_upload(c, &c->d_ref_soa, soa.data(), 3 * c->S))) return rcs;
+    }
+    {
+        std::vector<unsigned> vh16((size_t)(4 * n));
+        for (i64 q = 0; q < n; q++) for (int w = 0; w < 4; w++) vh16[(size_t)(4 * q + w)] = vh[(size_t)(8 * q + w)];
+        if ((rc = dev_upload(c, &c->d_vh16, vh16.data(), 4 * n))) return rc;
+    }
     if ((rc = dev_upload(c, &c->d_vh, vh.data(), 8 * n))) return rc;      // last: its presence marks the tables as built
     return SIT_OK;
 }
@@ -997,12 +1061,14 @@ static int fill3_basis_tables(sit_ctx *c)
 // list entries as the kernel wants them, 16 bytes each: {landmark << ksh | critical vertex << 5 (the byte offset of that
 // vertex record in vh), 24 * its static id, its exact threshold} - a candidate test reads nothing else
 // (hi: the threshold with the error bound of the cheap distance on top, from the record's last eight bytes)
-__global__ __launch_bounds__(256) void k_pack_lists(const i32 *list, const unsigned char *crit, i64 n, int ksh, const uint4 *vh, uint4 *out, int hi)
+// (lg: log2 of the padded vertices per landmark; the offset is in records of 1 << rsh bytes, as the kernel's KSH / RSH)
+__global__ __launch_bounds__(256) void k_pack_lists(const i32 *list, const unsigned char *crit, i64 n, int lg, int rsh, const uint4 *vh, uint4 *out, int hi)
 {
     const i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const unsigned off = ((unsigned)list[i] << ksh) | ((unsigned)crit[i] << 5);
-    const uint4 r = vh[off >> 4], r2 = vh[(off >> 4) + 1];
+    const unsigned rec = ((unsigned)list[i] << lg) | (unsigned)crit[i];           // record number
+    const unsigned off = rec << rsh;
+    const uint4 r = vh[2 * (size_t)rec], r2 = vh[2 * (size_t)rec + 1];
     out[i] = hi ? make_uint4(off, r.x, r2.z, r2.w) : make_uint4(off, r.x, r2.x, r2.y);
 }
 
@@ -1019,9 +1085,9 @@ static int fill3_pack_lists(sit_ctx *c, bool have_tight, bool cheap)
     int rc;
     if ((rc = dev_alloc(c, &c->d_pack, 4 * ((i64)nt + (i64)nl + 1)))) return rc;       // 16 bytes per entry
     uint4 *pk = (uint4 *)c->d_pack;
-    const int ksh = (f3_vp(c) == 16 ? 4 : (f3_vp(c) == 8 ? 3 : 2)) + 5;
-    if (nt > 0) k_pack_lists<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_tbin_list, c->d_tbin_crit, nt, ksh, (const uint4 *)c->d_vh, pk, cheap ? 1 : 0);
-    if (nl > 0) k_pack_lists<<<dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_bin_list, c->d_bin_crit, nl, ksh, (const uint4 *)c->d_vh, pk + nt, cheap ? 1 : 0);
+    const int lg = f3_vp(c) == 16 ? 4 : (f3_vp(c) == 8 ? 3 : 2), rsh = cheap ? 4 : 5;      // (k_fill3: KSH = lg + rsh)
+    if (nt > 0) k_pack_lists<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_tbin_list, c->d_tbin_crit, nt, lg, rsh, (const uint4 *)c->d_vh, pk, cheap ? 1 : 0);
+    if (nl > 0) k_pack_lists<<<dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream>>>(c->d_bin_list, c->d_bin_crit, nl, lg, rsh, (const uint4 *)c->d_vh, pk + nt, cheap ? 1 : 0);
     HIP_TRY(c, hipGetLastError());
     c->pack_nt = nt; c->pack_gen = c->table_gen; c->pack_tight = have_tight ? 1 : 0; c->pack_cheap = cheap ? 1 : 0;
     return SIT_OK;
@@ -1109,7 +1175,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
                  f3_env_int("SITATOR_DEBUG_STOP", 0))) fuse = false;
     Fill3Args a;
     memset(&a, 0, sizeof(a));
-    a.vh = (const uint4 *)c->d_vh; a.nvtab = c->d_nv;
+    a.vh = (const uint4 *)c->d_vh; a.vh16 = (const uint4 *)c->d_vh16; a.nvtab = c->d_nv;
     a.pack = (const uint4 *)c->d_pack;
     a.f_off = c->d_bin_off; a.fG0 = c->G[0]; a.fG1 = c->G[1]; a.fG2 = c->G[2];
     a.f_base = (unsigned)c->pack_nt;
@@ -1129,7 +1195,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     Fill3Head h;
     memset(&h, 0, sizeof(h));
     h.P = c->pbc; h.frames = c->d_frames; h.static_idx = c->d_static_idx; h.mobile_idx = c->d_mobile_idx;
-    h.ref_static = c->d_ref_static;
+    h.ref_static = c->d_ref_soa;
     h.frame_dmax = p->dynamic_lattice_mapping ? c->d_frame_dmax : nullptr;
     h.exptab = c->d_exptab;
     h.F = f_hi; h.fbeg = f_lo; h.A = c->A;
@@ -1287,6 +1353,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     h.contig = contig;
     h.frame_mod = f3_env_int("SITATOR_F3_FRAME_MOD", 0);
     h.prio = f3_env_int("SITATOR_F3_PRIO", 1);
+    h.skipw = diag && !dynmap && c->f3_ref_in_cell && f3_env_int("SITATOR_F3_SKIPWRAP", 1) ? 1 : 0;
 
     // ---- survivor slots / task-table size: measured once per kind of fill ----
     if (rcap_auto && tt_auto && !fuse && h.debug_stop == 0 && f3_env_int("SITATOR_FILL_AUTOTUNE", 1) && (f_hi - f_lo) * M >= (1 << 18)) {

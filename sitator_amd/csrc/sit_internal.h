@@ -68,6 +68,8 @@ struct sit_ctx {
     double *d_frame_dmax = nullptr;   // [F] per-frame displacement maximum (dynamic mapping)
     // third-generation fill (fill3.hip): vertex records, vertex counts, exp table, lists
     unsigned *d_vh = nullptr;         // [D,Vp,8] {24 * static id, static id, exact squared-distance threshold, 1 / vcd, -}
+    unsigned *d_vh16 = nullptr;       // [D,Vp,4] the first 16 bytes of every d_vh record on their own (diagonal cells: all a (task, vertex) lane reads)
+    double *d_ref_soa = nullptr;      // [3,S] the reference positions, a coordinate at a time
     unsigned char *d_nv = nullptr;    // [D] vertices per landmark
     double *d_exptab = nullptr;       // [128] 2^(j/128)
     unsigned *d_pack = nullptr;       // list entries of the tight table, then of the loose table, as record offsets
@@ -79,6 +81,7 @@ struct sit_ctx {
     double hmin = 0;                  // smallest perpendicular height of the cell
     int last_kernel = 0, last_iw = 0, last_nw = 0, last_tt = 0;
     int nv_uniform = 0;               // > 0: every landmark has this many vertices
+    bool f3_ref_in_cell = false;      // every reference position within [-0.25, 1.25) of the cell (k_fill3 may leave statics unwrapped)
     bool f3_cheap_ok = false;         // k_fill3 may decide on the logistic argument (diagonal cell, steepness > 0, vcd > 0)
     double f3_x0lo = 0, f3_x0hi = 0;  // the argument at the cut-off -/+ the error bound of the kernel's
     bool last_fused = false;          // the last sit_fill assigned the narrow rows inside the fill kernel
