@@ -79,6 +79,7 @@ struct Fill3Args {
     double cen[3];                    // the cell's centroid for the instantiations that need it on rare paths only (CHEAP)
     double x0lo, x0hi;                // CHEAP: the logistic argument at the cut-off, minus / plus the error bound of ours
     int nv_uniform;                   // > 0: every landmark has this many vertices (nvtab is not read)
+    u64 *dbgbuf;                      // DBG = 2 builds, stops 10-12: [1024][4] span sums
     // ---- fused site assignment (FUSE = 1) ----
     int store;                        // rows are wanted in the row buffers as well
     const i32 *col_ptr, *col_k;       // the centres, CSC over the landmarks (sit_set_centers)
@@ -102,6 +103,8 @@ struct Fill3Head {
     i64 F, A, fbeg;                   // the launch covers frames [fbeg, F)
     int S, M, fpb, contig, debug_stop, rcap, iw, has_fallback, s0, m0, tt, mcap, frame_mod, prio;
     int skipw;                        // CHEAP: static atoms stay as loaded (unwrapped) in LDS, see phase 1b
+    int lay[12];                      // F3Layout of the launch, worked out on the host (the kernel spent ~100 scalar instructions per
+                                      //   wave on these offsets, behind the second barrier)
     double delta2, thr2_lo, thr2_hi, static_thr, safe2;
 };
 typedef const Fill3Args __attribute__((address_space(4))) *Fill3ArgsPtr;
@@ -241,6 +244,16 @@ __device__ __forceinline__ double root_chain(double p, int nv)
 }
 
 // ---- wave helpers --------------------------------------------------------------------------------------------------
+
+// issue priority of the wave (the instruction takes an immediate)
+__device__ __forceinline__ void f3_setprio(int lvl)
+{
+    if (lvl == 0) __builtin_amdgcn_s_setprio(0);
+    else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+    else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
 
 // An LDS pointer from a byte offset.  The kernel has no static LDS, so its dynamic allocation starts at LDS address 0
 // (checked at the top of the kernel): `smem + off` would add the symbol's address - a vector add of zero per look-up.
@@ -539,6 +552,15 @@ __device__ __forceinline__ double dpp_row_shl(double x)
                             __builtin_amdgcn_mov_dpp(lo, 0x100 + N, 0xf, 0xf, true));
 }
 
+// DBG = 2 builds, SITATOR_DEBUG_STOP = 10 / 11 / 12: where a wave's life goes - the shader clock (s_memtime) at the phase
+// boundaries, the differences summed over all waves into the census words (sit_info [24..27]): 10: start -> first
+// barrier, -> second barrier, -> window set-up done, D0 passes; 11: D1 + E passes, T + end of window, whole wave, number
+// of waves; 12: start -> frame requested, wait at the first barrier only, phase 1b, wait at the second barrier only
+// (summed per workgroup slot first - 1 024 slots of four words in the scratch buffer, k_f3_spans adds them up: 400 000 waves
+// adding to ONE word serialise, the timed kernel then measures its own atomics)
+#define F3_STAMP(var) do { if (DBG == 2 && dbg >= 10) var = __builtin_amdgcn_s_memtime(); } while (0)
+#define F3_SPAN(mode, word, t0, t1) do { if (DBG == 2 && dbg == (mode) && lane == 0) atomicAdd(&g.dbgbuf[4 * (blockIdx.x & 1023u) + (word)], (u64)((t1) - (t0))); } while (0)
+
 // LG: log2 of the padded vertices per landmark (2, 3 or 4).  NW: waves per workgroup.  DYN: dynamic lattice mapping
 // (static ids go through the frame's lattice map; the static-lattice check was made by k_lattice_map).  FPB1: one frame
 // per workgroup (the LDS offsets of an ion follow from its number; otherwise they are looked up).  FUSE: the site
@@ -578,7 +600,9 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rcap = h.rcap, IW = h.iw, TT = h.tt;
     const int dbg = DBG ? h.debug_stop : 0;                     // the ablation stops and the census live in the DBG = 1 build
-    const F3Layout L = f3_layout(fpb, SM, M, NW, rcap, IW, TT, h.mcap, FPB1);
+    F3Layout L;                                                 // (from the host: f3_layout(fpb, SM, M, NW, rcap, IW, TT, h.mcap, FPB1))
+    L.fmax = h.lay[0]; L.gsync = h.lay[1]; L.ioninfo = h.lay[2]; L.etab = h.lay[3]; L.wave0 = h.lay[4]; L.o_ionrec = h.lay[5];
+    L.o_ttab = h.lay[6]; L.o_sv = h.lay[7]; L.o_nzc = h.lay[8]; L.o_mark = h.lay[9]; L.wbytes = h.lay[10]; L.total = h.lay[11];
     double *xyz = (double *)smem;                               // [fpb][S + M][3]; mobiles become centroid - ion
     u64 *fmax = (u64 *)(smem + L.fmax);                         // [fpb]
     unsigned *garrive = (unsigned *)(smem + L.gsync);           // [NW] waves of a group that have finished their window
@@ -606,7 +630,12 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     // phase 1 at a raised issue priority: a new workgroup gets its frame requested and wrapped ahead of the arithmetic of
     // the six others on its CU - they have plenty to overlap with, it has nothing (round 4: 0.667 -> 0.655 ms at C2; the
     // other way round, or the priority kept through the window set-up or raised again for T: no gain)
-    if (h.prio) __builtin_amdgcn_s_setprio(3);
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, tsa = 0, tsb = 0, acc_d0 = 0, acc_d1 = 0;
+    F3_STAMP(ts0);
+    // (round 5: a raised priority for the stretches of phase 2 that ISSUE loads - the head of a D0 pass, the head of a D1 + E
+    // iteration - measured at levels 1-3 beside every phase-1 level: within noise of this, or worse)
+    const int prio1 = h.prio & 3;
+    if (prio1) f3_setprio(prio1);
     if (tid < fpb) fmax[tid] = 0ull;
     if (FUSE && tid < 2 * NW) garrive[tid] = 0u;
     double etv = 0.0;
@@ -674,7 +703,10 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
         }
     }
     if (tid < F3_EXPN) etab[tid] = etv;
+    F3_STAMP(tsa);
     __syncthreads();
+    F3_STAMP(ts1);
+    F3_SPAN(10, 0, ts0, ts1); F3_SPAN(12, 0, ts0, tsa); F3_SPAN(12, 1, tsa, ts1);
     // ---- phase 1b: wrap in place (Step 0), static-lattice check (helpers.pyx:57-80); a mobile ion becomes its
     //      offset vector centroid - ion (helpers.pyx:100) and leaves its candidate list behind ----
     // SKIPW (diagonal cells with the minimum-image distance; round 5): a static atom that lies within `safe` of its
@@ -732,14 +764,17 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
             ioninfo[fl * M + (r - S)] = make_uint2((unsigned)lo, (unsigned)(hi - lo) | (fb << 8));
         }
     }
+    F3_STAMP(tsb);
     __syncthreads();
+    F3_STAMP(ts2);
+    F3_SPAN(10, 1, ts1, ts2); F3_SPAN(12, 2, ts1, tsb); F3_SPAN(12, 3, tsb, ts2);
     // fmax[fl] != 0: some static atom of frame fl moved beyond delta -> the frame takes the fallback table
     if (tid < nf && h.has_fallback) {
         const bool tight = DYN ? (h.frame_dmax[f0 + tid] * h.frame_dmax[f0 + tid] <= h.delta2) : (fmax[tid] == 0ull);
         if (!tight) atomicAdd(&g.scal[2], 1ull);
     }
     if (dbg == 1) return;
-    if (h.prio) __builtin_amdgcn_s_setprio(0);
+    if (prio1) __builtin_amdgcn_s_setprio(0);
 
     // phase-2 constants
     const char *vh = CHEAP ? (const char *)g.vh16 : (const char *)g.vh;
@@ -801,12 +836,15 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
         }
         if (DBG && dbg == 9 && lane == 0) { atomicAdd(&g.scal[5], (u64)nlt); atomicAdd(&g.scal[7], 1ull); }
         const unsigned ionbase = xyz_s + 24u * (unsigned)ib0;   // FPB1: byte offset of the window's first offset vector
+        F3_STAMP(ts3);
+        F3_SPAN(10, 2, ts2, ts3);
         int t_end = 0, carry = 0, cnt = 0;
         spilled = false;
         const int nlt0 = (DBG && dbg == 2) ? 0 : nlt;           // ablation: stop after the owner stage
         for (int base = 0; base < nlt0; base += 64) {
             // ---- D0: a lane per candidate task: its ion (maximum scan over the start markers), its list entry, the
             //      CRITICAL vertex of (bin, landmark) tested; the tasks that pass are appended to the task table ----
+            F3_STAMP(ts4);
             {
                 const int t = base + lane;
                 const unsigned long long vmask = first_lanes(nlt0 - base);
@@ -849,6 +887,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                 if (F3_LANES(km)) ttab[mask_rank(km, t_end)] = (en.x & KMASK) | (unsigned)ion;
                 t_end += __popcll(km);
             }
+            if (DBG == 2 && dbg >= 10) { unsigned long long tq = __builtin_amdgcn_s_memtime(); acc_d0 += tq - ts4; ts4 = tq; }
             if (t_end <= TT - 64 && base + 64 < nlt0) continue;         // room for another pass of candidates
             if (DBG && dbg == 9 && lane == 0) atomicAdd(&g.scal[4], (u64)t_end);
             if (DBG && dbg == 3) t_end = 0;                     // ablation: stop after the critical-vertex test
@@ -874,8 +913,10 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                 if (cursor < pend) F3_T_ROUND(0);               // the list is full: its entries leave for the row buffers
             }
             t_end = 0;
+            if (DBG == 2 && dbg >= 10) { unsigned long long tq = __builtin_amdgcn_s_memtime(); acc_d1 += tq - ts4; }
         }
         if (DBG && dbg == 5) cnt = 0;                           // ablation: stop after the logistic factors
+        F3_STAMP(ts4);
         F3_T_ROUND(1);
         if (lane < nib) {
             int nnz = (int)nzc[lane];
@@ -887,6 +928,10 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                 if (g.check_zeros) atomicMin(g.err, (u64)(g.frame0 + f0 + fl) * errw + (u64)(S + 1 + j));
                 else atomicAdd(&g.scal[0], 1ull);
             }
+        }
+        if (DBG == 2 && dbg >= 10) {
+            unsigned long long te = __builtin_amdgcn_s_memtime();
+            F3_SPAN(10, 3, 0ull, acc_d0); F3_SPAN(11, 0, 0ull, acc_d1); F3_SPAN(11, 1, ts4, te); F3_SPAN(11, 2, ts0, te); F3_SPAN(11, 3, 0ull, 1ull);
         }
     }
     if (FUSE) {
@@ -1058,6 +1103,15 @@ static int fill3_basis_tables(sit_ctx *c)
     return SIT_OK;
 }
 
+__global__ void k_f3_spans(const u64 *buf, u64 *scal)
+{
+    const int w = threadIdx.x;
+    if (w >= 4) return;
+    u64 t = 0;
+    for (int b = 0; b < 1024; b++) t += buf[4 * b + w];
+    scal[4 + w] = t;
+}
+
 // list entries as the kernel wants them, 16 bytes each: {landmark << ksh | critical vertex << 5 (the byte offset of that
 // vertex record in vh), 24 * its static id, its exact threshold} - a candidate test reads nothing else
 // (hi: the threshold with the error bound of the cheap distance on top, from the record's last eight bytes)
@@ -1104,9 +1158,16 @@ bool fill3_eligible(sit_ctx *c)
 }
 
 // the instantiation for this cell / landmark width / waves per workgroup / mapping mode / frames per workgroup
-static hipError_t f3_dispatch(sit_ctx *c, const Fill3Head &h, Fill3ArgsPtr full, unsigned grid, size_t lds, int nw, int vp,
+static hipError_t f3_dispatch(sit_ctx *c, const Fill3Head &h_in, Fill3ArgsPtr full, unsigned grid, size_t lds, int nw, int vp,
                               bool diag, bool dynmap, bool fuse)
 {
+    Fill3Head h = h_in;
+    {
+        const int fpb1 = (nw != 4 || h.fpb == 1) ? 1 : 0;       // (as F3_PICK below)
+        const F3Layout L = f3_layout(fpb1 ? 1 : h.fpb, h.S + h.M, h.M, nw, h.rcap, h.iw, h.tt, h.mcap, fpb1);
+        const int v[12] = {L.fmax, L.gsync, L.ioninfo, L.etab, L.wave0, L.o_ionrec, L.o_ttab, L.o_sv, L.o_nzc, L.o_mark, L.wbytes, L.total};
+        for (int i = 0; i < 12; i++) h.lay[i] = v[i];
+    }
 #define F3_LAUNCH(CELL, LGV, NWV, DY, F1, DB, FU)                                                                              \
     do {                                                                                                                   \
         hipError_t e = lds_limit((const void *)k_fill3<CELL, LGV, NWV, DY, F1, DB, FU>, lds, c->device);                   \
@@ -1116,6 +1177,7 @@ static hipError_t f3_dispatch(sit_ctx *c, const Fill3Head &h, Fill3ArgsPtr full,
 #define F3_PICK3(CELL, LGV, NWV, F1)                                                                                           \
     do {                                                                                                                   \
         if (dynmap) F3_LAUNCH(CELL, LGV, NWV, 1, F1, 0, 0);                                                                \
+        else if (h.debug_stop >= 10) F3_LAUNCH(CELL, LGV, NWV, 0, F1, 2, 0);                                                  \
         else if (h.debug_stop) F3_LAUNCH(CELL, LGV, NWV, 0, F1, 1, 0);                                                     \
         else if (fuse) F3_LAUNCH(CELL, LGV, NWV, 0, F1, 0, 1);                                                             \
         else F3_LAUNCH(CELL, LGV, NWV, 0, F1, 0, 0);                                                                       \
@@ -1333,6 +1395,11 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
         a.labels = c->d_labels; a.confs = c->d_confs;
         a.normed = c->centers_normed; a.threshold = p->predict_threshold;
     }
+    if (h.debug_stop >= 10) {
+        if ((rc = ensure_scratch(c, 1024 * 4 * 8 + 64))) return rc;
+        a.dbgbuf = (u64 *)c->d_scratch;
+        HIP_TRY(c, hipMemsetAsync(a.dbgbuf, 0, 1024 * 4 * 8, c->stream));
+    }
     if (c->fill_args_host.size() != sizeof(Fill3Args) || memcmp(c->fill_args_host.data(), &a, sizeof(Fill3Args)) != 0) {
         c->fill_args_host.assign((const char *)&a, (const char *)&a + sizeof(Fill3Args));
         HIP_TRY(c, hipMemcpyAsync(c->d_fill_args, c->fill_args_host.data(), sizeof(Fill3Args), hipMemcpyHostToDevice, c->stream));
@@ -1352,7 +1419,7 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     }
     h.contig = contig;
     h.frame_mod = f3_env_int("SITATOR_F3_FRAME_MOD", 0);
-    h.prio = f3_env_int("SITATOR_F3_PRIO", 1);
+    h.prio = f3_env_int("SITATOR_F3_PRIO", 3);             // issue priority of phase 1 (0-3)
     h.skipw = diag && !dynmap && c->f3_ref_in_cell && f3_env_int("SITATOR_F3_SKIPWRAP", 1) ? 1 : 0;
 
     // ---- survivor slots / task-table size: measured once per kind of fill ----
@@ -1429,5 +1496,6 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     } else if (fuse_asked && (rc = reset_fill_words(c))) return rc;   // a caller that asks for the fused pass leaves the reset to it
     if (f_hi <= f_lo) return SIT_OK;
     HIP_TRY(c, f3_dispatch(c, h, full, grid, lds, nw, vp, diag, dynmap, fuse));
+    if (h.debug_stop >= 10) { k_f3_spans<<<dim3(1), dim3(64), 0, c->stream>>>(a.dbgbuf, c->d_scal); HIP_TRY(c, hipGetLastError()); }
     return SIT_OK;
 }
