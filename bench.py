@@ -54,7 +54,8 @@ def parse():
     ap.add_argument("--config", default=None, help="C2 (BASELINE.json configs[1]) at every N; C4 = configs[3]'s per-GPU share")
     ap.add_argument("--algo", default=None, help="clustering plugin of the end-to-end run: dotprod, or mcl (the default of C5)")
     ap.add_argument("--cpu-frames", type=int, default=1000, help="frames per core of the CPU-baseline cut (0 = skip)")
-    ap.add_argument("--no-scale-ref", action="store_true", help="N = 1, default workload: skip the extra pass over one GPU's share of configs[3] (C4)")
+    ap.add_argument("--no-scale-ref", action="store_true", help="default workload: skip the extra passes over the other BASELINE configurations (C3, C4's per-GPU share, C5)")
+    ap.add_argument("--repeats", type=int, default=4, help="further timed regions of K steps behind the reported one (min / median of ms_per_step)")
     return ap.parse_args()
 
 
@@ -262,18 +263,53 @@ def main():
     tot1 = ctx.timer_totals()
     laps = {k: ((tot1[k][0] - tot0[k][0]) / max(1, tot1[k][1] - tot0[k][1]), tot1[k][1] - tot0[k][1]) for k in ("fill", "predict")}
     assert laps["fill"][1] == args.steps and laps["predict"][1] == args.steps, laps
-    if comm is not None:
+    elapsed_own = elapsed
+
+    def max_over_ranks(x):
+        if comm is None:
+            return float(x)
         if hasattr(comm, "allreduce_max"):
-            elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
-        else:
-            elapsed = float(np.max(comm.allgather(np.array([elapsed]))))
+            return float(comm.allreduce_max(np.array([x]))[0])
+        return float(np.max(comm.allgather(np.array([x]))))
+
+    elapsed = max_over_ranks(elapsed)
+    # The reported region is 20 x 0.8 ms: one hiccup is 5 %.  Further regions of K steps each (every one bracketed like
+    # the first; the maximum over the ranks each), for a minimum and a median beside the value.
+    regions = [1e3 * elapsed / args.steps]
+    for _ in range(max(0, args.repeats)):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync_all()
+        regions.append(1e3 * max_over_ranks(time.perf_counter() - t0) / args.steps)
     info = ctx.info()
 
+    # N > 1: the line proves its own rank count - what every rank's RCCL communicator says about itself (read back
+    # from the library, not what the launcher asked for) and every rank's own rate
+    rccl_info = per_rank_value = None
+    if comm is not None:
+        mine = comm.info() if hasattr(comm, "info") else {"ranks": comm.size, "rank": comm.rank, "device": local, "rccl_version": 0}
+        got = comm.allgather(np.array([mine["ranks"], mine["rank"], mine["device"], mine.get("rccl_version", 0)], dtype=np.int64))
+        rccl_info = {"backend": exchange, "ranks": [int(x) for x in got[:, 0]], "rank": [int(x) for x in got[:, 1]],
+                     "device": [int(x) for x in got[:, 2]], "rccl_version": int(got[0, 3])}
+        per_rank_value = [float(x) for x in comm.allgather(np.array([F * M * args.steps / elapsed_own]))[:, 0]]
     labels, confs, counts = ctx.assignments()
     checks = {"unassigned_frac": float(np.mean(labels < 0)), "sites": int(len(counts)),
               "labels_equal_end_to_end_run": bool(np.array_equal(labels, e2e_labels)),
               "label_checksum": int(np.sum(labels[labels >= 0] * 7 + 1) % 1000003)}
 
+    # N > 1, default workload: every rank also times one GPU's share of configs[3] (C4: 125 000 of the 1e6 frames) - the
+    # configuration BASELINE.json names for the 8-GPU run - bracketed by barriers; the record carries the sum over the ranks
+    c4 = None
+    if world > 1 and args.config == "C2" and F == FRAMES_PER_GPU["C2"] and not args.no_scale_ref:
+        del frames, la, st_full
+        comm.barrier()
+        c4 = other_config(args, local, "C4")
+        vals = comm.allgather(np.array([c4["value"], c4["ms_per_step"]]))
+        c4["value_per_rank"] = [float(x) for x in vals[:, 0]]
+        c4["value"] = float(np.sum(vals[:, 0]) * np.min(vals[:, 1]) / np.max(vals[:, 1]))     # all ranks' vectors over the slowest rank's time
+        c4["ms_per_step"] = float(np.max(vals[:, 1]))
+        c4["workload"] = c4["workload"].replace("(one GPU's share of the 8-GPU run)", "per GPU, %d GPUs" % world)
     if rank == 0:
         n_lvec = world * F * M * args.steps
         value = n_lvec / elapsed
@@ -287,6 +323,11 @@ def main():
             "metric": "landmark-vectors/sec (frames x mobile atoms), fill + site assignment",
             "value": value, "unit": "lvec/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step_regions": {"n": len(regions), "min": min(regions), "median": float(np.median(regions)), "max": max(regions),
+                                    "note": "regions of K steps each; the first is the reported one"},
+            # how the pass was run: enqueued with defer = 1 (no host synchronisation per pass, every pass's
+            # error word collected before the clock stops), labels + confidences written, landmark rows not kept
+            "pass_mode": {"workload_id": args.config, "deferred": True, "store_rows": False, "assign": True},
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s, %d frames per GPU" % (synth.CONFIG_TEXT.get(args.config, args.config), F),
                        "frames_per_gpu": F, "n_mobile": M, "n_static": S, "landmark_dim": D,
@@ -300,7 +341,11 @@ def main():
                          # `bound` names the roofline the kernel is priced against (its bytes are 1.09x the algorithmic
                          # ones: no wasted traffic); what the counters say holds it below that roofline
                          # (profiles/pmc_valu.json, taken with this build; null if the library has changed since):
-                         "limiter": limiter_of(valu), "valu": valu},
+                         "limiter": limiter_of(valu), "valu": valu,
+                         # SURVEY 8(d)'s other roofline: FP64 vector lane-instructions per second of the kernel against
+                         # the FP64 vector peak (256 CUs x 4 SIMDs x 16 FP64 lanes per clock x 2.4 GHz = 39.3e12 lane-
+                         # instructions/s = the guide's 78.6 TFLOP/s with an fma as two); from the same counter set
+                         "valu_frac": valu_fraction(valu, F * M, fill_avg_ms)},
             "clock_ramp_steps": ramp,
             "fill_shape": {k: info.get(k) for k in ("waves_per_workgroup", "frames_per_workgroup", "survivors_per_wave", "task_table_per_wave", "assignment_fused")},
             "stages_ms": {"fill": fill_avg_ms, "predict": float(laps["predict"][0]), "h2d_frames": h2d_ms,
@@ -308,13 +353,21 @@ def main():
             "end_to_end_run": e2e,
             "checks": checks,
         }
+        if comm is not None:
+            out["rccl"] = rccl_info
+            out["value_per_rank"] = per_rank_value
         if args.cpu_frames > 0 and world == 1:          # a reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(host, gen, frames, ref, fit_ctx_centers, M, args.cpu_frames, ncpu)
         if world == 1 and args.config == "C2" and F == FRAMES_PER_GPU["C2"] and not args.no_scale_ref:
-            # BASELINE configs[3] (C4: 1e6 frames over 8 GPUs) is the configuration named for the multi-GPU runs: the N = 1
-            # line also carries the same pass over ONE GPU's share of it (`--gpus N --config C4` times it on N GPUs).
+            # The other BASELINE configurations in the same line: C3 (configs[2], the larger one-GPU configuration, at its
+            # stated size), one GPU's share of C4 (configs[3]; also `scale_ref`: what `--gpus N --config C4` times on N GPUs)
+            # and of C5 (configs[4]: the end-to-end run is Markov clustering + jump detection).
             del frames, ctx, la, st_full
-            out["scale_ref"] = scale_reference(args, local)
+            out["configs"] = [other_config(args, local, c) for c in ("C3", "C4", "C5")]
+            out["scale_ref"] = {k: v for k, v in out["configs"][1].items() if k in ("workload", "value", "unit", "ms_per_step", "steps")}
+            out["scale_ref"]["end_to_end_run_seconds_cold"] = out["configs"][1]["end_to_end_run"]["cold_seconds"]
+        if c4 is not None:
+            out["configs"] = [c4]
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
@@ -323,23 +376,31 @@ def main():
             comm.close()
 
 
-def scale_reference(args, device):
-    """The timed pass of `--gpus N` (N > 1) on one GPU: one rank's share of BASELINE configs[3]."""
+def other_config(args, device, cfg):
+    """Another BASELINE configuration on this GPU, in brief: the end-to-end `run()` (cold, then warm) and the timed pass
+    with its roofline fractions."""
     import numpy as np
-    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth, _lib
-    cfg, F = "C4", FRAMES_PER_GPU["C4"]
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure, synth
+    F = FRAMES_PER_GPU[cfg]
     host = synth.config_host(cfg)
     M = synth.CONFIG_MOBILE[cfg]
+    A = len(host.static_pos) + M
     gen = synth.TrajectoryGenerator(host, M, seed=synth.CONFIG_SEED[cfg], threads=16)
     ref = gen.reference_positions()
     frames = gen.generate(F)
     sn = SiteNetwork(Structure(ref, host.cell), gen.static_mask, gen.mobile_mask)
     sn.centers = host.centers
     sn.vertices = host.vertices
+    kw = {"clustering_algorithm": "mcl", "max_mobile_per_site": 2} if cfg == "C5" else {}
     t0 = time.time()
-    la = LandmarkAnalysis(verbose=False, device=device)
-    la.run(sn, frames)
+    LandmarkAnalysis(verbose=False, device=device, **kw).run(sn, frames)
+    t_cold = time.time() - t0
+    t0 = time.time()
+    la = LandmarkAnalysis(verbose=False, device=device, **kw)
+    st = la.run(sn, frames)
     t_run = time.time() - t0
+    n_jumps = sum(1 for _ in st.jumps())
+    t_e2e = time.time() - t0
     ctx = la._ctx
     centers = np.asarray(la.cluster_centers_)
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -355,12 +416,25 @@ def scale_reference(args, device):
 
     passes(12)
     steps = max(3, args.steps // 2)
+    tot0 = ctx.timer_totals()
     t0 = time.perf_counter()
     passes(steps)
     dt = time.perf_counter() - t0
-    return {"workload": "%s, %d frames (one GPU's share of the N > 1 runs)" % (synth.CONFIG_TEXT.get(cfg, cfg), F),
+    tot1 = ctx.timer_totals()
+    lap = {k: (tot1[k][0] - tot0[k][0]) / max(1, tot1[k][1] - tot0[k][1]) for k in ("fill", "predict")}
+    bpl = 24.0 * A / M + 16.0
+    info = ctx.info()
+    return {"workload": "%s, %d frames%s" % (synth.CONFIG_TEXT.get(cfg, cfg), F, " (one GPU's share of the 8-GPU run)" if cfg in ("C4", "C5") else ""),
             "value": F * M * steps / dt, "unit": "lvec/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
-            "end_to_end_run_seconds_cold": round(t_run, 4)}
+            "stages_ms": {"fill": float(lap["fill"]), "predict": float(lap["predict"])},
+            "roofline": {"bound": "hbm", "kernel": "k_fill%d" % info["fill_kernel"], "kernel_ms": float(lap["fill"]),
+                         "algorithmic_bytes_per_lvec": bpl, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": F * M * bpl / (lap["fill"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_step": F * M * bpl / dt * steps / 1e9 / HBM_PEAK_GBS},
+            "fill_shape": {k: info.get(k) for k in ("waves_per_workgroup", "frames_per_workgroup", "assignment_fused")},
+            "end_to_end_run": {"algo": kw.get("clustering_algorithm", "dotprod"), "seconds": round(t_e2e, 4), "cold_seconds": round(t_cold, 4),
+                               "run_seconds": round(t_run, 4), "jumps": n_jumps, "sites": int(st.site_network.n_sites),
+                               "lvec_per_s": round(F * M / t_e2e, 1)}}
 
 
 def lib_sha():
@@ -383,6 +457,15 @@ def measured_traffic(kernel):
     except Exception:
         pass
     return None
+
+
+FP64_LANE_INSTS_PER_S = 256 * 4 * 16 * 2.4e9
+
+
+def valu_fraction(valu, n_lvec, kernel_ms):
+    if not valu or "floor_insts_per_ion" not in valu or not kernel_ms:
+        return None
+    return valu["floor_insts_per_ion"] * n_lvec * 64.0 / (kernel_ms * 1e-3) / FP64_LANE_INSTS_PER_S
 
 
 def limiter_of(valu):

@@ -383,6 +383,11 @@ class RcclComm(Comm):
     def barrier(self):
         self.ctx.comm_barrier()
 
+    def info(self):
+        """What the communicator says about itself (``sit_comm_info``: ncclCommCount / ncclCommUserRank /
+        ncclCommCuDevice read back, not what ``from_env`` was told)."""
+        return self.ctx.comm_info()
+
     def close(self):
         self.ctx.comm_destroy()
         self.ctx.close()
