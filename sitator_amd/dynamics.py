@@ -47,12 +47,22 @@ class JumpAnalysis(object):
             last_in = tac_in = None
             parts = None
             for r in range(comm.size):
+                failure = None
                 if comm.rank == r:
-                    parts = ctx.jump_analysis(n_sites, last_in, tac_in)
-                    halo = np.stack([parts[5], parts[6]])
+                    try:
+                        parts = ctx.jump_analysis(n_sites, last_in, tac_in)
+                        halo = np.stack([parts[5], parts[6]])
+                    except IndexError as e:
+                        # (a label beyond the site tables on THIS rank: the others are about to wait for the halo - they
+                        # get a flag instead and everybody raises)
+                        failure = e
+                        halo = np.full((2, sn.n_mobile), np.iinfo(np.int64).min, dtype=np.int64)
                 else:
                     halo = np.zeros((2, sn.n_mobile), dtype=np.int64)
                 halo = comm.bcast(halo, root=r)
+                if sn.n_mobile > 0 and halo[1, 0] == np.iinfo(np.int64).min:
+                    raise failure if failure is not None else IndexError(
+                        "a site index beyond the %d sites of the network in the frames of rank %d" % (n_sites, r))
                 if comm.rank == r + 1:
                     last_in, tac_in = halo[0], halo[1]
             n_ij = comm.allreduce_sum(parts[0])

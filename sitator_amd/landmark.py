@@ -19,7 +19,7 @@ import time
 
 import numpy as np
 
-from . import _lib, errors
+from . import _lib, errors, progress
 from .dotprod_classifier import LandmarkVectors
 from .pbc import PBCCalculator
 from .sharding import Comm
@@ -192,7 +192,9 @@ class LandmarkAnalysis(object):
             if fitted:
                 prefit = thr
             self._pipelined = bool(fitted)      # the pipelined call was taken (tests look at this)
-            lap("upload")
+            # (one call: the upload, the fill of the chunks as they land and the first pass of fit_centers behind them -
+            # at every BASELINE size the ordered fit, not the PCIe link, is what it waits for: DESIGN.md section 9)
+            lap("upload+fill+fit" if fitted else "upload")
         else:
             ctx.set_frames(frames, static_idx, mobile_idx, frame0=frame0)
             if self._recenter_masses is not None:
@@ -207,6 +209,8 @@ class LandmarkAnalysis(object):
         if not self.check_for_zero_landmarks and self.n_all_zero_lvecs > 0:
             logger.warning("     Had %i all-zero landmark vectors; no error because `check_for_zero_landmarks = False`."
                            % self.n_all_zero_lvecs)
+        # the reference's "Landmark Frame" bar (landmark/helpers.pyx:50): one launch here, so one line when it is done
+        progress.stage("Landmark Frame", n_frames, time.perf_counter() - t_last[0] + wall.get("upload", 0.0) + wall.get("upload+fill+fit", 0.0), unit="frame")
         self._landmark_vectors = LandmarkVectors(ctx, comm)
         self._landmark_vectors.prefit_threshold = prefit    # the first pass of fit_centers is in the context already
         self._landmark_vectors.fit_mode = self._fit_mode
@@ -220,6 +224,8 @@ class LandmarkAnalysis(object):
             min_samples=self._minimum_site_occupancy / float(sn.n_mobile), verbose=self.verbose)
 
         lap("cluster")
+        if self.verbose:                                       # `verbose`: the clustering algorithm's own output (:81)
+            progress.stage("Clustering (%s)" % self._cluster_algo, n_frames * sn.n_mobile, wall["cluster"], unit="sample")
         cluster_counts = clustering[self.CLUSTERING_CLUSTER_SIZE]
         lmk_lbls = clustering[self.CLUSTERING_LABELS]
         lmk_confs = clustering[self.CLUSTERING_CONFIDENCES]
@@ -251,7 +257,6 @@ class LandmarkAnalysis(object):
         lap("site_centers")
         # the label array was made for this call and nothing else refers to it: adopted, not copied (0.9 GB at C3)
         out_st = SiteTrajectory(out_sn, lmk_lbls, lmk_confs, _ctx=ctx, _comm=comm, _adopt=True)
-        out_st._labels_from_kernel = True      # written by the assignment kernel against these very sites
         self.n_multiple_assignments, self.avg_mobile_per_site = out_st.check_multiple_occupancy(
             max_mobile_per_site=self.max_mobile_per_site)
         # the context is shared with this object (predict() through landmark_vectors rewrites its labels and bumps
@@ -301,9 +306,12 @@ class LandmarkAnalysis(object):
         self._children = las
         self._landmark_dimension = first._landmark_dimension
         self._landmark_vectors = _StackedLandmarkVectors([la._landmark_vectors for la in las])
-        for name in ("n_all_zero_lvecs", "n_multiple_assignments", "avg_mobile_per_site", "cluster_centers_", "timings",
-                     "wall_timings", "fit_timings"):
+        # results every shard agrees on (they were reduced over the shards) ...
+        for name in ("n_all_zero_lvecs", "n_multiple_assignments", "avg_mobile_per_site", "cluster_centers_"):
             setattr(self, name, getattr(first, name, None))
+        # ... and the diagnostics per device, in `devices` order
+        for name in ("timings", "wall_timings", "fit_timings"):
+            setattr(self, name, [getattr(la, name, None) for la in las])
         out_st = SiteTrajectory(sts[0].site_network, np.concatenate([st.traj for st in sts]),
                                 np.concatenate([st.confidences for st in sts]), _adopt=True)
         out_st.set_real_traj(frames)
@@ -378,10 +386,50 @@ class LandmarkAnalysis(object):
 
 
 class _StackedLandmarkVectors(object):
-    """``landmark_vectors`` of a ``devices=[...]`` run: the shards' rows one after the other, densified on demand."""
+    """``landmark_vectors`` of a ``devices=[...]`` run: the shards' rows one after the other, densified on demand.  A
+    HOST-side view (read-only, like the reference's memmap): ``shape`` / ``len`` / row indexing / ``np.asarray`` work; the
+    classifier entry points that need device-resident rows (``DotProdClassifier.predict(la.landmark_vectors)``) take the
+    per-device handles in ``parts``."""
 
     def __init__(self, parts):
-        self.parts = parts
+        self.parts = list(parts)
+        self._offsets = np.concatenate([[0], np.cumsum([p.shape[0] for p in self.parts])]).astype(np.int64)
+
+    @property
+    def shape(self):
+        return (int(self._offsets[-1]), int(self.parts[0].shape[1]) if self.parts else 0)
+
+    @property
+    def ndim(self):
+        return 2
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float64)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, key):
+        """Rows by integer, slice or index array (then anything numpy allows on the dense rows picked)."""
+        rest = ()
+        if isinstance(key, tuple):
+            key, rest = key[0], key[1:]
+        n = self.shape[0]
+        if isinstance(key, (int, np.integer)):
+            r = int(key) + (n if key < 0 else 0)
+            if not 0 <= r < n:
+                raise IndexError("row %d out of %d" % (key, n))
+            part = int(np.searchsorted(self._offsets, r, side="right") - 1)
+            row = np.asarray(self.parts[part][r - int(self._offsets[part])])
+            return row[rest] if rest else row
+        rows = np.arange(n)[key]
+        out = np.empty((len(rows), self.shape[1]))
+        which = np.searchsorted(self._offsets, rows, side="right") - 1
+        for part in np.unique(which):
+            sel = which == part
+            out[sel] = np.asarray(self.parts[int(part)][rows[sel] - int(self._offsets[int(part)])])
+        return out[(slice(None),) + rest] if rest else out
 
     def __array__(self, dtype=None, copy=None):
         out = np.concatenate([np.asarray(p) for p in self.parts])

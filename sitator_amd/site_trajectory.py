@@ -53,9 +53,6 @@ class SiteTrajectory(object):
         self._ctx = _ctx
         self._synced_version = _ctx.labels_version if _ctx is not None else -1
         self._host_shared = False
-        # True only for labels written by the assignment kernel (LandmarkAnalysis.run sets it) that have not left the
-        # object since: those are below n_sites by construction.  Anything else is looked at before it indexes a table.
-        self._labels_from_kernel = False
         self._comm = _comm
 
     # -- container protocol ---------------------------------------------------------------

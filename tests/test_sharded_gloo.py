@@ -177,3 +177,11 @@ def test_devices_mode_threads_reproduce_the_reference(name, tag, n, monkeypatch)
     np.testing.assert_allclose(np.asarray(st.site_network.centers), exp["site_centers"], rtol=1e-6, atol=1e-8)
     assert int(la.n_multiple_assignments) == int(exp["n_multiple_assignments"])
     assert la.n_all_zero_lvecs == int(exp["n_all_zero_lvecs"])
+    # the stacked landmark vectors of the shards behave like the reference's (read-only) matrix
+    lv, dense = la._landmark_vectors, np.asarray(la.landmark_vectors)
+    assert lv.shape == dense.shape == exp["lvecs"].shape and len(lv) == len(dense) and lv.ndim == 2
+    far = len(dense) - 3
+    assert np.array_equal(lv[5], dense[5]) and np.array_equal(lv[far], dense[far]) and np.array_equal(lv[-1], dense[-1])
+    assert np.array_equal(lv[far - 40:far + 2], dense[far - 40:far + 2]) and np.array_equal(lv[[0, far, 7]], dense[[0, far, 7]])
+    assert np.array_equal(lv[3:9, 2], dense[3:9, 2])
+    assert len(la.timings) == n and len(la.wall_timings) == n            # diagnostics per device, in `devices` order
