@@ -334,7 +334,7 @@ int sit_timers(sit_ctx *ctx, double *ms, int n);
  * rows at a cut) / [15] steps cut short by a wrong speculation, summed over the speculative fits of the context,
  * [16] generation of the fill kernel the last sit_fill launched (1 or 3), [17] survivor slots per wave and
  * [18] waves per workgroup of that launch, [19] capacity bits that ended a speculative fit (0: none) and
- * [20] the row it stopped at, [21] task-table entries per wave of that launch, [22] 1 if the last sit_fill assigned the narrow rows inside the fill kernel, [24..27] work census of a SITATOR_DEBUG_STOP=9 fill.                         */
+ * [20] the row it stopped at, [21] task-table entries per wave of that launch, [22] 1 if the last sit_fill assigned the narrow rows inside the fill kernel, [23] diagonal cells: groups of passes of the last fill that fell inside the error band of the cheap cut-off decision and were repeated with the reference's arithmetic, [24..27] work census of a SITATOR_DEBUG_STOP=9 fill.                         */
 int sit_info(sit_ctx *ctx, double *out, int n);
 int sit_synchronize(sit_ctx *ctx);
 

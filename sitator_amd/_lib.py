@@ -691,6 +691,7 @@ class HipContext(object):
         out["fit_capacity_hit"], out["fit_stop_row"] = int(v[19]), int(v[20])
         out["task_table_per_wave"] = int(v[21])
         out["assignment_fused"] = bool(v[22])
+        out["band_redos"] = int(v[23])
         out["census"] = [float(x) for x in v[24:28]]
         return out
 

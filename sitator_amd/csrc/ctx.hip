@@ -281,7 +281,7 @@ extern "C" int sit_info(sit_ctx *c, double *out, int n)
                           c->tight_delta, (double)c->fallback_frames, (double)c->G[0], (double)c->G[1],
                           (double)c->G[2], (double)c->tG[0], (double)c->tG[1], (double)c->tG[2], (double)c->last_fpb,
                           (double)c->ff_batches, (double)c->ff_serial_rows, (double)c->ff_rewalks,
-                          (double)c->last_kernel, (double)c->last_iw, (double)c->last_nw, (double)c->ff_why, (double)c->ff_stop_row, (double)c->last_tt, c->last_fused ? 1.0 : 0.0, 0.0,
+                          (double)c->last_kernel, (double)c->last_iw, (double)c->last_nw, (double)c->ff_why, (double)c->ff_stop_row, (double)c->last_tt, c->last_fused ? 1.0 : 0.0, (double)c->band_redos,
                           c->census[0], c->census[1], c->census[2], c->census[3]};
     for (int i = 0; i < n; i++) out[i] = i < 28 ? v[i] : 0.0;
     return SIT_OK;

@@ -522,6 +522,7 @@ static int fill_decode(sit_ctx *c, const FillPending &s, i64 *n_all_zero, sit_er
     for (int q = 0; q < 4; q++) c->census[q] = (double)hb[5 + q];
     if (n_all_zero) *n_all_zero = (i64)hs[0];
     c->fallback_frames = (i64)hs[2];
+    c->band_redos = (i64)hs[1];
     const int kind = decode_error(c, hkey, err);
     if (kind != SIT_OK) { c->assign_valid = false; return kind; }
     if (s.v3 && hs[3]) {
@@ -994,6 +995,7 @@ extern "C" int sit_upload_fill_fit(sit_ctx *c, const double *frames, i64 F, i64 
     const u64 hkey = hb[0], hs[4] = {hb[1], hb[2], hb[3], hb[4]};
     if (n_all_zero) *n_all_zero = (i64)hs[0];
     c->fallback_frames = (i64)hs[2];
+    c->band_redos = (i64)hs[1];
     const int kind = decode_error(c, hkey, err);
     if (kind != SIT_OK) return kind;
     if (hs[3]) {

@@ -440,7 +440,11 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
     do {                                                                                                                   \
         bool redo_ = false;                                          /* wave-uniform */                                    \
         F3_D1E_BODY(NP, 0, redo_);                                                                                         \
-        if (CHEAP && redo_) { bool never_ = false; F3_D1E_BODY(NP, 1, never_); }                                           \
+        if (CHEAP && redo_) {                                                                                              \
+            if (lane == 0) atomicAdd(&g.scal[1], 1ull);              /* counted: sit_info [23] (tests: the band IS entered) */ \
+            bool never_ = false;                                                                                           \
+            F3_D1E_BODY(NP, 1, never_);                                                                                    \
+        }                                                                                                                  \
     } while (0)
 
 // T: the n-th root (helpers.pyx:212) of the product (:208), one lane per survivor of the wave's list; the row entry of a

@@ -81,6 +81,7 @@ struct sit_ctx {
     double hmin = 0;                  // smallest perpendicular height of the cell
     int last_kernel = 0, last_iw = 0, last_nw = 0, last_tt = 0;
     int nv_uniform = 0;               // > 0: every landmark has this many vertices
+    i64 band_redos = 0;               // k_fill3 on diagonal cells: pass groups of the last fill that went round again with the reference's arithmetic
     bool f3_ref_in_cell = false;      // every reference position within [-0.25, 1.25) of the cell (k_fill3 may leave statics unwrapped)
     bool f3_cheap_ok = false;         // k_fill3 may decide on the logistic argument (diagonal cell, steepness > 0, vcd > 0)
     double f3_x0lo = 0, f3_x0hi = 0;  // the argument at the cut-off -/+ the error bound of the kernel's

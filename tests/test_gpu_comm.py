@@ -28,7 +28,15 @@ def test_rccl_comm_of_one_rank_runs_every_collective():
     assert np.array_equal(comm.bcast(x, root=0), x)
     assert comm.bcast(np.zeros((0, 4)), root=0).shape == (0, 4)
     comm.barrier()
+    # what the communicator says about itself (ncclCommCount / ncclCommUserRank / ncclCommCuDevice read back, not the
+    # arguments of sit_comm_create): the N > 1 bench line prints this from every rank
+    info = comm.info()
+    assert (info["ranks"], info["rank"], info["device"]) == (1, 0, 0) and info["rccl_version"] > 0
+    assert (info["asked_ranks"], info["asked_rank"]) == (1, 0)
     comm.close()
+    plain = _lib.HipContext(np.eye(3))
+    with pytest.raises(ValueError):                    # no communicator on this context
+        plain.comm_info()
 
 
 def test_landmark_analysis_on_an_rccl_comm_matches_the_plain_run():

@@ -318,6 +318,20 @@ def test_predict_with_centres_in_lds_equals_predict_from_global_memory(oracle, c
     assert np.array_equal(lab_o, lab_a)
 
 
+def test_cheap_decision_band_is_counted():
+    """sit_info [23]: the groups of passes that fell inside the error band of the cheap cut-off decision (diagonal cells)
+    and were repeated with the reference's arithmetic: none on a plain trajectory, every group with the band forced open."""
+    from sitator_amd import synth
+    host = synth.config_host("C2")
+    ctx, *_ = _setup(host, 64, 120, seed=9)
+    assert ctx.fill()[0] == 0 and ctx.info()["band_redos"] == 0
+    os.environ["SITATOR_F3_FORCE_EXACT"] = "1"
+    try:
+        assert ctx.fill()[0] == 0 and ctx.info()["band_redos"] > 100
+    finally:
+        os.environ.pop("SITATOR_F3_FORCE_EXACT", None)
+
+
 def test_frames_beyond_sampled_displacement_fall_back_and_match_oracle(oracle):
     from sitator_amd import synth
     host = synth.config_host("C2")
