@@ -27,7 +27,12 @@ $T python3 $R/scratch/ab_fill.py C2 100000 20 > $O/ab_fill_c2.txt 2>&1 || exit 1
 SWEEP_STEPS=10 $T python3 $R/scratch/sweep_env.py C5 62500 "SITATOR_FUSE=0" "SITATOR_FUSE=1" > $O/ab_fill_c5.txt 2>&1 || exit 1
 timeout -k 10 400 bash $R/scratch/pmc_stages.sh gpurun_out/$tag/stages 20000 C2 > $O/stages.txt 2>&1 || exit 1
 rm -rf $O/stages
-SITATOR_BENCH_BACKEND=tcp $T python3 $R/bench.py --gpus 2 --config C2 --frames 30000 --steps 5 --warmup 2 > $O/bench_tcp2.json 2> $O/bench_tcp2.err || exit 1
+SITATOR_BENCH_BACKEND=tcp $T python3 $R/bench.py --gpus 2 --config C2 --frames 30000 --steps 5 --warmup 2 --no-scale-ref > $O/bench_tcp2.json 2> $O/bench_tcp2.err || exit 1
+# round 5: the 8-GPU configurations rehearsed with two ranks on the one GPU (configs[3] per GPU; configs[4] with the mcl plugin)
+SITATOR_BENCH_BACKEND=tcp $T python3 $R/bench.py --gpus 2 --config C4 --steps 5 --warmup 2 --cpu-frames 0 > $O/bench_tcp2_C4.json 2> $O/bench_tcp2_C4.err || exit 1
+SITATOR_BENCH_BACKEND=tcp $T python3 $R/bench.py --gpus 2 --config C5 --algo mcl --steps 5 --warmup 2 --cpu-frames 0 > $O/bench_tcp2_C5.json 2> $O/bench_tcp2_C5.err || exit 1
+timeout -k 10 200 python3 $R/scratch/phase_times.py C2 100000 > $O/phase_times.txt 2>&1 || exit 1
+timeout -k 10 500 bash $R/scratch/pmc_mem.sh gpurun_out/$tag/mem 100000 C2 > $O/mem_counters.txt 2>&1 || exit 1
 $T python3 $R/scratch/e2e_walls.py C2 100000 4 > $O/e2e_walls_c2.txt 2>&1 || exit 1
 sha256sum $R/sitator_amd/lib/libsitator_hip.so | cut -c1-16 > $O/lib_sha16
 find $O -name "*.db" -delete
