@@ -80,6 +80,12 @@ struct Fill3Args {
     double x0lo, x0hi;                // CHEAP: the logistic argument at the cut-off, minus / plus the error bound of ours
     int nv_uniform;                   // > 0: every landmark has this many vertices (nvtab is not read)
     u64 *dbgbuf;                      // DBG = 2 builds, stops 10-12: [1024][4] span sums
+    // ---- met on rare paths only (round 5: as by-value kernel arguments they sat in scalar registers - or in spill lanes - all
+    //      through phase 1) ----
+    const i32 *static_idx, *mobile_idx;     // index lists (h.contig == 0)
+    const double *frame_dmax;               // DYN: the frames' largest static displacement (k_lattice_map)
+    int s0, m0, frame_mod;
+    double delta2, thr2_lo, thr2_hi, static_thr;
     // ---- fused site assignment (FUSE = 1) ----
     int store;                        // rows are wanted in the row buffers as well
     const i32 *col_ptr, *col_k;       // the centres, CSC over the landmarks (sit_set_centers)
@@ -96,16 +102,14 @@ struct Fill3Args {
 struct Fill3Head {
     Pbc P;
     const double *frames;
-    const i32 *static_idx, *mobile_idx;
     const double *ref_static;         // [3,S]: x of every static atom, then y, then z (a wave's loads are three runs of 512 bytes)
-    const double *frame_dmax;
     const double *exptab;
     i64 F, A, fbeg;                   // the launch covers frames [fbeg, F)
-    int S, M, fpb, contig, debug_stop, rcap, iw, has_fallback, s0, m0, tt, mcap, frame_mod, prio;
+    int S, M, fpb, contig, debug_stop, rcap, iw, has_fallback, tt, mcap, prio;
     int skipw;                        // CHEAP: static atoms stay as loaded (unwrapped) in LDS, see phase 1b
     int lay[12];                      // F3Layout of the launch, worked out on the host (the kernel spent ~100 scalar instructions per
                                       //   wave on these offsets, behind the second barrier)
-    double delta2, thr2_lo, thr2_hi, static_thr, safe2;
+    double safe2;                     // (the other thresholds of the static check are met on its rare path only: Fill3Args)
 };
 typedef const Fill3Args __attribute__((address_space(4))) *Fill3ArgsPtr;
 
@@ -648,9 +652,9 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     for (int q = lane; q < (FPB1 ? 2 * (IW + 1) : 4 * IW + (IW + 4) / 4); q += 64) ionrec[q] = 0u;      // stale tasks look their ion up
     // ---- phase 1a: copy this workgroup's atoms into LDS ----
     {
-        // (h.frame_mod > 0, an experiment: the workgroups read the first frame_mod frames over and over - the frames then
+        // (g.frame_mod > 0, an experiment: the workgroups read the first frame_mod frames over and over - the frames then
         // come from the L2 / Infinity cache, an upper bound on what hiding the HBM latency of this load could gain)
-        const double *fbase = h.frames + (h.frame_mod > 0 ? f0 % h.frame_mod : f0) * h.A * 3;
+        const double *fbase = h.frames + (g.frame_mod > 0 ? f0 % g.frame_mod : f0) * h.A * 3;
         if (h.contig == 4) {
             // one run of doubles, by LDS-DMA: a wave-instruction moves 64 x 16 bytes from per-lane addresses to
             // consecutive LDS bytes - no registers, no LDS stores, no address arithmetic but the lane's own
@@ -696,8 +700,8 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                         const int e = e0 + u * NT;
                         v[u] = 0.0;
                         if (e < n) {
-                            if (h.contig == 1) v[u] = src[e < 3 * S ? 3 * h.s0 + e : 3 * h.m0 + (e - 3 * S)];
-                            else { const int a = e / 3; v[u] = src[3 * (a < S ? h.static_idx[a] : h.mobile_idx[a - S]) + (e - 3 * a)]; }
+                            if (h.contig == 1) v[u] = src[e < 3 * S ? 3 * g.s0 + e : 3 * g.m0 + (e - 3 * S)];
+                            else { const int a = e / 3; v[u] = src[3 * (a < S ? g.static_idx[a] : g.mobile_idx[a - S]) + (e - 3 * a)]; }
                         }
                     }
 #pragma unroll
@@ -746,9 +750,9 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                     wrapc3<CELL>(P, qx, qy, qz);
                     const double dx = -qx + c0, dy = -qy + c1, dz = -qz + c2;
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (d2 > h.delta2) {
+                    if (d2 > g.delta2) {
                         atomicOr(&fmax[fl], 1ull);
-                        if (d2 > h.thr2_lo && (d2 > h.thr2_hi || sqrt(d2) > h.static_thr))
+                        if (d2 > g.thr2_lo && (d2 > g.thr2_hi || sqrt(d2) > g.static_thr))
                             atomicMin(g.err, (u64)(g.frame0 + f0 + fl) * errw + (u64)r);
                     }
                 }
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     F3_SPAN(10, 1, ts1, ts2); F3_SPAN(12, 2, ts1, tsb); F3_SPAN(12, 3, tsb, ts2);
     // fmax[fl] != 0: some static atom of frame fl moved beyond delta -> the frame takes the fallback table
     if (tid < nf && h.has_fallback) {
-        const bool tight = DYN ? (h.frame_dmax[f0 + tid] * h.frame_dmax[f0 + tid] <= h.delta2) : (fmax[tid] == 0ull);
+        const bool tight = DYN ? (g.frame_dmax[f0 + tid] * g.frame_dmax[f0 + tid] <= g.delta2) : (fmax[tid] == 0ull);
         if (!tight) atomicAdd(&g.scal[2], 1ull);
     }
     if (dbg == 1) return;
@@ -809,7 +813,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
             const uint2 ii = ioninfo[ion];
             lo = ii.x; nL = (int)(ii.y & 255u);
             if (h.has_fallback) {
-                const bool tight = DYN ? (h.frame_dmax[f0 + fl] * h.frame_dmax[f0 + fl] <= h.delta2) : (fmax[fl] == 0ull);
+                const bool tight = DYN ? (g.frame_dmax[f0 + fl] * g.frame_dmax[f0 + fl] <= g.delta2) : (fmax[fl] == 0ull);
                 if (!tight) {
                     const unsigned fb = ii.y >> 8;
                     uint2 pr;
@@ -1257,23 +1261,24 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
     for (int i = 0; i < 3; i++) a.cen[i] = c->pbc.cen[i];
     if (f3_env_int("SITATOR_F3_FORCE_EXACT", 0)) { a.x0lo = -INFINITY; a.x0hi = INFINITY; }     // tests: every pass goes round again
     a.nv_uniform = f3_env_int("SITATOR_F3_NVU", 1) ? c->nv_uniform : 0;
+    a.frame_mod = f3_env_int("SITATOR_F3_FRAME_MOD", 0);
 
     Fill3Head h;
     memset(&h, 0, sizeof(h));
-    h.P = c->pbc; h.frames = c->d_frames; h.static_idx = c->d_static_idx; h.mobile_idx = c->d_mobile_idx;
+    h.P = c->pbc; h.frames = c->d_frames; a.static_idx = c->d_static_idx; a.mobile_idx = c->d_mobile_idx;
     h.ref_static = c->d_ref_soa;
-    h.frame_dmax = p->dynamic_lattice_mapping ? c->d_frame_dmax : nullptr;
+    a.frame_dmax = p->dynamic_lattice_mapping ? c->d_frame_dmax : nullptr;
     h.exptab = c->d_exptab;
     h.F = f_hi; h.fbeg = f_lo; h.A = c->A;
     h.S = (int)S; h.M = (int)M;
     const bool dynmap = a.lattice_map != nullptr;
     h.debug_stop = dynmap ? 0 : f3_env_int("SITATOR_DEBUG_STOP", 0);
     h.has_fallback = have_tight ? 1 : 0;
-    h.s0 = (int)c->idx_s0; h.m0 = (int)c->idx_m0;
-    h.delta2 = have_tight ? c->tight_delta * c->tight_delta : -1.0;
-    h.thr2_lo = c->static_thr * c->static_thr * (1.0 - 1e-14);
-    h.thr2_hi = c->static_thr * c->static_thr * (1.0 + 1e-14);
-    h.static_thr = c->static_thr;
+    a.s0 = (int)c->idx_s0; a.m0 = (int)c->idx_m0;
+    a.delta2 = have_tight ? c->tight_delta * c->tight_delta : -1.0;
+    a.thr2_lo = c->static_thr * c->static_thr * (1.0 - 1e-14);
+    a.thr2_hi = c->static_thr * c->static_thr * (1.0 + 1e-14);
+    a.static_thr = c->static_thr;
     {
         double safe = 0.45 * c->hmin;
         if (have_tight && c->tight_delta < safe) safe = c->tight_delta;
@@ -1422,7 +1427,6 @@ int fill3_launch(sit_ctx *c, const sit_fill_params *p, bool store, i64 f_lo, i64
         if (contig == 3 && f3_env_int("SITATOR_FILL_DMA", 1) && (even_frame || even_groups || f_hi < c->F)) contig = 4;
     }
     h.contig = contig;
-    h.frame_mod = f3_env_int("SITATOR_F3_FRAME_MOD", 0);
     h.prio = f3_env_int("SITATOR_F3_PRIO", 3);             // issue priority of phase 1 (0-3)
     h.skipw = diag && !dynmap && c->f3_ref_in_cell && f3_env_int("SITATOR_F3_SKIPWRAP", 1) ? 1 : 0;
 
