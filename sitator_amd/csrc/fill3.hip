@@ -126,7 +126,7 @@ __host__ __device__ inline F3Layout f3_layout(int fpb, int SM, int M, int nw, in
     F3Layout L;
     int o = fpb * SM * 24;
     o = (o + 15) & ~15;                                  // LDS-DMA lands whole 16-byte pieces
-    L.fmax = o; o += fpb * 8;
+    L.fmax = o; o += fpb * 8 + ((fpb * (SM - M) + 63) / 64) * 8;      // + a bit per static atom: LDS holds its WRAPPED position (skipw)
     L.gsync = o; o += nw * 8;                            // FUSE: arrivals per group of waves, "window spilled" per wave
     L.ioninfo = o; o += fpb * M * 8;                     // {first entry, entries | fallback bin << 8} per ion
     L.etab = o; o += F3_EXPN * 8;
@@ -342,16 +342,16 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
 }
 
 // The LDS byte offsets of the static vertex and of the ion of task TK (first word(s) of the vertex record in R0X / R0Y)
-#define F3_TASK_OFFSETS(TK, R0X, R0Y, VOFF, IONOFF, STATOFF)                                                               \
+#define F3_TASK_OFFSETS(TK, R0X, R0Y, VOFF, IONOFF, STATOFF, FLX)                                                          \
     do {                                                                                                                   \
-        VOFF = (R0X); STATOFF = 0u;                                                                                        \
+        VOFF = (R0X); STATOFF = 0u; FLX = 0u;                                                                              \
         const unsigned ion_ = (TK) & ~KMASK;                                                                               \
         if (FPB1) {                                                                                                        \
             IONOFF = ionbase + 24u * ion_;                                                                                 \
             if (DYN) VOFF = 24u * (unsigned)g.lattice_map[f0 * S + (i64)(R0Y)];                                            \
         } else {                                                                                                           \
             const uint4 ir = ((const uint4 *)ionrec)[ion_];                                                                \
-            IONOFF = ir.y; STATOFF = ir.z;                                                                                 \
+            IONOFF = ir.y; STATOFF = ir.z; FLX = ir.w;                                                                     \
             if (DYN) VOFF = 24u * (unsigned)g.lattice_map[(f0 + (i64)ir.w) * S + (i64)(R0Y)];                              \
         }                                                                                                                  \
     } while (0)
@@ -380,8 +380,8 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
             uint2 r1 = make_uint2(0u, 0u);                                                                                 \
             if (!APPROX) r1 = CHEAP ? *(const uint2 *)((const char *)g.vh + 2u * ((tk_[u] & KMASK) | hh32) + 16)           \
                                     : *(const uint2 *)(rp + 16);     /* the exact threshold (32-byte records) */             \
-            unsigned voff, ionoff, statoff;                                                                                \
-            F3_TASK_OFFSETS(tk_[u], r0.x, r0.y, voff, ionoff, statoff);                                                    \
+            unsigned voff, ionoff, statoff, flx_;                                                                          \
+            F3_TASK_OFFSETS(tk_[u], r0.x, r0.y, voff, ionoff, statoff, flx_);                                              \
             rv_[u] = __hiloint2double((int)r0.w, (int)r0.z);                                                               \
             const double *sp = lds_f64(statoff + voff);                                                                    \
             const double *op = lds_f64(ionoff);                                                                            \
@@ -395,7 +395,10 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
                 const double c0_ = CHEAP ? g.cen[0] : P.cen[0], c1_ = CHEAP ? g.cen[1] : P.cen[1], c2_ = CHEAP ? g.cen[2] : P.cen[2]; \
                 if (CHEAP) { ox = c0_ + ox; oy = c1_ + oy; oz = c2_ + oz; }                                                \
                 double sx_ = sp[0], sy_ = sp[1], sz_ = sp[2];                                                              \
-                if (CHEAP && !DYN && h.skipw) wrapc3<CELL>(P, sx_, sy_, sz_);        /* LDS holds the atom as loaded */     \
+                if (CHEAP && !DYN && h.skipw) {                      /* LDS holds the atom as loaded, unless flagged */     \
+                    const unsigned sb_ = flx_ * (unsigned)S + r0.y;                                                        \
+                    if (!((wflag[sb_ >> 5] >> (sb_ & 31u)) & 1u)) wrapc3<CELL>(P, sx_, sy_, sz_);                          \
+                }                                                                                                          \
                 double qx = sx_ + ox, qy = sy_ + oy, qz = sz_ + oz;                                                        \
                 wrapc3<CELL>(P, qx, qy, qz);                                                                               \
                 const double dx = qx - c0_, dy = qy - c1_, dz = qz - c2_;                                                  \
@@ -613,6 +616,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     L.o_ttab = h.lay[6]; L.o_sv = h.lay[7]; L.o_nzc = h.lay[8]; L.o_mark = h.lay[9]; L.wbytes = h.lay[10]; L.total = h.lay[11];
     double *xyz = (double *)smem;                               // [fpb][S + M][3]; mobiles become centroid - ion
     u64 *fmax = (u64 *)(smem + L.fmax);                         // [fpb]
+    unsigned *wflag = (unsigned *)(fmax + fpb);                 // [fpb * S bits] static atoms whose LDS copy was wrapped in phase 1b (skipw)
     unsigned *garrive = (unsigned *)(smem + L.gsync);           // [NW] waves of a group that have finished their window
     unsigned *wspill = garrive + NW;                            // [NW] the wave's window went to the row buffers
     uint2 *ioninfo = (uint2 *)(smem + L.ioninfo);               // [fpb * M]
@@ -645,6 +649,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
     const int prio1 = h.prio & 3;
     if (prio1) f3_setprio(prio1);
     if (tid < fpb) fmax[tid] = 0ull;
+    if (CHEAP && !DYN) for (int q = tid; q < 2 * ((fpb * S + 63) / 64); q += NT) wflag[q] = 0u;
     if (FUSE && tid < 2 * NW) garrive[tid] = 0u;
     double etv = 0.0;
     if (tid < F3_EXPN) etv = h.exptab[tid];                    // in flight beside the frame loads; parked below
@@ -744,7 +749,14 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
                 if (!(e2 <= h.safe2)) {
                     // PBCCalculator.distances(ref, atom) (util/PBCCalculator.pyx:64-103), squared; the sqrt is
                     // taken only inside the rounding band around static_movement_threshold^2
-                    if (skipw) wrapc3<CELL>(P, x, y, z);            // (the reference's wrapped atom; LDS keeps the raw one)
+                    // (the reference's wrapped atom.  It replaces the loaded one in LDS - an atom that is NOT close to its
+                    // reference position may be any number of cells away, and the cheap distance's error bound needs
+                    // bounded coordinates - and is flagged, so that the exact pass does not wrap it a second time)
+                    if (skipw) {
+                        wrapc3<CELL>(P, x, y, z);
+                        need_store = true;
+                        atomicOr(&wflag[(fl * S + r) >> 5], 1u << ((fl * S + r) & 31));
+                    }
                     const double c0 = CHEAP ? g.cen[0] : P.cen[0], c1 = CHEAP ? g.cen[1] : P.cen[1], c2 = CHEAP ? g.cen[2] : P.cen[2];
                     double qx = x + (c0 - rx), qy = y + (c1 - ry), qz = z + (c2 - rz_);
                     wrapc3<CELL>(P, qx, qy, qz);

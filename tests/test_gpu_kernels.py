@@ -318,6 +318,42 @@ def test_predict_with_centres_in_lds_equals_predict_from_global_memory(oracle, c
     assert np.array_equal(lab_o, lab_a)
 
 
+@pytest.mark.parametrize("cfg,M,F", [("C2", 64, 40), ("C1b", 4, 300)])
+def test_atoms_in_other_periodic_images_give_the_same_rows(oracle, cfg, M, F, monkeypatch):
+    """Frames whose atoms sit in other periodic images - by one cell (an MD code that wraps differently), by a few, by a
+    thousand: the reference wraps every frame first (Step 0), so must the kernel, whatever it leaves unwrapped for speed
+    (diagonal cells: static atoms close to their reference position stay as loaded; one that is NOT - any shifted atom -
+    is wrapped, stored and flagged, so that the cheap distance sees bounded coordinates and the exact pass does not wrap
+    twice).  Rows against the oracle on the same frames: the zero pattern entry for entry - also with every pass sent
+    through the exact arithmetic."""
+    from sitator_amd import synth
+    host = synth.config_host(cfg)
+    rng = np.random.default_rng(17)
+
+    def shift(frames, sm, mm):
+        cell = np.asarray(host.cell, dtype=np.float64)
+        pick = rng.random(frames.shape[:2]) < 0.15
+        n = rng.choice([-1000, -3, -1, 1, 2, 1000], size=frames.shape[:2] + (3,)) * (rng.random(frames.shape[:2] + (3,)) < 0.6)
+        frames += np.where(pick[..., None], n @ cell, 0.0)
+
+    ctx, frames, sm, mm, ref = _setup(host, M, F, seed=23, mutate=shift)
+    sidx, midx = np.where(sm)[0], np.where(mm)[0]
+    ref_static = ref[sm]
+    verts, vcd = oracle.site_vertex_distances(host.cell, host.centers, host.vertices, ref_static)
+    exp, nz_exp = oracle.fill(host.cell, oracle.wrap_points(host.cell, frames), sidx, midx, ref_static, verts, vcd, check_for_zeros=False)
+    for env in ({}, {"SITATOR_F3_FORCE_EXACT": "1"}, {"SITATOR_F3_SKIPWRAP": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rc, nz, err = ctx.fill(check_for_zeros=False)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert rc == 0 and ctx.info()["fill_kernel"] == 3, (rc, err.frame, err.index)
+        got = ctx.rows_dense()
+        assert np.array_equal(got != 0, exp != 0), env
+        assert nz == nz_exp
+        np.testing.assert_allclose(got, exp, rtol=1e-6, atol=0)
+
+
 def test_cheap_decision_band_is_counted():
     """sit_info [23]: the groups of passes that fell inside the error band of the cheap cut-off decision (diagonal cells)
     and were repeated with the reference's arithmetic: none on a plain trajectory, every group with the band forced open."""
