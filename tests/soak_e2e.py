@@ -1,6 +1,7 @@
 """Soak script (not collected by pytest): many more seeds of tests/test_gpu_fuzz_e2e.py against the oracle;
 prints every mismatch.  python tests/soak_e2e.py [n]   (FUZZ_BASE=<first seed>)"""
 import sys, os, time
+os.environ.setdefault("SITATOR_PROGRESSBAR", "false")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import oracle

@@ -1,6 +1,7 @@
 """Soak script (not collected by pytest): speculative fit vs the ordered single-workgroup stream on medium
 trajectories of every configuration, many seeds.  python tests/soak_fit.py [n]"""
 import sys, os, time
+os.environ.setdefault("SITATOR_PROGRESSBAR", "false")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tests.test_gpu_kernels import _setup, _fit_once
