@@ -356,6 +356,61 @@ __device__ __forceinline__ int bin_of3(const Pbc &P, double px, double py, doubl
         }                                                                                                                  \
     } while (0)
 
+// NP0 passes of D0 from task `base` on: a lane per candidate task - its list (the number of end-of-list bits below it), its
+// list entry, the CRITICAL vertex of (bin, landmark) tested; the tasks that pass are appended to the task table.  The
+// entries of all NP0 passes are requested before the first is used.
+#define F3_D0_PASSES(NP0)                                                                                                  \
+    do {                                                                                                                   \
+        uint4 en_[NP0];                                                                                                    \
+        unsigned ionoff_[NP0], statoff_[NP0], tfl_[NP0];                                                                   \
+        int ion_[NP0];                                                                                                     \
+        unsigned long long vmask_[NP0];                                                                                    \
+        _Pragma("unroll") for (int u = 0; u < NP0; u++) {                                                                  \
+            const int b_ = base + 64 * u, t = b_ + lane;                                                                   \
+            vmask_[u] = first_lanes(nlt0 - b_);                                                                            \
+            const uint2 mw = *(const uint2 *)(mark + (b_ >> 5));                  /* (one address for the wave) */          \
+            const unsigned m_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)mw.x), m_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)mw.y); \
+            const unsigned rk = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, (unsigned)carry));         \
+            carry += __builtin_popcount(m_lo) + __builtin_popcount(m_hi);                                                  \
+            en_[u] = make_uint4(0u, 0u, 0u, 0x7ff00000u);         /* an idle lane: landmark 0, static 0, threshold +inf */  \
+            statoff_[u] = 0u; tfl_[u] = 0u;                                                                                \
+            if (FPB1) {                                                                                                    \
+                const uint2 rr = ((const uint2 *)ionrec)[rk];                                                              \
+                ion_[u] = (int)rr.y;                                                                                       \
+                if (F3_LANES(vmask_[u])) en_[u] = pack[rr.x + (unsigned)t];                                                \
+                ionoff_[u] = ionbase + 24u * (unsigned)ion_[u];                                                            \
+            } else {                                                                                                       \
+                ion_[u] = (int)rk2ion[rk];                                                                                 \
+                const uint4 ir = ((const uint4 *)ionrec)[ion_[u]];                                                         \
+                if (F3_LANES(vmask_[u])) en_[u] = pack[ir.x + (unsigned)t];                                                \
+                ionoff_[u] = ir.y; statoff_[u] = ir.z; tfl_[u] = ir.w;                                                     \
+            }                                                                                                              \
+        }                                                                                                                  \
+        _Pragma("unroll") for (int u = 0; u < NP0; u++) {                                                                  \
+            const uint4 en = en_[u];                                                                                       \
+            unsigned voff = en.y;                                                                                          \
+            if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)tfl_[u]) * S + (i64)(en.y / 24u)];                    \
+            const double hk = __hiloint2double((int)en.w, (int)en.z);                                                      \
+            const double *sp = lds_f64(statoff_[u] + voff);                                                                \
+            const double *op = lds_f64(ionoff_[u]);                                                                        \
+            double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];                                             \
+            double d2;                                                                                                     \
+            if (CHEAP) {                                                                                                   \
+                /* (the entry's threshold is the exact one plus the error bound of this distance: a candidate the */       \
+                /* reference keeps is never dropped here, and D1 + E decides) */                                           \
+                qx = minimg1(qx, P.ci[0], P.cm[0]); qy = minimg1(qy, P.ci[4], P.cm[4]); qz = minimg1(qz, P.ci[8], P.cm[8]); \
+                d2 = __builtin_fma(qz, qz, __builtin_fma(qy, qy, qx * qx));                                                \
+            } else {                                                                                                       \
+                wrapc3<CELL>(P, qx, qy, qz);                                                                               \
+                const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];                                   \
+                d2 = (dx * dx + dy * dy) + dz * dz;                                                                        \
+            }                                                                                                              \
+            const unsigned long long km = __ballot(!(d2 > hk)) & vmask_[u];                                                \
+            if (F3_LANES(km)) ttab[mask_rank(km, t_end)] = (en.x & KMASK) | (unsigned)ion_[u];                             \
+            t_end += __popcll(km);                                                                                         \
+        }                                                                                                                  \
+    } while (0)
+
 // NP passes of TPP tasks from the task table (cursor, cursor + 1): distances, thresholds, factors, products; the tasks
 // that keep all their lanes are appended to the survivors (prod, sv); cnt grows.  A macro: it lives inside the kernel's
 // locals (a lambda made the compiler spill its captures).
@@ -865,48 +920,11 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
             // ---- D0: a lane per candidate task: its ion (maximum scan over the start markers), its list entry, the
             //      CRITICAL vertex of (bin, landmark) tested; the tasks that pass are appended to the task table ----
             F3_STAMP(ts4);
-            {
-                const int t = base + lane;
-                const unsigned long long vmask = first_lanes(nlt0 - base);
-                const uint2 mw = *(const uint2 *)(mark + (base >> 5));            // (one address for the wave)
-                const unsigned m_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)mw.x), m_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)mw.y);
-                const unsigned rk = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, (unsigned)carry));
-                carry += __builtin_popcount(m_lo) + __builtin_popcount(m_hi);
-                uint4 en = make_uint4(0u, 0u, 0u, 0x7ff00000u);   // an idle lane: landmark 0, static 0, threshold +inf
-                unsigned ionoff, statoff = 0u, tfl = 0u;
-                int ion;
-                if (FPB1) {
-                    const uint2 rr = ((const uint2 *)ionrec)[rk];
-                    ion = (int)rr.y;
-                    if (F3_LANES(vmask)) en = pack[rr.x + (unsigned)t];
-                    ionoff = ionbase + 24u * (unsigned)ion;
-                } else {
-                    ion = (int)rk2ion[rk];
-                    const uint4 ir = ((const uint4 *)ionrec)[ion];
-                    if (F3_LANES(vmask)) en = pack[ir.x + (unsigned)t];
-                    ionoff = ir.y; statoff = ir.z; tfl = ir.w;
-                }
-                unsigned voff = en.y;
-                if (DYN) voff = 24u * (unsigned)g.lattice_map[(f0 + (i64)tfl) * S + (i64)(en.y / 24u)];
-                const double hk = __hiloint2double((int)en.w, (int)en.z);
-                const double *sp = lds_f64(statoff + voff);
-                const double *op = lds_f64(ionoff);
-                double qx = sp[0] + op[0], qy = sp[1] + op[1], qz = sp[2] + op[2];
-                double d2;
-                if (CHEAP) {
-                    // (the entry's threshold is the exact one plus the error bound of this distance: a candidate the
-                    // reference keeps is never dropped here, and D1 + E decides)
-                    qx = minimg1(qx, P.ci[0], P.cm[0]); qy = minimg1(qy, P.ci[4], P.cm[4]); qz = minimg1(qz, P.ci[8], P.cm[8]);
-                    d2 = __builtin_fma(qz, qz, __builtin_fma(qy, qy, qx * qx));
-                } else {
-                    wrapc3<CELL>(P, qx, qy, qz);
-                    const double dx = qx - P.cen[0], dy = qy - P.cen[1], dz = qz - P.cen[2];
-                    d2 = (dx * dx + dy * dy) + dz * dz;
-                }
-                const unsigned long long km = __ballot(!(d2 > hk)) & vmask;
-                if (F3_LANES(km)) ttab[mask_rank(km, t_end)] = (en.x & KMASK) | (unsigned)ion;
-                t_end += __popcll(km);
-            }
+            // (round 5: two passes at a time where two are left and the table has room for both - their list entries are
+            // then on their way together, one L2 round trip instead of two; not in the sixteen-wave build, which has no
+            // registers to spare)
+            if (NW < 16 && base + 64 < nlt0 && t_end <= TT - 128) { F3_D0_PASSES(2); base += 64; }
+            else F3_D0_PASSES(1);
             if (DBG == 2 && dbg >= 10) { unsigned long long tq = __builtin_amdgcn_s_memtime(); acc_d0 += tq - ts4; ts4 = tq; }
             if (t_end <= TT - 64 && base + 64 < nlt0) continue;         // room for another pass of candidates
             if (DBG && dbg == 9 && lane == 0) atomicAdd(&g.scal[4], (u64)t_end);
