@@ -13,10 +13,12 @@
 // and scalar instructions are nearly free, so the design rule is: few vector instructions, full lanes, masks and loop
 // control on the scalar unit.
 //   * a workgroup parks one frame (of a 64-ion system) in LDS (LDS-DMA where the frame is one run of doubles: no
-//     registers, no LDS stores), wrapped in place; the thread that wraps a mobile ion also looks up the ion's bin;
+//     registers, no LDS stores); the ions are wrapped in place (the thread that wraps one also looks up its bin), the
+//     static atoms too - except on diagonal cells, where an atom close to its reference position stays as loaded (the
+//     minimum-image distance does not care; phase 1b);
 //   * each wave then owns a window of the ions.  The candidate landmarks of the window form one flat task index
-//     space (a prefix sum over the window's list lengths); a lane per TASK finds its ion with a maximum scan over
-//     start markers, loads its list entry - 16 bytes: the landmark's CRITICAL vertex (the vertex with the least room
+//     space (a prefix sum over the window's list lengths); a lane per TASK finds its list - the r-th non-empty
+//     one, r = the end-of-list bits below the task in the pass's 64-bit mask: two mbcnt -, loads its list entry - 16 bytes: the landmark's CRITICAL vertex (the vertex with the least room
 //     in the ion's bin, from the table builder), that vertex's LDS offset and its exact threshold - and tests that
 //     vertex; what passes is compacted into the wave's task table with a ballot;
 //   * the remaining tasks take (task, vertex) LANES: eight lanes per task, one squared distance each, compared with
@@ -266,21 +268,6 @@ __device__ __forceinline__ const double *lds_f64(unsigned off)
     return (const double *)(const __attribute__((address_space(3))) double *)(size_t)off;
 }
 
-
-// inclusive maximum scan over the 64 lanes (values >= 0; 0 is the identity)
-__device__ __forceinline__ int wave_max_scan(int x)
-{
-#define F3_DPP(ctrl, rmask) __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false)
-    int y;
-    y = F3_DPP(0x111, 0xf); x = x > y ? x : y;        // row_shr:1
-    y = F3_DPP(0x112, 0xf); x = x > y ? x : y;        // row_shr:2
-    y = F3_DPP(0x114, 0xf); x = x > y ? x : y;        // row_shr:4
-    y = F3_DPP(0x118, 0xf); x = x > y ? x : y;        // row_shr:8
-    y = F3_DPP(0x142, 0xa); x = x > y ? x : y;        // row_bcast:15 into rows 1 and 3
-    y = F3_DPP(0x143, 0xc); x = x > y ? x : y;        // row_bcast:31 into rows 2 and 3
-#undef F3_DPP
-    return x;
-}
 
 // inclusive sum scan over the 64 lanes
 __device__ __forceinline__ int wave_add_scan(int x)
@@ -917,8 +904,7 @@ __global__ __launch_bounds__(NW * 64) F3_WPE_ATTR void k_fill3(Fill3Head h, Fill
         spilled = false;
         const int nlt0 = (DBG && dbg == 2) ? 0 : nlt;           // ablation: stop after the owner stage
         for (int base = 0; base < nlt0; base += 64) {
-            // ---- D0: a lane per candidate task: its ion (maximum scan over the start markers), its list entry, the
-            //      CRITICAL vertex of (bin, landmark) tested; the tasks that pass are appended to the task table ----
+            // ---- D0: a lane per candidate task (F3_D0_PASSES) ----
             F3_STAMP(ts4);
             // (round 5: two passes at a time where two are left and the table has room for both - their list entries are
             // then on their way together, one L2 round trip instead of two; not in the sixteen-wave build, which has no
