@@ -232,6 +232,117 @@ __global__ __launch_bounds__(NTMAX) void k_predict_rows_lds(PredArgs a, i32 *wid
     }
 }
 
+// Round 5: the same kernel over PACKED columns.  k_predict_rows_lds' merge is bound by its instructions (62 vector
+// instructions and four dependent LDS waits per step: an entry's value and the next entry's centre id are two loads from
+// two arrays, each behind its own address arithmetic and an end-of-column compare).  Here a column is a run of 12-byte
+// records {value, centre id} closed by a sentinel record (id = "none"): a column head - id AND value - sits in
+// registers, a step multiplies what it holds and advances with one 12-byte read (two LDS instructions behind one address) per matching column, no end compare,
+// and the loads of a step are waited for together at the top of the next.  dot = 0.0 + t for a first term that is not
+// column 0's: the same bits as t but for the sign of a zero, and only |dot| is used.
+// ArgMaxQ (sit_internal.h) without its nest of branches: the incumbent starts at -1 (any |dot| beats it, so "none yet" needs
+// no test of its own), the centre id stays 32 bits wide, a NaN is taken by the same select as a larger value and then keeps
+// the place (nothing compares greater than it; a later NaN is refused by the flag); only the near-tie of two quotients
+// (:177-178: the reference divides before it compares) is a branch, and a rare one.
+struct ArgMaxR {
+    double m;
+    i32 i;
+    bool nan;
+    __device__ __forceinline__ void init() { m = -1.0; i = -1; nan = false; }
+    __device__ __forceinline__ void push(double dot, i32 cid, double xn, bool normed)
+    {
+        const double v = fabs(dot);
+        bool gt = v > m;
+        if (normed && gt && !(v > m * (1.0 + 1e-15))) gt = v / xn > m / xn;   // equal quotients: the earlier centre keeps the place
+        const bool vnan = v != v;
+        const bool take = !nan && (gt || vnan);
+        m = take ? v : m;
+        i = take ? cid : i;
+        nan = nan || vnan;
+    }
+    __device__ __forceinline__ Best result(double xn, bool normed) const
+    {
+        Best b;
+        b.i = (i64)i; b.nan = nan ? 1 : 0;
+        b.v = i < 0 ? 0.0 : (normed ? m / xn : m);                   // :177-178 (NaN / xn stays NaN)
+        return b;
+    }
+};
+struct RecHead { i32 h; double hv; unsigned p; };
+#define PRED_REC 12                   // bytes of a record {value (two words), centre id}: 12 keeps the LDS footprint of the split arrays
+__device__ __forceinline__ void rec_load(const char *l_rec, RecHead &c)
+{
+    const unsigned *r = (const unsigned *)(l_rec + c.p);
+    const unsigned r0 = r[0], r1 = r[1], r2 = r[2];
+    c.h = (i32)r2;
+    c.hv = __hiloint2double((int)r1, (int)r0);
+}
+__device__ __forceinline__ Best merge4_rec(int n, i32 d0, i32 d1, i32 d2, i32 d3, double v0, double v1, double v2, double v3,
+                                           double xn, bool normed, const unsigned *l_off, const char *l_rec)
+{
+    ArgMaxR am;
+    am.init();
+    const i32 none = 0x7fffffff;
+    RecHead c0, c1, c2, c3;
+    c0.p = l_off[d0]; rec_load(l_rec, c0);
+    c1.h = none; c1.hv = 0.0; c1.p = 0u;
+    c2 = c1; c3 = c1;
+    if (n > 1) { c1.p = l_off[d1]; rec_load(l_rec, c1); }
+    if (n > 2) { c2.p = l_off[d2]; rec_load(l_rec, c2); }
+    if (n > 3) { c3.p = l_off[d3]; rec_load(l_rec, c3); }
+    while (true) {
+        i32 cid = c0.h < c1.h ? c0.h : c1.h;
+        const i32 m23 = c2.h < c3.h ? c2.h : c3.h;
+        cid = cid < m23 ? cid : m23;
+        if (cid == none) break;
+        double dot = 0.0;
+        if (c0.h == cid) { dot = c0.hv * v0; c0.p += PRED_REC; rec_load(l_rec, c0); }
+        if (c1.h == cid) { dot = dot + c1.hv * v1; c1.p += PRED_REC; rec_load(l_rec, c1); }
+        if (c2.h == cid) { dot = dot + c2.hv * v2; c2.p += PRED_REC; rec_load(l_rec, c2); }
+        if (c3.h == cid) { dot = dot + c3.hv * v3; c3.p += PRED_REC; rec_load(l_rec, c3); }
+        am.push(dot, cid, xn, normed);                              // :177-179
+    }
+    return am.result(xn, normed);
+}
+
+template <int NTMAX>
+__global__ __launch_bounds__(NTMAX) void k_predict_rows_rec(PredArgs a, const unsigned *recs, int nrec, i32 *wide_list, unsigned *wide_count,
+                                                            i64 seg_cap, int hist_K, u64 *counts)
+{
+    extern __shared__ __attribute__((aligned(16))) char pl_smem[];
+    unsigned *l_rec = (unsigned *)pl_smem;                         // [nrec][3] = entries + a sentinel per column
+    unsigned *l_off = l_rec + 3 * nrec;                            // [D] byte offset of a column's first record
+    unsigned *hist = l_off + a.D;
+    const int NT = NTMAX;
+    for (int q = threadIdx.x; q < hist_K; q += NT) hist[q] = 0u;
+    for (int q = threadIdx.x; q < 3 * nrec; q += NT) l_rec[q] = recs[q];
+    for (int q = threadIdx.x; q < (int)a.D; q += NT) l_off[q] = (unsigned)PRED_REC * (unsigned)(a.col_ptr[q] + q);
+    __syncthreads();
+    i32 *seg = wide_list + (i64)blockIdx.x * seg_cap;
+    unsigned *seg_count = wide_count + 2 * blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    for (i64 r0 = (i64)blockIdx.x * NT; r0 < a.N; r0 += (i64)gridDim.x * NT) {
+        const i64 row = r0 + threadIdx.x;
+        int n = 0;
+        double xn = 0.0;
+        const bool live = row < a.N && predict_row_head(a, row, n, xn);
+        const bool wide = live && n > 4;
+        list_wide_rows(n, live, row, seg, seg_count, seg_cap, lane);
+        if (live && !wide) {
+            i32 d0 = a.row_idx[row], d1 = 0, d2 = 0, d3 = 0;
+            double v0 = a.row_val[row], v1 = 0, v2 = 0, v3 = 0;
+            if (n > 1) { d1 = a.row_idx[a.N + row]; v1 = a.row_val[a.N + row]; }
+            if (n > 2) { d2 = a.row_idx[2 * a.N + row]; v2 = a.row_val[2 * a.N + row]; }
+            if (n > 3) { d3 = a.row_idx[3 * a.N + row]; v3 = a.row_val[3 * a.N + row]; }
+            const i64 to = finish_predict(a, row, merge4_rec(n, d0, d1, d2, d3, v0, v1, v2, v3, xn, a.normed != 0, l_off, (const char *)l_rec));
+            if (hist_K > 0 && to >= 0) atomicAdd(&hist[to], 1u);
+        }
+    }
+    if (hist_K > 0) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < hist_K; q += NT) { const unsigned v = hist[q]; if (v) atomicAdd(&counts[q], (u64)v); }
+    }
+}
+
 // one wide row, centres from `col_*` (global memory or LDS)
 __device__ __forceinline__ void predict_wide_row(const PredArgs &a, i64 row, const i32 *col_ptr, const i32 *col_k, const double *col_val,
                                                  u64 *counts)
@@ -287,6 +398,80 @@ __global__ __launch_bounds__(PRED_WIDE_LDS_BLOCK) void k_predict_rows_wide_lds(P
     }
 }
 
+// The wide merges over the packed columns (merge4_rec's form; C5's rows hold 5-13 entries: the assignment is half its step).
+template <int NW>
+__device__ __forceinline__ i64 predict_row_merge_wide_rec(const PredArgs &a, i64 row, int n, double xn, const unsigned *l_off, const char *l_rec)
+{
+    ArgMaxR am;
+    am.init();
+    const i32 none = 0x7fffffff;
+    RecHead c[NW];
+    double v[NW];
+#pragma unroll
+    for (int s = 0; s < NW; s++) {
+        c[s].h = none; c[s].hv = 0.0; c[s].p = 0u; v[s] = 0.0;
+        if (s < n) {
+            c[s].p = l_off[a.row_idx[(i64)s * a.N + row]];
+            v[s] = a.row_val[(i64)s * a.N + row];
+            rec_load(l_rec, c[s]);
+        }
+    }
+    while (true) {
+        i32 cid = c[0].h;
+#pragma unroll
+        for (int s = 1; s < NW; s++) cid = c[s].h < cid ? c[s].h : cid;
+        if (cid == none) break;
+        double dot = 0.0;
+#pragma unroll
+        for (int s = 0; s < NW; s++) {
+            if (c[s].h == cid) {                                     // ascending dimension order (:176)
+                dot = dot + c[s].hv * v[s];
+                c[s].p += PRED_REC;
+                rec_load(l_rec, c[s]);
+            }
+        }
+        am.push(dot, cid, xn, a.normed != 0);                       // :177-179
+    }
+    return finish_predict(a, row, am.result(xn, a.normed != 0));
+}
+
+__device__ __forceinline__ void predict_wide_row_rec(const PredArgs &a, i64 row, const unsigned *l_off, const char *l_rec, u64 *counts)
+{
+    int n;
+    double xn;
+    if (!predict_row_head(a, row, n, xn)) return;
+    i64 to;
+    if (n <= 8) to = predict_row_merge_wide_rec<8>(a, row, n, xn, l_off, l_rec);
+    else if (n <= 10) to = predict_row_merge_wide_rec<10>(a, row, n, xn, l_off, l_rec);
+    else if (n <= 16) to = predict_row_merge_wide_rec<16>(a, row, n, xn, l_off, l_rec);
+    else to = predict_row_generic(a, row, n, xn);
+    if (counts && to >= 0) atomicAdd(&counts[to], 1ull);
+}
+
+__global__ __launch_bounds__(PRED_WIDE_LDS_BLOCK) void k_predict_rows_wide_rec(PredArgs a, const unsigned *recs, int nrec, const i32 *wide_list,
+                                                                              const unsigned *wide_count, i64 seg_cap, int nseg, u64 *counts)
+{
+    extern __shared__ __attribute__((aligned(16))) char pl_smem[];
+    __shared__ unsigned any;
+    unsigned *l_rec = (unsigned *)pl_smem;
+    unsigned *l_off = l_rec + 3 * nrec;
+    if (threadIdx.x == 0) any = 0u;
+    __syncthreads();
+    for (int sg = blockIdx.x + threadIdx.x * gridDim.x; sg < nseg; sg += gridDim.x * PRED_WIDE_LDS_BLOCK)
+        if (wide_count[2 * sg] | wide_count[2 * sg + 1]) any = 1u;
+    __syncthreads();
+    if (!any) return;                                              // nothing for this workgroup: skip the staging
+    for (int q = threadIdx.x; q < 3 * nrec; q += PRED_WIDE_LDS_BLOCK) l_rec[q] = recs[q];
+    for (int q = threadIdx.x; q < (int)a.D; q += PRED_WIDE_LDS_BLOCK) l_off[q] = (unsigned)PRED_REC * (unsigned)(a.col_ptr[q] + q);
+    __syncthreads();
+    for (int sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
+        const i64 na = (i64)wide_count[2 * sg], nb = (i64)wide_count[2 * sg + 1];
+        const i32 *seg = wide_list + (i64)sg * seg_cap;
+        for (i64 q = threadIdx.x; q < na; q += PRED_WIDE_LDS_BLOCK) predict_wide_row_rec(a, seg[q], l_off, (const char *)l_rec, counts);
+        for (i64 q = threadIdx.x; q < nb; q += PRED_WIDE_LDS_BLOCK) predict_wide_row_rec(a, seg[seg_cap - 1 - q], l_off, (const char *)l_rec, counts);
+    }
+}
+
 // Dense fallback: every centre, sparse row against the dense (normalised) centre matrix.
 __global__ __launch_bounds__(PRED_BLOCK) void k_predict_rows_dense(PredArgs a)
 {
@@ -337,6 +522,22 @@ extern "C" int sit_set_centers(sit_ctx *c, const double *centers, i64 K, int nor
     if ((rc = dev_upload(c, &c->d_col_ptr, ptr.data(), D + 1))) return rc;
     if ((rc = dev_upload(c, &c->d_col_k, ks.data(), (i64)ks.size()))) return rc;
     if ((rc = dev_upload(c, &c->d_col_val, vals.data(), (i64)vals.size()))) return rc;
+    {   // the packed form of the same columns (k_predict_rows_rec): column d's records start at ptr[d] + d
+        const size_t nrec = (size_t)ptr[(size_t)D] + (size_t)D;
+        std::vector<unsigned> recs(3 * nrec);
+        for (i64 d = 0; d < D; d++) {
+            for (i32 q = ptr[(size_t)d]; q < ptr[(size_t)d + 1]; q++) {
+                unsigned w[2];
+                memcpy(w, &vals[(size_t)q], 8);
+                unsigned *r = &recs[3 * ((size_t)q + (size_t)d)];
+                r[0] = w[0]; r[1] = w[1]; r[2] = (unsigned)ks[(size_t)q];
+            }
+            unsigned *e = &recs[3 * ((size_t)ptr[(size_t)d + 1] + (size_t)d)];
+            e[0] = 0u; e[1] = 0u; e[2] = 0x7fffffffu;
+        }
+        if ((rc = dev_upload(c, &c->d_col_rec, recs.data(), (i64)recs.size()))) return rc;
+        c->csc_nrec = (i64)nrec;
+    }
     c->K = K; c->centers_normed = normed;
     c->csc_nnz = (i64)vals.size();
     c->max_col = 0;
@@ -350,7 +551,7 @@ extern "C" int sit_set_centers(sit_ctx *c, const double *centers, i64 K, int nor
 // Launch shape of the assignment pass and its counters in the scratch buffer (the label counts, one length word per
 // segment of the wide-row list).
 struct PredPlan {
-    bool narrow_lds, wide_lds;
+    bool narrow_lds, wide_lds, rec;
     int nt, per_cu, nseg;
     i64 seg_cap;
     size_t lds, csc;
@@ -369,6 +570,11 @@ static int predict_plan(sit_ctx *c, PredPlan &p)
     p.lds = p.csc + (size_t)c->K * 4;
     const char *pl = getenv("SITATOR_PREDICT_LDS");                 // "0": keep the centres in global memory (A/B, tests)
     const bool no_lds = pl && pl[0] == '0';
+    // the packed columns where they fit (12 bytes an entry + a sentinel a column); SITATOR_PREDICT_REC=0: the split arrays
+    const size_t rec_lds = (size_t)c->csc_nrec * PRED_REC + (size_t)c->D * 4 + (size_t)c->K * 4;
+    const char *pr = getenv("SITATOR_PREDICT_REC");
+    p.rec = rec_lds <= 150 * 1024 && !no_lds && !(pr && pr[0] == '0') && c->d_col_rec;
+    if (p.rec) p.lds = rec_lds;
     p.narrow_lds = p.lds <= 150 * 1024 && !no_lds;
     p.wide_lds = p.csc <= 150 * 1024 && !no_lds;
     // the listing kernel: persistent workgroups, each with its own segment of the wide-row list
@@ -400,6 +606,25 @@ int predict_reset_with_fill(sit_ctx *c, bool *done)
     return SIT_OK;
 }
 
+// the listed (wide) rows: packed columns in LDS where they fit, the split arrays in LDS, or global memory
+static int launch_wide_rows(sit_ctx *c, const PredArgs &a, i32 *wlist, unsigned *wcount, i64 seg_cap, int nseg, u64 *cnt)
+{
+    const int ncu = c->num_cu > 0 ? c->num_cu : 256;
+    const size_t csc = (size_t)c->csc_nnz * 12 + (size_t)(c->D + 1) * 4 + 16;
+    const size_t rec = (size_t)c->csc_nrec * PRED_REC + (size_t)c->D * 4;
+    const char *pl = getenv("SITATOR_PREDICT_LDS"), *pr = getenv("SITATOR_PREDICT_REC");
+    const bool no_lds = pl && pl[0] == '0';
+    if (c->d_col_rec && rec <= 150 * 1024 && !no_lds && !(pr && pr[0] == '0')) {
+        HIP_TRY(c, lds_limit((const void *)k_predict_rows_wide_rec, rec, c->device));
+        k_predict_rows_wide_rec<<<dim3((unsigned)std::min(ncu, nseg)), dim3(PRED_WIDE_LDS_BLOCK), rec, c->stream>>>(a, c->d_col_rec, (int)c->csc_nrec, wlist, wcount, seg_cap, nseg, cnt);
+    } else if (csc <= 150 * 1024 && !no_lds) {
+        HIP_TRY(c, lds_limit((const void *)k_predict_rows_wide_lds, csc, c->device));
+        k_predict_rows_wide_lds<<<dim3((unsigned)std::min(ncu, nseg)), dim3(PRED_WIDE_LDS_BLOCK), csc, c->stream>>>(a, wlist, wcount, seg_cap, nseg, (int)c->csc_nnz, cnt);
+    } else
+        k_predict_rows_wide<<<dim3((unsigned)std::min(nseg, ncu * 8)), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, seg_cap, nseg, cnt);
+    return SIT_OK;
+}
+
 static int run_predict(sit_ctx *c, double threshold, bool words_reset = false)
 {
     SIT_REQUIRE(c, c->rows_valid, "predict: no landmark rows on the device (run sit_fill with store_rows)");
@@ -426,7 +651,6 @@ static int run_predict(sit_ctx *c, double threshold, bool words_reset = false)
         int v = 0;
         c->num_cu = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0 ? v : 256;
     }
-    const int ncu = c->num_cu;
     StageTimer t(c, T_PREDICT);
     bool counted = false;
     if (c->max_col <= PRED_MAXCOL) {
@@ -435,14 +659,24 @@ static int run_predict(sit_ctx *c, double threshold, bool words_reset = false)
         const bool narrow_lds = pp.narrow_lds, wide_lds = pp.wide_lds;
         const int nt = pp.nt, nseg = pp.nseg;
         const i64 seg_cap = pp.seg_cap;
-        const size_t lds = pp.lds, csc = pp.csc;
+        const size_t lds = pp.lds;
         unsigned *wcount = pp.wcount;
         i32 *wlist = pp.wlist;
-        if (getenv("SITATOR_DEBUG_SHAPE")) fprintf(stderr, "predict: lds %zu nt %d per_cu %d nseg %d seg_cap %lld narrow_lds %d wide_lds %d rows_W %lld\n", lds, nt, pp.per_cu, nseg, (long long)seg_cap, (int)narrow_lds, (int)wide_lds, (long long)c->rows_W);
+        if (getenv("SITATOR_DEBUG_SHAPE")) fprintf(stderr, "predict: lds %zu nt %d per_cu %d nseg %d seg_cap %lld narrow_lds %d wide_lds %d rec %d rows_W %lld\n", lds, nt, pp.per_cu, nseg, (long long)seg_cap, (int)narrow_lds, (int)wide_lds, (int)pp.rec, (long long)c->rows_W);
         u64 *cnt = narrow_lds ? (u64 *)c->d_counts : nullptr;            // the LDS kernel counts the labels on the way
         // sit_fill with assign = 1 has reset these words together with its own, ahead of the fill kernel
         if (!words_reset && (rc = reset_predict_words(c, narrow_lds, wcount, 2 * nseg))) return rc;
-        if (narrow_lds) {
+        if (narrow_lds && pp.rec) {
+            const int nrec = (int)c->csc_nrec;
+            if (nt == PRED_LDS_BLOCK) {
+                HIP_TRY(c, lds_limit((const void *)k_predict_rows_rec<PRED_LDS_BLOCK>, lds, c->device));
+                k_predict_rows_rec<PRED_LDS_BLOCK><<<dim3((unsigned)nseg), dim3(nt), lds, c->stream>>>(a, c->d_col_rec, nrec, wlist, wcount, seg_cap, (int)c->K, (u64 *)c->d_counts);
+            } else {
+                HIP_TRY(c, lds_limit((const void *)k_predict_rows_rec<1024>, lds, c->device));
+                k_predict_rows_rec<1024><<<dim3((unsigned)nseg), dim3(nt), lds, c->stream>>>(a, c->d_col_rec, nrec, wlist, wcount, seg_cap, (int)c->K, (u64 *)c->d_counts);
+            }
+            counted = true;
+        } else if (narrow_lds) {
             if (nt == PRED_LDS_BLOCK) {
                 HIP_TRY(c, lds_limit((const void *)k_predict_rows_lds<PRED_LDS_BLOCK>, lds, c->device));
                 k_predict_rows_lds<PRED_LDS_BLOCK><<<dim3((unsigned)nseg), dim3(nt), lds, c->stream>>>(a, wlist, wcount, seg_cap, (int)c->csc_nnz, (int)c->K, (u64 *)c->d_counts);
@@ -453,13 +687,7 @@ static int run_predict(sit_ctx *c, double threshold, bool words_reset = false)
             counted = true;
         } else
             k_predict_rows<<<dim3((unsigned)nseg), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, seg_cap);
-        if (c->rows_W > 4) {
-            if (wide_lds) {
-                HIP_TRY(c, lds_limit((const void *)k_predict_rows_wide_lds, csc, c->device));
-                k_predict_rows_wide_lds<<<dim3((unsigned)std::min(ncu, nseg)), dim3(PRED_WIDE_LDS_BLOCK), csc, c->stream>>>(a, wlist, wcount, seg_cap, nseg, (int)c->csc_nnz, cnt);
-            } else
-                k_predict_rows_wide<<<dim3((unsigned)std::min(nseg, ncu * 8)), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, seg_cap, nseg, cnt);
-        }
+        if (c->rows_W > 4 && (rc = launch_wide_rows(c, a, wlist, wcount, seg_cap, nseg, cnt))) return rc;
     } else k_predict_rows_dense<<<dim3(grid), dim3(PRED_BLOCK), 0, c->stream>>>(a);
     HIP_TRY(c, hipGetLastError());
     if (!counted && (rc = sit_label_counts(c))) return rc;      // np.bincount(labels[labels >= 0]) (:92)
@@ -478,16 +706,8 @@ int predict_listed_rows(sit_ctx *c, double threshold, i32 *wlist, unsigned *wcou
     a.col_ptr = c->d_col_ptr; a.col_k = c->d_col_k; a.col_val = c->d_col_val; a.dense = c->d_cen_dense;
     a.labels = c->d_labels; a.confs = c->d_confs;
     a.N = c->rows_N; a.K = c->K; a.D = c->D; a.normed = c->centers_normed; a.threshold = threshold;
-    const int ncu = c->num_cu > 0 ? c->num_cu : 256;
-    const size_t csc = (size_t)c->csc_nnz * 12 + (size_t)(c->D + 1) * 4 + 16;
-    const char *pl = getenv("SITATOR_PREDICT_LDS");
-    const bool wide_lds = csc <= 150 * 1024 && !(pl && pl[0] == '0');
     StageTimer t(c, T_PREDICT);
-    if (wide_lds) {
-        HIP_TRY(c, lds_limit((const void *)k_predict_rows_wide_lds, csc, c->device));
-        k_predict_rows_wide_lds<<<dim3((unsigned)std::min(ncu, nseg)), dim3(PRED_WIDE_LDS_BLOCK), csc, c->stream>>>(a, wlist, wcount, seg_cap, nseg, (int)c->csc_nnz, nullptr);
-    } else
-        k_predict_rows_wide<<<dim3((unsigned)std::min(nseg, ncu * 8)), dim3(PRED_BLOCK), 0, c->stream>>>(a, wlist, wcount, seg_cap, nseg, nullptr);
+    { const int rcw = launch_wide_rows(c, a, wlist, wcount, seg_cap, nseg, nullptr); if (rcw) return rcw; }
     HIP_TRY(c, hipGetLastError());
     int rc = sit_label_counts(c, false);
     if (rc) return rc;

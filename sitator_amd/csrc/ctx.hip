@@ -239,7 +239,7 @@ extern "C" void sit_destroy(sit_ctx *c)
     void *ptrs[] = {c->d_ref_static, c->d_verts, c->d_vcd, c->d_bin_off, c->d_bin_list,
                     c->frames_owned ? c->d_frames : nullptr, c->d_static_idx, c->d_mobile_idx,
                     c->d_lattice_map, c->d_tbin_off, c->d_tbin_list, c->d_fill_args, c->d_frame_dmax, c->d_row_nnz, c->d_row_idx, c->d_row_val, c->d_labels, c->d_confs,
-                    c->d_counts, c->d_col_ptr, c->d_col_k, c->d_col_val, c->d_cen_dense, c->d_fit_centers,
+                    c->d_counts, c->d_col_ptr, c->d_col_k, c->d_col_val, c->d_col_rec, c->d_cen_dense, c->d_fit_centers,
                     c->d_vh, c->d_vh16, c->d_ref_soa, c->d_nv, c->d_exptab, c->d_pack, c->d_bin_crit, c->d_tbin_crit,
                     c->d_fit_nrm2, c->d_fit_counts, c->d_fit_K, c->d_err, c->d_scratch};
     for (void *p : ptrs) if (p) sit_dfree(c, p);

@@ -123,6 +123,8 @@ struct sit_ctx {
     i64 csc_nnz = 0;                  // entries of the CSC arrays
     i32 *d_col_ptr = nullptr, *d_col_k = nullptr;
     double *d_col_val = nullptr;
+    i64 csc_nrec = 0;
+    unsigned *d_col_rec = nullptr;    // the same entries as 12-byte records {value, centre id}, a sentinel behind every column (csc_nrec = csc_nnz + D)
     double *d_cen_dense = nullptr;    // [K,D] the same matrix, dense (fallback predict)
 
     // fit state (dense centres on device)
