@@ -239,66 +239,68 @@ __global__ __launch_bounds__(NTMAX) void k_predict_rows_lds(PredArgs a, i32 *wid
 // registers, a step multiplies what it holds and advances with one 12-byte read (two LDS instructions behind one address) per matching column, no end compare,
 // and the loads of a step are waited for together at the top of the next.  dot = 0.0 + t for a first term that is not
 // column 0's: the same bits as t but for the sign of a zero, and only |dot| is used.
-// ArgMaxQ (sit_internal.h) without its nest of branches: the incumbent starts at -1 (any |dot| beats it, so "none yet" needs
-// no test of its own), the centre id stays 32 bits wide, a NaN is taken by the same select as a larger value and then keeps
-// the place (nothing compares greater than it; a later NaN is refused by the flag); only the near-tie of two quotients
-// (:177-178: the reference divides before it compares) is a branch, and a rare one.
+// ArgMaxQ (sit_internal.h) without its nest of branches and without state beside the incumbent: `ms` is the incumbent's dot
+// product with its sign (every use takes |ms| - a source modifier, not an instruction), +0.0 with i = -1 before the first
+// (a first candidate scoring exactly 0 is then not taken, which finish_assignment cannot tell from taking it: both end as
+// centre 0 with confidence 0).  A NaN is taken by the same select as a larger value ("not less-or-equal") and then keeps
+// the place: nothing is taken while ms is a NaN.  Only the near-tie of two quotients (:177-178: the reference divides
+// before it compares) is a branch, and a rare one.
 struct ArgMaxR {
-    double m;
+    double ms;
     i32 i;
-    bool nan;
-    __device__ __forceinline__ void init() { m = -1.0; i = -1; nan = false; }
+    __device__ __forceinline__ void init() { ms = 0.0; i = -1; }
     __device__ __forceinline__ void push(double dot, i32 cid, double xn, bool normed)
     {
-        const double v = fabs(dot);
-        bool gt = v > m;
-        if (normed && gt && !(v > m * (1.0 + 1e-15))) gt = v / xn > m / xn;   // equal quotients: the earlier centre keeps the place
-        const bool vnan = v != v;
-        const bool take = !nan && (gt || vnan);
-        m = take ? v : m;
+        bool take = !(fabs(dot) <= fabs(ms));                        // greater, or unordered
+        const bool clear = fabs(dot) > fabs(ms) * (1.0 + 1e-15);     // (computed by every lane: the test below stays rare)
+        if (normed & take & !clear)
+            take = dot != dot || fabs(dot) / xn > fabs(ms) / xn;    // equal quotients: the earlier centre keeps the place
+        take = take & (ms == ms);                                    // the first NaN stays (np.argmax)
+        ms = take ? dot : ms;
         i = take ? cid : i;
-        nan = nan || vnan;
     }
     __device__ __forceinline__ Best result(double xn, bool normed) const
     {
         Best b;
-        b.i = (i64)i; b.nan = nan ? 1 : 0;
+        const double m = fabs(ms);
+        b.i = (i64)i; b.nan = m != m ? 1 : 0;
         b.v = i < 0 ? 0.0 : (normed ? m / xn : m);                   // :177-178 (NaN / xn stays NaN)
         return b;
     }
 };
-struct RecHead { i32 h; double hv; unsigned p; };
+typedef const unsigned __attribute__((address_space(3))) *LdsWords;
+struct RecHead { i32 h; double hv; unsigned p; };                   // p: the LDS address of the record
 #define PRED_REC 12                   // bytes of a record {value (two words), centre id}: 12 keeps the LDS footprint of the split arrays
-__device__ __forceinline__ void rec_load(const char *l_rec, RecHead &c)
+__device__ __forceinline__ void rec_load(RecHead &c)
 {
-    const unsigned *r = (const unsigned *)(l_rec + c.p);
+    LdsWords r = (LdsWords)(uintptr_t)c.p;
     const unsigned r0 = r[0], r1 = r[1], r2 = r[2];
     c.h = (i32)r2;
     c.hv = __hiloint2double((int)r1, (int)r0);
 }
 __device__ __forceinline__ Best merge4_rec(int n, i32 d0, i32 d1, i32 d2, i32 d3, double v0, double v1, double v2, double v3,
-                                           double xn, bool normed, const unsigned *l_off, const char *l_rec)
+                                           double xn, bool normed, const unsigned *l_off)
 {
     ArgMaxR am;
     am.init();
     const i32 none = 0x7fffffff;
     RecHead c0, c1, c2, c3;
-    c0.p = l_off[d0]; rec_load(l_rec, c0);
+    c0.p = l_off[d0]; rec_load(c0);
     c1.h = none; c1.hv = 0.0; c1.p = 0u;
     c2 = c1; c3 = c1;
-    if (n > 1) { c1.p = l_off[d1]; rec_load(l_rec, c1); }
-    if (n > 2) { c2.p = l_off[d2]; rec_load(l_rec, c2); }
-    if (n > 3) { c3.p = l_off[d3]; rec_load(l_rec, c3); }
+    if (n > 1) { c1.p = l_off[d1]; rec_load(c1); }
+    if (n > 2) { c2.p = l_off[d2]; rec_load(c2); }
+    if (n > 3) { c3.p = l_off[d3]; rec_load(c3); }
     while (true) {
         i32 cid = c0.h < c1.h ? c0.h : c1.h;
         const i32 m23 = c2.h < c3.h ? c2.h : c3.h;
         cid = cid < m23 ? cid : m23;
         if (cid == none) break;
         double dot = 0.0;
-        if (c0.h == cid) { dot = c0.hv * v0; c0.p += PRED_REC; rec_load(l_rec, c0); }
-        if (c1.h == cid) { dot = dot + c1.hv * v1; c1.p += PRED_REC; rec_load(l_rec, c1); }
-        if (c2.h == cid) { dot = dot + c2.hv * v2; c2.p += PRED_REC; rec_load(l_rec, c2); }
-        if (c3.h == cid) { dot = dot + c3.hv * v3; c3.p += PRED_REC; rec_load(l_rec, c3); }
+        if (c0.h == cid) { dot = c0.hv * v0; c0.p += PRED_REC; rec_load(c0); }
+        if (c1.h == cid) { dot = dot + c1.hv * v1; c1.p += PRED_REC; rec_load(c1); }
+        if (c2.h == cid) { dot = dot + c2.hv * v2; c2.p += PRED_REC; rec_load(c2); }
+        if (c3.h == cid) { dot = dot + c3.hv * v3; c3.p += PRED_REC; rec_load(c3); }
         am.push(dot, cid, xn, normed);                              // :177-179
     }
     return am.result(xn, normed);
@@ -310,12 +312,12 @@ __global__ __launch_bounds__(NTMAX) void k_predict_rows_rec(PredArgs a, const un
 {
     extern __shared__ __attribute__((aligned(16))) char pl_smem[];
     unsigned *l_rec = (unsigned *)pl_smem;                         // [nrec][3] = entries + a sentinel per column
-    unsigned *l_off = l_rec + 3 * nrec;                            // [D] byte offset of a column's first record
+    unsigned *l_off = l_rec + 3 * nrec;                            // [D] LDS address of a column's first record
     unsigned *hist = l_off + a.D;
     const int NT = NTMAX;
     for (int q = threadIdx.x; q < hist_K; q += NT) hist[q] = 0u;
     for (int q = threadIdx.x; q < 3 * nrec; q += NT) l_rec[q] = recs[q];
-    for (int q = threadIdx.x; q < (int)a.D; q += NT) l_off[q] = (unsigned)PRED_REC * (unsigned)(a.col_ptr[q] + q);
+    for (int q = threadIdx.x; q < (int)a.D; q += NT) l_off[q] = (unsigned)(uintptr_t)(LdsWords)l_rec + (unsigned)PRED_REC * (unsigned)(a.col_ptr[q] + q);
     __syncthreads();
     i32 *seg = wide_list + (i64)blockIdx.x * seg_cap;
     unsigned *seg_count = wide_count + 2 * blockIdx.x;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(NTMAX) void k_predict_rows_rec(PredArgs a, const un
             if (n > 1) { d1 = a.row_idx[a.N + row]; v1 = a.row_val[a.N + row]; }
             if (n > 2) { d2 = a.row_idx[2 * a.N + row]; v2 = a.row_val[2 * a.N + row]; }
             if (n > 3) { d3 = a.row_idx[3 * a.N + row]; v3 = a.row_val[3 * a.N + row]; }
-            const i64 to = finish_predict(a, row, merge4_rec(n, d0, d1, d2, d3, v0, v1, v2, v3, xn, a.normed != 0, l_off, (const char *)l_rec));
+            const i64 to = finish_predict(a, row, merge4_rec(n, d0, d1, d2, d3, v0, v1, v2, v3, xn, a.normed != 0, l_off));
             if (hist_K > 0 && to >= 0) atomicAdd(&hist[to], 1u);
         }
     }
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(PRED_WIDE_LDS_BLOCK) void k_predict_rows_wide_lds(P
 
 // The wide merges over the packed columns (merge4_rec's form; C5's rows hold 5-13 entries: the assignment is half its step).
 template <int NW>
-__device__ __forceinline__ i64 predict_row_merge_wide_rec(const PredArgs &a, i64 row, int n, double xn, const unsigned *l_off, const char *l_rec)
+__device__ __forceinline__ i64 predict_row_merge_wide_rec(const PredArgs &a, i64 row, int n, double xn, const unsigned *l_off)
 {
     ArgMaxR am;
     am.init();
@@ -413,7 +415,7 @@ __device__ __forceinline__ i64 predict_row_merge_wide_rec(const PredArgs &a, i64
         if (s < n) {
             c[s].p = l_off[a.row_idx[(i64)s * a.N + row]];
             v[s] = a.row_val[(i64)s * a.N + row];
-            rec_load(l_rec, c[s]);
+            rec_load(c[s]);
         }
     }
     while (true) {
@@ -427,7 +429,7 @@ __device__ __forceinline__ i64 predict_row_merge_wide_rec(const PredArgs &a, i64
             if (c[s].h == cid) {                                     // ascending dimension order (:176)
                 dot = dot + c[s].hv * v[s];
                 c[s].p += PRED_REC;
-                rec_load(l_rec, c[s]);
+                rec_load(c[s]);
             }
         }
         am.push(dot, cid, xn, a.normed != 0);                       // :177-179
@@ -435,15 +437,15 @@ __device__ __forceinline__ i64 predict_row_merge_wide_rec(const PredArgs &a, i64
     return finish_predict(a, row, am.result(xn, a.normed != 0));
 }
 
-__device__ __forceinline__ void predict_wide_row_rec(const PredArgs &a, i64 row, const unsigned *l_off, const char *l_rec, u64 *counts)
+__device__ __forceinline__ void predict_wide_row_rec(const PredArgs &a, i64 row, const unsigned *l_off, u64 *counts)
 {
     int n;
     double xn;
     if (!predict_row_head(a, row, n, xn)) return;
     i64 to;
-    if (n <= 8) to = predict_row_merge_wide_rec<8>(a, row, n, xn, l_off, l_rec);
-    else if (n <= 10) to = predict_row_merge_wide_rec<10>(a, row, n, xn, l_off, l_rec);
-    else if (n <= 16) to = predict_row_merge_wide_rec<16>(a, row, n, xn, l_off, l_rec);
+    if (n <= 8) to = predict_row_merge_wide_rec<8>(a, row, n, xn, l_off);
+    else if (n <= 10) to = predict_row_merge_wide_rec<10>(a, row, n, xn, l_off);
+    else if (n <= 16) to = predict_row_merge_wide_rec<16>(a, row, n, xn, l_off);
     else to = predict_row_generic(a, row, n, xn);
     if (counts && to >= 0) atomicAdd(&counts[to], 1ull);
 }
@@ -462,13 +464,13 @@ __global__ __launch_bounds__(PRED_WIDE_LDS_BLOCK) void k_predict_rows_wide_rec(P
     __syncthreads();
     if (!any) return;                                              // nothing for this workgroup: skip the staging
     for (int q = threadIdx.x; q < 3 * nrec; q += PRED_WIDE_LDS_BLOCK) l_rec[q] = recs[q];
-    for (int q = threadIdx.x; q < (int)a.D; q += PRED_WIDE_LDS_BLOCK) l_off[q] = (unsigned)PRED_REC * (unsigned)(a.col_ptr[q] + q);
+    for (int q = threadIdx.x; q < (int)a.D; q += PRED_WIDE_LDS_BLOCK) l_off[q] = (unsigned)(uintptr_t)(LdsWords)l_rec + (unsigned)PRED_REC * (unsigned)(a.col_ptr[q] + q);
     __syncthreads();
     for (int sg = blockIdx.x; sg < nseg; sg += gridDim.x) {
         const i64 na = (i64)wide_count[2 * sg], nb = (i64)wide_count[2 * sg + 1];
         const i32 *seg = wide_list + (i64)sg * seg_cap;
-        for (i64 q = threadIdx.x; q < na; q += PRED_WIDE_LDS_BLOCK) predict_wide_row_rec(a, seg[q], l_off, (const char *)l_rec, counts);
-        for (i64 q = threadIdx.x; q < nb; q += PRED_WIDE_LDS_BLOCK) predict_wide_row_rec(a, seg[seg_cap - 1 - q], l_off, (const char *)l_rec, counts);
+        for (i64 q = threadIdx.x; q < na; q += PRED_WIDE_LDS_BLOCK) predict_wide_row_rec(a, seg[q], l_off, counts);
+        for (i64 q = threadIdx.x; q < nb; q += PRED_WIDE_LDS_BLOCK) predict_wide_row_rec(a, seg[seg_cap - 1 - q], l_off, counts);
     }
 }
 
@@ -582,6 +584,17 @@ static int predict_plan(sit_ctx *c, PredPlan &p)
     // for two or one, of 1024 threads (from global memory C3's assignment took 2.1 ms per 4.5e7 rows)
     p.nt = !p.narrow_lds ? PRED_BLOCK : (p.lds <= 52 * 1024 ? PRED_LDS_BLOCK : 1024);
     p.per_cu = !p.narrow_lds ? 8 : (p.lds <= 36 * 1024 ? 4 : (p.lds <= 52 * 1024 ? 3 : (p.lds <= 78 * 1024 ? 2 : 1)));
+    // the packed kernel holds 62 registers in either size: 32 waves per CU while two workgroups fit (C2, 37 KB: 0.116 ms with
+    // 3 x 512 threads, 0.111 with 4 x 512, 0.108 with 2 x 1 024; 0.143 with 16 waves)
+    if (p.rec && p.narrow_lds) {
+        if (p.lds <= 78 * 1024) { p.nt = 1024; p.per_cu = 2; }
+        else { p.nt = 1024; p.per_cu = 1; }
+    }
+    if (const char *ps = getenv("SITATOR_PREDICT_SHAPE")) {         // "NTxPER_CU" (A/B): 512 or 1024 threads, workgroups per CU
+        int ntv = 0, pcv = 0;
+        if (p.narrow_lds && sscanf(ps, "%dx%d", &ntv, &pcv) == 2 && (ntv == PRED_LDS_BLOCK || ntv == 1024) && pcv >= 1 && pcv <= 4 &&
+            (size_t)pcv * (p.lds + 512) <= 160 * 1024) { p.nt = ntv; p.per_cu = pcv; }
+    }
     const i64 blocks = (c->N + p.nt - 1) / p.nt;
     p.nseg = (int)std::min<i64>(blocks, (i64)ncu * p.per_cu);
     p.seg_cap = (blocks + p.nseg - 1) / p.nseg * p.nt;             // rows a workgroup can meet
