@@ -60,7 +60,7 @@ class LandmarkAnalysis(object):
                  verbose=True, comm=None, device=None, recenter_masses=None, fit_mode="exact", devices=None):
         # Not in the reference: `devices=[0, 1, ...]` - ONE process drives several GPUs, a thread per GPU, the frames in
         # contiguous blocks in device order (the single-process form of the frame sharding; `comm` / `device` are the
-        # process-per-GPU form).  The result is one SiteTrajectory over all frames.
+        # process-per-GPU form).  The result is one SiteTrajectory over all frames.  Distinct GPUs exchange over RCCL.
         self._devices = None if devices is None else [int(d) for d in devices]
         if self._devices is not None and comm is not None:
             raise ValueError("devices=[...] and comm= are two ways to shard the frames: give one")
@@ -138,7 +138,8 @@ class LandmarkAnalysis(object):
             raise ValueError("Input SiteNetwork must have vertices")
         if frames.dtype != np.float64:
             raise ValueError("Buffer dtype mismatch, expected 'double' but got '%s'" % frames.dtype)
-        if self._devices is not None and len(self._devices) > 1:
+        if self._devices is not None and (len(self._devices) > 1 or
+                                          (len(self._devices) == 1 and os.environ.get("SITATOR_DEVICES_COMM", "").lower() == "rccl")):
             return self._run_on_devices(sn, frames)
         if self._devices is not None and len(self._devices) == 1:
             self._device = self._devices[0]
@@ -270,28 +271,56 @@ class LandmarkAnalysis(object):
         return out_st
 
     def _run_on_devices(self, sn, frames):
-        """``devices=[...]``: a thread per GPU runs the sharded analysis on its block of frames (``ThreadComm``); the blocks'
-        assignments are joined into one trajectory.  An exception the reference would raise is raised by every shard alike
-        (the shards agree on the first offender): the first one is passed on."""
+        """``devices=[...]``: a thread per GPU runs the sharded analysis on its block of frames; the blocks' assignments are
+        joined into one trajectory.  The shards' statistics meet over RCCL when the listed GPUs are distinct and there
+        (``RcclThreadComm``: a communicator per thread, the ``mcl`` accumulators reduced on the devices), otherwise in host
+        memory (``ThreadComm``); ``SITATOR_DEVICES_COMM=thread|rccl`` overrides, ``self.devices_comm`` says which it was.
+        An exception the reference would raise is raised by every shard alike (the shards agree on the first offender): the
+        first one is passed on."""
         import threading
-        from .sharding import ThreadComm, shard_frames
+        from .sharding import ThreadComm, RcclThreadComm, devices_comm_backend, shard_frames
         n = len(self._devices)
-        comms = ThreadComm.group(n)
+        gates = ThreadComm.group(n)
+        backend = devices_comm_backend(self._devices)
+        self.devices_comm = backend                    # 'rccl' (statistics over xGMI) or 'thread' (host memory)
+        uid = _lib.comm_unique_id() if backend == "rccl" else None
+        comms = list(gates)
+        inited = [threading.Event() for _ in range(n)]
         done = [None] * n
         failed = [None] * n
 
         def work(r):
             try:
+                try:
+                    if backend == "rccl":              # ncclCommInitRank: every thread enters, nobody returns before all have
+                        comms[r] = RcclThreadComm(self._devices[r], r, n, uid, gates[r])
+                finally:
+                    inited[r].set()
                 lo, hi = shard_frames(len(frames), r, n)
                 la = LandmarkAnalysis(comm=comms[r], device=self._devices[r], **self._init_kwargs)
                 done[r] = (la, la.run(sn, frames[lo:hi]))
             except BaseException as e:          # noqa: the others must not wait for a thread that has left
                 failed[r] = e
-                comms[r].abort()
+                gates[r].abort()
+            finally:
+                if isinstance(comms[r], RcclThreadComm):
+                    try:
+                        comms[r].close()
+                    except Exception:           # noqa: BLE001 - the result (or the first exception) stands
+                        pass
 
-        threads = [threading.Thread(target=work, args=(r,), name="sitator-gpu%d" % self._devices[r]) for r in range(n)]
+        threads = [threading.Thread(target=work, args=(r,), name="sitator-gpu%d" % self._devices[r], daemon=True) for r in range(n)]
         for t in threads:
             t.start()
+        if backend == "rccl":
+            limit = float(os.environ.get("SITATOR_RCCL_INIT_TIMEOUT", "120"))
+            t_end = time.perf_counter() + limit
+            for ev in inited:
+                if not ev.wait(max(0.0, t_end - time.perf_counter())):
+                    err = RuntimeError("devices=%s: ncclCommInitRank did not return within %.0f s "
+                                       "(SITATOR_DEVICES_COMM=thread exchanges through host memory)" % (self._devices, limit))
+                    err.stuck_in_rccl = True
+                    raise err
         for t in threads:
             t.join()
         real = [e for e in failed if e is not None and not isinstance(e, threading.BrokenBarrierError)]

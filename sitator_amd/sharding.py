@@ -393,6 +393,62 @@ class RcclComm(Comm):
         self.ctx.close()
 
 
+class RcclThreadComm(RcclComm):
+    """``LandmarkAnalysis(devices=[...])`` on RCCL (one process over several GPUs): a rank per
+    thread and GPU, the communicator made by ``ncclCommInitRank`` from every thread with the id the starting thread made
+    (what ``ncclCommInitAll`` does inside).  The statistics travel over xGMI instead of through host memory, and the
+    ``mcl`` plugin's exact Gram accumulators are all-reduced where they are (``sit_comm_attach``).  ``gate`` is this
+    rank's end of a ``ThreadComm``: every collective called from Python first meets the others there, so that a thread
+    which has left with an exception of its own (``abort()``) releases the rest with ``BrokenBarrierError`` instead of
+    leaving them inside a collective nobody else will enter."""
+
+    def __init__(self, device, rank, size, unique_id, gate):
+        RcclComm.__init__(self, device, rank, size, unique_id)
+        self._gate = gate
+
+    def _enter(self):
+        self._gate.barrier()
+
+    def allreduce_sum(self, arr):
+        self._enter()
+        return RcclComm.allreduce_sum(self, arr)
+
+    def allreduce_max(self, arr):
+        self._enter()
+        return RcclComm.allreduce_max(self, arr)
+
+    def allgather(self, arr):
+        self._enter()
+        return RcclComm.allgather(self, arr)
+
+    def bcast(self, arr, root=0):
+        self._enter()
+        return RcclComm.bcast(self, arr, root)
+
+    def barrier(self):
+        self._enter()
+        RcclComm.barrier(self)
+
+    def abort(self):
+        self._gate.abort()
+
+
+def devices_comm_backend(devices):
+    """'rccl' or 'thread' for ``LandmarkAnalysis(devices=[...])``: RCCL when every listed GPU is there and listed once
+    (RCCL refuses two ranks on one GPU) and librccl loads; ``SITATOR_DEVICES_COMM=thread|rccl`` decides otherwise."""
+    want = os.environ.get("SITATOR_DEVICES_COMM", "auto").lower()
+    if want in ("thread", "rccl"):
+        return want
+    from . import _lib
+    try:
+        if len(set(devices)) != len(devices) or max(devices) >= _lib.device_count() or min(devices) < 0:
+            return "thread"
+        _lib.comm_unique_id()
+        return "rccl"
+    except Exception:      # noqa: BLE001 - no library / no librccl: the host-memory exchange works everywhere
+        return "thread"
+
+
 def exact_sum_across(comm, hi, lo):
     """Sum over the ranks of exact accumulators (``sit_gram_limbs`` / ``sit_weighted_row_sums_limbs``: two's-complement
     128-bit integers hi * 2^64 + lo in units of 2^-80), rounded to float64 the way the library rounds a single rank's

@@ -306,16 +306,85 @@ def test_predict_with_centres_in_lds_equals_predict_from_global_memory(oracle, c
     X = ctx.rows_dense()
     centers = oracle.fit_centers(X, 0.45)
     ctx.set_centers(centers / np.linalg.norm(centers, axis=1)[:, None], True)
-    lab_a, conf_a, cnt_a = ctx.predict(0.8)
-    os.environ["SITATOR_PREDICT_LDS"] = "0"
-    try:
-        lab_b, conf_b, cnt_b = ctx.predict(0.8)
-    finally:
-        os.environ.pop("SITATOR_PREDICT_LDS", None)
-    assert np.array_equal(lab_a, lab_b) and np.array_equal(conf_a, conf_b) and np.array_equal(cnt_a, cnt_b)
+    lab_a, conf_a, cnt_a = ctx.predict(0.8)                  # packed columns in LDS (round 5)
+    for var in ("SITATOR_PREDICT_LDS", "SITATOR_PREDICT_REC"):   # global memory; the split arrays in LDS
+        os.environ[var] = "0"
+        try:
+            lab_b, conf_b, cnt_b = ctx.predict(0.8)
+        finally:
+            os.environ.pop(var, None)
+        assert np.array_equal(lab_a, lab_b) and np.array_equal(conf_a, conf_b) and np.array_equal(cnt_a, cnt_b), var
     assert np.array_equal(cnt_a, np.bincount(lab_a[lab_a >= 0], minlength=len(centers)))
     lab_o, conf_o = oracle.predict(X, centers, 0.8, True)
     assert np.array_equal(lab_o, lab_a)
+
+
+@pytest.mark.parametrize("normed,nonfinite", [(True, False), (False, False), (True, True)])
+def test_assignment_kernels_agree_on_ties_nans_and_every_row_width(oracle, normed, nonfinite):
+    """The three forms of the assignment (packed columns in LDS, split arrays in LDS, global memory) and the oracle
+    (util/DotProdClassifier.pyx:129-197: np.argmax of |centres . x| - the first maximum, the first NaN) on rows made to
+    meet every branch: exact ties between centres, quotients that differ in the last place only (the reference divides by
+    |x| BEFORE it compares), negative products, centres that do not overlap the row, rows of 0-4 entries (the narrow
+    kernel), 5-16 (the wide merges) and more (the generic one), thresholds on both sides.  With NaN / infinite centre
+    entries (nonfinite) the three forms are compared with each other only: the reference's DENSE product turns such a
+    centre's score into NaN for every row (0 x NaN), which no fitted centre set produces and the sparse kernels do not
+    reproduce for rows outside the entry's landmark."""
+    from sitator_amd import _lib
+    rng = np.random.default_rng(7 + int(normed))
+    D, K, N = 40, 24, 6000
+    centers = np.zeros((K, D))
+    for k in range(K):
+        sup = rng.choice(D, size=int(rng.integers(1, 9)), replace=False)
+        centers[k, sup] = rng.choice([0.25, 0.5, -0.5, 1.0, 0.3, 0.7, -0.9], size=len(sup))
+    centers[5] = centers[2]                                   # exact ties: the earlier centre keeps the place
+    centers[9] = -centers[2]
+    centers[11] = centers[3] * (1.0 + 2.0 ** -52)             # one unit in the last place apart
+    centers[13] = centers[3] * (1.0 - 2.0 ** -53)
+    if nonfinite:
+        centers[17, int(np.flatnonzero(centers[17])[0])] = np.nan
+        centers[19, int(np.flatnonzero(centers[19])[0])] = np.inf
+    dev_centers = centers.copy()
+    if normed:                                               # :155-161, summed in sequence as the oracle sums
+        for k in range(K):
+            n2 = 0.0
+            for d in range(D):
+                n2 += centers[k, d] * centers[k, d]
+            with np.errstate(invalid="ignore"):
+                dev_centers[k] = centers[k] / np.sqrt(n2)
+    X = np.zeros((N, D))
+    widths = rng.choice([0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 13, 16, 17, 22], size=N)
+    for r in range(N):
+        cols = rng.choice(D, size=int(widths[r]), replace=False)
+        X[r, cols] = rng.choice([1.0, 0.5, 0.25, 0.75, 1e-3, 3.0], size=len(cols))
+    for r in range(0, N, 7):                                  # rows on a centre's own support: scores near 1
+        k = int(rng.integers(K))
+        if np.all(np.isfinite(centers[k])):
+            X[r] = np.abs(centers[k]) * rng.choice([1.0, 2.0, 0.5])
+    ctx = _lib.HipContext(np.eye(3))
+    ctx.set_rows_dense(X)
+    ctx.set_centers(dev_centers, normed)
+    for thr in (0.0, 0.45, 0.8):
+        with np.errstate(invalid="ignore", over="ignore"):
+            lab_o, conf_o = oracle.predict(X, centers, thr, normed)
+        got = {}
+        for name, var in (("packed", None), ("split", "SITATOR_PREDICT_REC"), ("global", "SITATOR_PREDICT_LDS")):
+            if var:
+                os.environ[var] = "0"
+            try:
+                got[name] = ctx.predict(thr)
+            finally:
+                if var:
+                    os.environ.pop(var, None)
+        for name in ("split", "global"):
+            for a, b in zip(got["packed"], got[name]):
+                assert np.array_equal(a, b, equal_nan=True), (name, thr)
+        lab, conf, cnt = got["packed"]
+        assert np.array_equal(cnt, np.bincount(lab[lab >= 0], minlength=K))
+        if not nonfinite:
+            bad = np.flatnonzero(lab != lab_o)
+            assert bad.size == 0, (thr, bad[:5], lab[bad[:5]], lab_o[bad[:5]], conf[bad[:5]], conf_o[bad[:5]], widths[bad[:5]])
+            assert np.allclose(conf, conf_o, rtol=1e-12, atol=0)
+    ctx.close()
 
 
 @pytest.mark.parametrize("cfg,M,F", [("C2", 64, 40), ("C1b", 4, 300)])

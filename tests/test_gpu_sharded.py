@@ -93,3 +93,44 @@ def test_devices_mode_passes_the_reference_error_on():
     with pytest.raises(errors.StaticLatticeError) as ei:
         LandmarkAnalysis(verbose=False, devices=[0, 0], **c.kwargs("dotprod")).run(sn, frames)
     assert ei.value.frame == bad
+
+
+@pytest.mark.parametrize("tag", ["dotprod", "mcl"])
+def test_devices_mode_on_rccl_with_the_one_gpu_there_is(tag, monkeypatch):
+    """``devices=[...]`` with distinct GPUs exchanges over RCCL (``RcclThreadComm``: ``ncclCommInitRank`` from a thread per
+    GPU).  RCCL refuses two ranks on one GPU, so what a one-GPU box can run is the world of ONE: the id, the thread's
+    communicator, its gate, the run behind it and the tear-down - and, asked for two ranks on GPU 0 without the override,
+    the host-memory exchange is taken instead (the case above).  The multi-GPU form is the driver's to run."""
+    from sitator_amd import LandmarkAnalysis, SiteNetwork, Structure
+    from sitator_amd.sharding import devices_comm_backend
+    assert devices_comm_backend([0, 0]) == "thread" and devices_comm_backend([0]) == "rccl" and devices_comm_backend([0, 64]) == "thread"
+    monkeypatch.setenv("SITATOR_DEVICES_COMM", "rccl")
+    c = G.Case("c1_hex_scgrid")
+    sn = SiteNetwork(Structure(c.ref_positions, c.cell), c.static_mask, c.mobile_mask)
+    sn.centers = c.centers
+    sn.vertices = c.vertices
+    la = LandmarkAnalysis(verbose=False, devices=[0], **c.kwargs(tag))
+    st = la.run(sn, np.ascontiguousarray(c.frames))
+    assert la.devices_comm == "rccl"
+    exp = c.out(tag)
+    assert np.array_equal(st.traj, exp["labels"])
+    np.testing.assert_allclose(np.asarray(st.site_network.centers), exp["site_centers"], rtol=1e-6, atol=1e-8)
+
+
+def test_rccl_thread_comm_collectives_pass_the_gate_and_a_broken_gate_releases_them():
+    import threading
+    from sitator_amd import _lib
+    from sitator_amd.sharding import RcclThreadComm, ThreadComm
+    gate = ThreadComm.group(1)[0]
+    comm = RcclThreadComm(0, 0, 1, _lib.comm_unique_id(), gate)
+    try:
+        assert comm.info()["ranks"] == 1
+        x = np.arange(5, dtype=np.float64)
+        assert np.array_equal(comm.allreduce_sum(x), x) and np.array_equal(comm.allreduce_max(x), x)
+        assert np.array_equal(comm.allgather(x), x[None, :]) and np.array_equal(comm.bcast(x), x)
+        comm.barrier()
+        comm.abort()                                      # a thread has left: nobody enters another collective
+        with pytest.raises(threading.BrokenBarrierError):
+            comm.allreduce_sum(x)
+    finally:
+        comm.close()
