@@ -63,7 +63,7 @@ if "SQ_INSTS_VALU" in fill and "GRBM_GUI_ACTIVE" in fill:
                        "issue_frac = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs"},
               open("profiles/pmc_valu.json", "w"), indent=1)
 for extra in ("ab_fill_c2.txt", "ab_fill_c5.txt", "stages.txt", "bench_tcp2.json", "bench_tcp2_C4.json", "bench_tcp2_C5.json", "e2e_walls_c2.txt",
-              "phase_times.txt", "mem_counters.txt"):
+              "phase_times.txt", "mem_counters.txt", "predict_counters.txt", "ab_predict_c2.txt"):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), "profiles/%s_%s" % (name, extra))
 print("bench value %.4g lvec/s, fill %.4f ms, predict %.4f ms, frac %.4f, frac_step %.4f" % (

@@ -34,6 +34,11 @@ SITATOR_BENCH_BACKEND=tcp $T python3 $R/bench.py --gpus 2 --config C5 --algo mcl
 timeout -k 10 200 python3 $R/scratch/phase_times.py C2 100000 > $O/phase_times.txt 2>&1 || exit 1
 timeout -k 10 500 bash $R/scratch/pmc_mem.sh gpurun_out/$tag/mem 100000 C2 > $O/mem_counters.txt 2>&1 || exit 1
 $T python3 $R/scratch/e2e_walls.py C2 100000 4 > $O/e2e_walls_c2.txt 2>&1 || exit 1
+# round 5: the assignment kernel's counters, packed columns and (for comparison) the split arrays of round 4
+timeout -k 10 500 bash $R/scratch/pmc_predict.sh C2 > $O/predict_counters.txt 2>&1 || exit 1
+echo "---- SITATOR_PREDICT_REC=0 (the split-array kernel of round 4) ----" >> $O/predict_counters.txt
+SITATOR_PREDICT_REC=0 timeout -k 10 500 bash $R/scratch/pmc_predict.sh C2 >> $O/predict_counters.txt 2>&1 || exit 1
+SWEEP_FIT_FRAMES=100000 $T python3 $R/scratch/sweep_env.py C2 100000 "" "SITATOR_PREDICT_REC=0" "SITATOR_PREDICT_LDS=0" > $O/ab_predict_c2.txt 2>&1 || exit 1
 sha256sum $R/sitator_amd/lib/libsitator_hip.so | cut -c1-16 > $O/lib_sha16
 find $O -name "*.db" -delete
 tail -n 3 $O/e2e_c2.log $O/e2e_c5.log $O/dyn.log
