@@ -922,8 +922,8 @@ __device__ __forceinline__ double wave_incl_scan(double x, int lane)      // exa
 struct WalkLds {
     unsigned short lst[FS_LCAP];     // joining rows (batch row numbers), ascending
     double addm[66 * FS_CS];         // [join][support slot]: what the joining row adds to the slot (+2 rows: the chain reads ahead)
-    double2 fq[64];                  // per join of the group: sample count after it, its reciprocal
-    unsigned jo[64];                 // per join: byte offset of its version
+    double2 fq[68];                  // per join of the group: sample count after it, its reciprocal (+ slack: the chain reads ahead)
+    unsigned jo[68];                 // per join: byte offset of its version
     i32 supl[FS_CS];                 // the support, for the joins to look their dimensions up
     i32 rowi[64 * FS_NP];            // first entries of the joining rows, [entry][join]: a lane per join writes and reads
     double rowv[64 * FS_NP];         // without bank conflicts ([join][entry] put all 64 lanes on one or two banks)
@@ -1078,30 +1078,45 @@ __device__ __forceinline__ void fs_walk_centre(FSRef s, FSRowsRef r, FSCtl *ctl,
                 // the chain: per join multiply, add, divide (a / b as RN(a * RN(1 / b)) with one exact-residual
                 // correction: bit-identical to the IEEE quotient) and the version.  The join's constants come out of
                 // its lane's registers; what it adds to my slot is read from LDS one join ahead.
-#define FS_JOIN_STEP(q, a)                                                                              \
+#define FS_JOIN_STEP(f_, off_, a)                                                                       \
                 {                                                                                               \
-                    const double2 f_ = L.fq[q];                           /* fo of this join = fn of the one before */ \
-                    const unsigned off_ = L.jo[q];                                                              \
-                    const double t = wk.val * qfo + (a);                                                        \
+                    const double t = wk.val * qfo + (a);                  /* fo of this join = fn of the one before */ \
                     const double q0 = t * f_.y;                                                                 \
                     wk.val = __builtin_fma(__builtin_fma(-q0, f_.x, t), f_.y, q0);                              \
                     wk.cnt = f_.x;                                                                              \
                     wk.publish_at(s, off_);                                                                     \
                     qfo = f_.x;                                                                                 \
                 }
+                // (round 5: everything a join reads from LDS - its constants, its version's offset, what it adds to my slot -
+                // is requested one iteration = two joins ahead.  Before, the constants were read at the top of the iteration
+                // that used them: a lone wave waited out an LDS round trip per pair of joins, 228 cycles per join for a
+                // chain of five dependent FP64 operations.)
                 const int u0 = __builtin_amdgcn_readfirstlane(s0), u1 = __builtin_amdgcn_readfirstlane(s1);
                 const double *col = lane < SW ? addm + lane : &L.zero;      // lanes outside the support add 0 to their 0
                 const int stp = lane < SW ? SWP : 0;
-                double a0 = u0 < u1 ? col[u0 * stp] : 0.0, a1 = 0.0;
-                double qfo = bc_d(fo, u0 < 64 ? u0 : 0);
                 int q = u0;
-                for (; q + 1 < u1; q += 2) {
-                    a1 = col[(q + 1) * stp];
-                    FS_JOIN_STEP(q, a0)
-                    a0 = col[(q + 2) * stp];                               // (two rows of slack behind the last join)
-                    FS_JOIN_STEP(q + 1, a1)
+                double qfo = bc_d(fo, u0 < 64 ? u0 : 0);
+                // two register sets take turns (no copies at the end of an iteration: a copy would wait for the load)
+#define FS_LOAD_SET(X, qq)                                                                                      \
+                X##a0 = col[(qq) * stp]; X##a1 = col[((qq) + 1) * stp];   /* (two rows of slack behind the last join) */ \
+                X##f0 = L.fq[qq]; X##f1 = L.fq[(qq) + 1]; X##o0 = L.jo[qq]; X##o1 = L.jo[(qq) + 1];
+                double Aa0, Aa1, Ba0, Ba1;
+                double2 Af0, Af1, Bf0, Bf1;
+                unsigned Ao0, Ao1, Bo0, Bo1;
+                FS_LOAD_SET(A, q)
+                for (;;) {
+                    if (!(q + 1 < u1)) { if (q < u1) FS_JOIN_STEP(Af0, Ao0, Aa0) break; }
+                    FS_LOAD_SET(B, q + 2)
+                    FS_JOIN_STEP(Af0, Ao0, Aa0)
+                    FS_JOIN_STEP(Af1, Ao1, Aa1)
+                    q += 2;
+                    if (!(q + 1 < u1)) { if (q < u1) FS_JOIN_STEP(Bf0, Bo0, Ba0) break; }
+                    FS_LOAD_SET(A, q + 2)
+                    FS_JOIN_STEP(Bf0, Bo0, Ba0)
+                    FS_JOIN_STEP(Bf1, Bo1, Ba1)
+                    q += 2;
                 }
-                if (q < u1) FS_JOIN_STEP(q, a0)
+#undef FS_LOAD_SET
 #undef FS_JOIN_STEP
                 FF_T(t_l2);
                 FF_ACC(3, t_l2 - t_l1);
