@@ -1007,12 +1007,15 @@ __device__ __forceinline__ void fs_walk_centre(FSRef s, FSRowsRef r, FSCtl *ctl,
         FF_ACC(0, t_list1 - t_list0); FF_ACC(7, 1); FF_ACC(5, Ts);
         JoinRows J;
         join_rows_load(J, r, pos + (lane < Ts ? lst[lane] : 0), lane < Ts);
+        int fbad = __hip_atomic_load(&ctl->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int g0 = 0; g0 < Ts; g0 += 64) {
             const bool isj = g0 + lane < Ts;
             const int j = isj ? lst[g0 + lane] : 0x7fffffff;
             const int Tg = Ts - g0 < 64 ? Ts - g0 : 64;
-            // rows beyond the first row known to be wrong are void
-            if (bc_i(j, 0) > __hip_atomic_load(&ctl->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+            // rows beyond the first row known to be wrong are void (an early way out, not needed for the result: the value
+            // is the one requested a group earlier - waiting for it here cost a memory round trip per group of 64 joins)
+            if (bc_i(j, 0) > fbad) return;
+            fbad = __hip_atomic_load(&ctl->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             FF_T(t_g0);
             FF_ACC(6, 1);
             const i64 row = pos + (isj ? j : 0);
