@@ -938,17 +938,32 @@ struct JoinRows {
     double v[FS_NP];
 };
 
-__device__ __forceinline__ void join_rows_load(JoinRows &J, FSRowsRef r, i64 row, bool isj)
+// (round 5: in two stages - a row's entry count travels two groups ahead of its use, its entries one group ahead and only as
+// many of them as the widest row of the group holds: the rows of a C2 batch are up to ten entries wide, a group's rows three
+// or four, and every 64-address load costs the lone wave its 64 cycles in the address unit)
+__device__ __forceinline__ void join_rows_head(int &n, double &wd, FSRowsRef r, i64 row, bool isj)
 {
-    J.n = 0; J.wd = 0.0;
+    n = 0; wd = 0.0;
+    if (isj) {
+        n = r.nnz[row];
+        wd = r.weights ? (double)r.weights[row] : 1.0;
+    }
+}
+__device__ __forceinline__ int join_rows_widest(int n, FSRowsRef r)      // entries to stage for a group: uniform, <= FS_NP
+{
+    int m = 0;
+    while (m < FS_NP && m < r.width && __ballot(n > m)) m++;
+    return m;
+}
+__device__ __forceinline__ void join_rows_entries(JoinRows &J, FSRowsRef r, i64 row, bool isj, int n, double wd, int nstage)
+{
+    J.n = n; J.wd = wd;
 #pragma unroll
     for (int e = 0; e < FS_NP; e++) { J.i[e] = 0; J.v[e] = 0.0; }
     if (isj) {
-        J.n = r.nnz[row];
-        J.wd = r.weights ? (double)r.weights[row] : 1.0;
 #pragma unroll
         for (int e = 0; e < FS_NP; e++)
-            if (e < r.width) { J.i[e] = r.idx[(i64)e * r.stride + row]; J.v[e] = r.val[(i64)e * r.stride + row]; }
+            if (e < nstage) { J.i[e] = r.idx[(i64)e * r.stride + row]; J.v[e] = r.val[(i64)e * r.stride + row]; }
     }
 }
 
@@ -1006,7 +1021,16 @@ __device__ __forceinline__ void fs_walk_centre(FSRef s, FSRowsRef r, FSCtl *ctl,
         FF_T(t_list1);
         FF_ACC(0, t_list1 - t_list0); FF_ACC(7, 1); FF_ACC(5, Ts);
         JoinRows J;
-        join_rows_load(J, r, pos + (lane < Ts ? lst[lane] : 0), lane < Ts);
+        int nN, nstage;                                             // the entry counts of the group after next; entries staged in J
+        double wN;
+        {
+            int n0;
+            double w0;
+            join_rows_head(n0, w0, r, pos + (lane < Ts ? lst[lane] : 0), lane < Ts);
+            join_rows_head(nN, wN, r, pos + (64 + lane < Ts ? lst[64 + lane] : 0), 64 + lane < Ts);
+            nstage = join_rows_widest(n0, r);
+            join_rows_entries(J, r, pos + (lane < Ts ? lst[lane] : 0), lane < Ts, n0, w0, nstage);
+        }
         int fbad = __hip_atomic_load(&ctl->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int g0 = 0; g0 < Ts; g0 += 64) {
             const bool isj = g0 + lane < Ts;
@@ -1022,14 +1046,19 @@ __device__ __forceinline__ void fs_walk_centre(FSRef s, FSRowsRef r, FSCtl *ctl,
             const int n = J.n;
             const double wd = J.wd;
 #pragma unroll
-            for (int e = 0; e < FS_NP; e++) if (e < r.width) { rowi[e * 64 + lane] = J.i[e]; rowv[e * 64 + lane] = J.v[e]; }
-            const double fn = wk.cnt + wave_incl_scan(wd, lane), fo = fn - wd, fy = 1.0 / fn;
+            for (int e = 0; e < FS_NP; e++) if (e < nstage) { rowi[e * 64 + lane] = J.i[e]; rowv[e * 64 + lane] = J.v[e]; }
+            // (unit weights - every fit but the re-clustering of centres: the running count is the lane's rank, the same
+            // integers the scan adds up, without its six LDS-routed exchanges per group)
+            const double ranks = r.weights ? wave_incl_scan(wd, lane) : (double)(lane < Tg ? lane + 1 : Tg);
+            const double fn = wk.cnt + ranks, fo = fn - wd, fy = 1.0 / fn;
             L.fq[lane] = make_double2(fn, fy);                      // the chain reads a join's constants as LDS broadcasts
             L.jo[lane] = isj ? (unsigned)j * (unsigned)(FS_CS * sizeof(VsEnt)) : 0u;
             // the next group's rows are on their way while this group is applied
             {
-                const bool nj = g0 + 64 + lane < Ts;
-                join_rows_load(J, r, pos + (nj ? lst[g0 + 64 + lane] : 0), nj);
+                const bool nj = g0 + 64 + lane < Ts, nj2 = g0 + 128 + lane < Ts;
+                nstage = join_rows_widest(nN, r);
+                join_rows_entries(J, r, pos + (nj ? lst[g0 + 64 + lane] : 0), nj, nN, wN, nstage);
+                join_rows_head(nN, wN, r, pos + (nj2 ? lst[g0 + 128 + lane] : 0), nj2);
             }
             int s0 = 0;
             FF_T(t_g1);
