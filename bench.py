@@ -372,8 +372,9 @@ def main():
             del frames, ctx, la, st_full
             _lib.release_cached_memory()
             out["configs"] = [other_config_child(args, c) for c in ("C3", "C4", "C5")]
-            out["scale_ref"] = {k: v for k, v in out["configs"][1].items() if k in ("workload", "value", "unit", "ms_per_step", "steps")}
-            out["scale_ref"]["end_to_end_run_seconds_cold"] = out["configs"][1]["end_to_end_run"]["cold_seconds"]
+            if "error" not in out["configs"][1]:
+                out["scale_ref"] = {k: v for k, v in out["configs"][1].items() if k in ("workload", "value", "unit", "ms_per_step", "steps")}
+                out["scale_ref"]["end_to_end_run_seconds_cold"] = out["configs"][1]["end_to_end_run"]["cold_seconds"]
         if c4 is not None:
             out["configs"] = [c4]
         sys.stdout.flush()
@@ -389,11 +390,15 @@ def other_config_child(args, cfg):
     the sub-record of `configs`."""
     cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--cpu-frames", "0", "--repeats", "1", "--no-scale-ref"]
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=dict(os.environ))
-    line = p.stdout.decode().strip().splitlines()[-1] if p.stdout.strip() else ""
-    if p.returncode != 0 or not line.startswith("{"):
-        raise RuntimeError("bench.py --config %s failed (exit %d)" % (cfg, p.returncode))
-    d = json.loads(line)
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, env=dict(os.environ), timeout=600)
+        line = p.stdout.decode().strip().splitlines()[-1] if p.stdout.strip() else ""
+        if p.returncode != 0 or not line.startswith("{"):
+            raise RuntimeError("exit %d" % p.returncode)
+        d = json.loads(line)
+    except Exception as e:      # noqa: BLE001 - the headline line must not depend on a side record
+        print("bench.py --config %s failed: %s" % (cfg, e), file=sys.stderr, flush=True)
+        return {"workload": cfg, "error": "%s: %s" % (type(e).__name__, e), "process": "own (`bench.py --config %s`)" % cfg}
     e2e = d["end_to_end_run"]
     return {"workload": d["config"]["workload"] + (" (one GPU's share of the 8-GPU run)" if cfg in ("C4", "C5") else ""),
             "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
