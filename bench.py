@@ -13,8 +13,8 @@ C2 shape on a hexagonal / triclinic cell).  One "step" = one pass of the hot pat
 static-lattice check + landmark vector of every (frame, mobile ion) + cosine assignment to the fitted site centres ->
 int64 label + float64 confidence per (frame, ion).  Frames are resident in HBM before the timed region; the site
 centres come from the product's own end-to-end `run()` on the same trajectory (outside the timed region; it is run
-twice - `end_to_end_run.seconds` is the second, warm run incl. jump detection, `cold_seconds` the first one of the
-process).
+three times - `cold_seconds` is the first run of the process, `end_to_end_run.seconds` the faster of the two warm runs
+behind it incl. jump detection, both listed in `warm_runs_seconds`).
 At N = 1 the default line also carries the other BASELINE configurations a GPU can hold (`configs`: C3, one GPU's share
 of C4 and of C5), each timed by a child process running `bench.py --config <it>` - a fresh process, because tens of GB of
 device buffers of another size class in the same process cost their hipFree / hipMalloc in whoever runs next.
@@ -171,16 +171,29 @@ def main():
     t_cold = time.time() - t0
     if comm is not None:
         comm.barrier()
-    t0 = time.time()
-    la = LandmarkAnalysis(verbose=False, device=local, comm=comm, **la_kw)
-    st_full = la.run(sn, frames)
-    t_run = time.time() - t0
-    n_jumps = sum(1 for _ in st_full.jumps())          # jump detection (SiteTrajectory.py:307-373): configs[4]'s last step
-    t_e2e = time.time() - t0
-    e2e = {"frames": F * world, "seconds": round(t_e2e, 4), "cold_seconds": round(t_cold, 4),
+    # two warm runs, the faster one reported and both listed: the SECOND run of a process comes out 5-8 ms slower than
+    # the third and later ones on some boxes (its uploads are slower; scratch/e2e_walls.py shows the series)
+    warm = []
+    la = st_full = None
+    for _ in range(2):
+        del la, st_full
+        if comm is not None:
+            comm.barrier()
+        t0 = time.time()
+        la = LandmarkAnalysis(verbose=False, device=local, comm=comm, **la_kw)
+        st_full = la.run(sn, frames)
+        t_run_i = time.time() - t0
+        n_jumps = sum(1 for _ in st_full.jumps())      # jump detection (SiteTrajectory.py:307-373): configs[4]'s last step
+        warm.append((time.time() - t0, t_run_i, dict(la.wall_timings)))
+    if comm is not None:                                # every rank reports the same run: the one rank 0 found faster
+        pick = int(comm.bcast(np.array([0 if warm[0][0] <= warm[1][0] else 1], dtype=np.int64))[0])
+    else:
+        pick = 0 if warm[0][0] <= warm[1][0] else 1
+    t_e2e, t_run, walls = warm[pick]
+    e2e = {"frames": F * world, "seconds": round(t_e2e, 4), "cold_seconds": round(t_cold, 4), "warm_runs_seconds": [round(w[0], 4) for w in warm],
            "algo": args.algo, "run_seconds": round(t_run, 4), "jump_detection_seconds": round(t_e2e - t_run, 4),
            "jumps": n_jumps, "lvec_per_s": round(world * F * M / t_e2e, 1),
-           "wall_s": {k: round(v, 4) for k, v in la.wall_timings.items()},
+           "wall_s": {k: round(v, 4) for k, v in walls.items()},
            "sites": int(st_full.site_network.n_sites), "unassigned_frac": float(st_full.percent_unassigned),
            "fit": {k: v for k, v in la._ctx.info().items() if k.startswith("fit_")},
            "exchange": exchange}
