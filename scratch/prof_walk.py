@@ -24,4 +24,4 @@ joins, groups, waves = v[5], v[6], v[7]
 print("joins %d groups %d waves-with-joins %d" % (joins, groups, waves))
 for n, c in zip(names, v[:5]):
     print("%-14s %.3g cycles  (%.0f per join, %.0f per group, %.0f per wave)" % (n, c, c / max(joins, 1), c / max(groups, 1), c / max(waves, 1)))
-print("longest walking wave: %d cycles, %d joins, %d groups" % (v[8], v[9], v[10]))
+print("longest walking wave: %d cycles, %d joins, %d groups; workgroups of the pair kernel whose two waves share a SIMD: %d" % (v[8], v[9], v[10], v[11]))

@@ -930,6 +930,16 @@ struct WalkLds {
     double zero;
 };
 
+// Round 5, two waves per centre (k_fs_walk_pair): the groups of a centre's joins alternate between the waves.  A group's
+// set-up (its rows from memory, its constants) does not depend on the chain and runs while the OTHER wave applies the group
+// before; the chain itself passes from wave to wave through this block - the support's values and landmarks as of the end
+// of a group, and whose turn it is.
+struct WalkShare {
+    double val[64];
+    i32 idx[64];
+    int sn, turn, quit, gen;          // gen: how often the support has grown so far
+};
+
 // the rows of one group of joins, a lane each, on their way from memory
 struct JoinRows {
     int n;
@@ -970,11 +980,59 @@ __device__ __forceinline__ void join_rows_entries(JoinRows &J, FSRowsRef r, i64 
 // The joins of centre k among batch rows [0, jlim), in order.  The wave lists them from the centre's bitmap (lane l
 // takes WPL consecutive words; at most FS_LCAP joins are listed at a time), then applies them in groups of 64: the
 // rows of a group are fetched by a lane each while the previous group is being applied.
-__device__ __forceinline__ void fs_walk_centre(FSRef s, FSRowsRef r, FSCtl *ctl, WalkLds &L, int k, int jlim, i64 pos, int lane)
+// Joins s0.. of a group look their dimensions up in the support (idx in the lanes' registers, SW entries) and write what
+// they add to each slot into the [join][slot] matrix; returns the joins that hold a dimension the support lacks.
+__device__ __forceinline__ u64 walk_lookups(FSRowsRef r, WalkLds &L, i32 widx, int SW, int s0, bool isj, int n, i64 row, int lane)
+{
+    double *addm = L.addm, *rowv = L.rowv;
+    i32 *supl = L.supl, *rowi = L.rowi;
+    const int SWP = SW | 1;
+    if (lane < SW) supl[lane] = widx;
+    __builtin_amdgcn_wave_barrier();
+    bool grow = false;
+    {
+        // The first four entries of a join's row against the support, which sits in the lanes' registers: one
+        // readlane per support entry and a compare per row entry, no dependent LDS reads (the binary search
+        // below cost 74 cycles per join, most of it the latency of its probes); further entries the slow way.
+        const bool act = isj && lane >= s0;
+        i32 d4[4];
+        double v4[4];
+        int sl[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            d4[e] = -1; v4[e] = 0.0; sl[e] = -1;
+            if (act && e < n) { d4[e] = rowi[e * 64 + lane]; v4[e] = rowv[e * 64 + lane]; }
+        }
+        for (int i = 0; i < SW; i++) {
+            const i32 si = bc_i(widx, i);
+#pragma unroll
+            for (int e = 0; e < 4; e++) sl[e] = d4[e] == si ? i : sl[e];
+        }
+        if (act) {
+            for (int i = 0; i < SW; i++) addm[lane * SWP + i] = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (e < n) { if (sl[e] >= 0) addm[lane * SWP + sl[e]] = v4[e]; else grow = true; }
+            for (int e = 4; e < n; e++) {
+                const i32 d = e < FS_NP ? rowi[e * 64 + lane] : r.idx[(i64)e * r.stride + row];
+                const double v = e < FS_NP ? rowv[e * 64 + lane] : r.val[(i64)e * r.stride + row];
+                int lo = 0, hi = SW;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (supl[mid] < d) lo = mid + 1; else hi = mid; }
+                if (lo < SW && supl[lo] == d) addm[lane * SWP + lo] = v; else grow = true;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return __ballot(grow);
+}
+
+#define FS_WALK_LEAVE do { if (PAIR) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); if (lane == 0) __hip_atomic_store(&sh->quit, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } return; } while (0)
+template <bool PAIR>
+__device__ __forceinline__ void fs_walk_centre(FSRef s, FSRowsRef r, FSCtl *ctl, WalkLds &L, WalkShare *sh, int w, int k, int jlim, i64 pos, int lane)
 {
     unsigned short *lst = L.lst;
     double *addm = L.addm, *rowv = L.rowv;
-    i32 *supl = L.supl, *rowi = L.rowi;
+    i32 *rowi = L.rowi;
     const u64 l1 = lane < FS_W1 ? s.bm1[(i64)k * FS_W1 + lane] : 0ull;
     if (!__ballot(l1 != 0)) return;
     FF_T(t_list0);
@@ -982,26 +1040,32 @@ __device__ __forceinline__ void fs_walk_centre(FSRef s, FSRowsRef r, FSCtl *ctl,
     const int WPL = (nwords + 63) >> 6;                         // words per lane, <= 16
     u64 wv[FS_W1];
     int mine = 0;
+    // (round 5: the words are requested in one sweep and looked at in a second - masking and counting a word where it was
+    // loaded made every one of a lane's sixteen loads wait for the one before: 26 000 of the 37 000 cycles a busy centre's
+    // listing took)
 #pragma unroll
     for (int q = 0; q < FS_W1; q++) {
         wv[q] = 0ull;
         const int w = lane * WPL + q;
         if (q >= WPL) continue;                                 // uniform
         const u64 lw = __shfl(l1, (w >> 6) & (FS_W1 - 1));      // every lane takes part in the exchange
-        if (w < nwords) {
-            if ((lw >> (w & 63)) & 1ull) {
-                u64 word = s.bm0[(i64)k * FS_W0 + w];
-                if (w * 64 + 64 > jlim) word &= (1ull << (jlim - w * 64)) - 1ull;      // w * 64 < jlim
-                wv[q] = word;
-                mine += __popcll(word);
-            }
-        }
+        if (w < nwords && ((lw >> (w & 63)) & 1ull)) wv[q] = s.bm0[(i64)k * FS_W0 + w];
+    }
+#pragma unroll
+    for (int q = 0; q < FS_W1; q++) {
+        const int w = lane * WPL + q;
+        if (q >= WPL) continue;                                 // uniform
+        if (w < nwords && w * 64 + 64 > jlim) wv[q] &= (1ull << (jlim - w * 64)) - 1ull;      // w * 64 < jlim
+        mine += __popcll(wv[q]);
     }
     int T;
     const int P = wave_excl_scan(mine, lane, T);
     if (T == 0) return;
     Walker wk;
     wk.load_state(s, k, lane);
+    const double cnt0 = wk.cnt;                                 // PAIR (unit weights): the count before a group = cnt0 + the joins before it
+    int gen = 0;                                                // PAIR: growths of the support this wave knows of
+    int G0 = 0;                                                 // PAIR: groups of the chunks before this one
     int a = 0, Pa = 0;                                          // lanes [a, b) are listed next; Pa joins precede them
     while (a < 64) {
         // as many whole lanes as fit the list (one lane holds at most 1024 joins)
@@ -1023,22 +1087,24 @@ __device__ __forceinline__ void fs_walk_centre(FSRef s, FSRowsRef r, FSCtl *ctl,
         JoinRows J;
         int nN, nstage;                                             // the entry counts of the group after next; entries staged in J
         double wN;
+        // PAIR: this wave's groups of the chunk are those whose number within the centre has its parity; GS joins on
+        const int GS = PAIR ? 128 : 64, gfirst = PAIR ? ((((G0 & 1) == w) ? 0 : 64)) : 0;
         {
             int n0;
             double w0;
-            join_rows_head(n0, w0, r, pos + (lane < Ts ? lst[lane] : 0), lane < Ts);
-            join_rows_head(nN, wN, r, pos + (64 + lane < Ts ? lst[64 + lane] : 0), 64 + lane < Ts);
+            join_rows_head(n0, w0, r, pos + (gfirst + lane < Ts ? lst[gfirst + lane] : 0), gfirst + lane < Ts);
+            join_rows_head(nN, wN, r, pos + (gfirst + GS + lane < Ts ? lst[gfirst + GS + lane] : 0), gfirst + GS + lane < Ts);
             nstage = join_rows_widest(n0, r);
-            join_rows_entries(J, r, pos + (lane < Ts ? lst[lane] : 0), lane < Ts, n0, w0, nstage);
+            join_rows_entries(J, r, pos + (gfirst + lane < Ts ? lst[gfirst + lane] : 0), gfirst + lane < Ts, n0, w0, nstage);
         }
         int fbad = __hip_atomic_load(&ctl->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int g0 = 0; g0 < Ts; g0 += 64) {
+        for (int g0 = gfirst; g0 < Ts; g0 += GS) {
             const bool isj = g0 + lane < Ts;
             const int j = isj ? lst[g0 + lane] : 0x7fffffff;
             const int Tg = Ts - g0 < 64 ? Ts - g0 : 64;
             // rows beyond the first row known to be wrong are void (an early way out, not needed for the result: the value
             // is the one requested a group earlier - waiting for it here cost a memory round trip per group of 64 joins)
-            if (bc_i(j, 0) > fbad) return;
+            if (bc_i(j, 0) > fbad) FS_WALK_LEAVE;
             fbad = __hip_atomic_load(&ctl->first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             FF_T(t_g0);
             FF_ACC(6, 1);
@@ -1050,60 +1116,65 @@ __device__ __forceinline__ void fs_walk_centre(FSRef s, FSRowsRef r, FSCtl *ctl,
             // (unit weights - every fit but the re-clustering of centres: the running count is the lane's rank, the same
             // integers the scan adds up, without its six LDS-routed exchanges per group)
             const double ranks = r.weights ? wave_incl_scan(wd, lane) : (double)(lane < Tg ? lane + 1 : Tg);
-            const double fn = wk.cnt + ranks, fo = fn - wd, fy = 1.0 / fn;
+            // (PAIR: the count before this group is not in this wave's registers - the other wave is still applying the
+            // group before - but it is known: unit weights, so the initial count + the joins listed before the group)
+            const double cntg = PAIR ? cnt0 + (double)(Pa + g0) : wk.cnt;
+            const double fn = cntg + ranks, fo = fn - wd, fy = 1.0 / fn;
             L.fq[lane] = make_double2(fn, fy);                      // the chain reads a join's constants as LDS broadcasts
             L.jo[lane] = isj ? (unsigned)j * (unsigned)(FS_CS * sizeof(VsEnt)) : 0u;
             // the next group's rows are on their way while this group is applied
             {
-                const bool nj = g0 + 64 + lane < Ts, nj2 = g0 + 128 + lane < Ts;
+                const bool nj = g0 + GS + lane < Ts, nj2 = g0 + 2 * GS + lane < Ts;
                 nstage = join_rows_widest(nN, r);
-                join_rows_entries(J, r, pos + (nj ? lst[g0 + 64 + lane] : 0), nj, nN, wN, nstage);
-                join_rows_head(nN, wN, r, pos + (nj2 ? lst[g0 + 128 + lane] : 0), nj2);
+                join_rows_entries(J, r, pos + (nj ? lst[g0 + GS + lane] : 0), nj, nN, wN, nstage);
+                join_rows_head(nN, wN, r, pos + (nj2 ? lst[g0 + 2 * GS + lane] : 0), nj2);
             }
             int s0 = 0;
             FF_T(t_g1);
             FF_ACC(1, t_g1 - t_g0);
+            const int Gc = G0 + (g0 >> 6);                          // this group's number within the centre
+            bool pre_ok = false;
+            u64 pre_gm = 0ull;
+            if (PAIR && Gc > 0) {
+                // the look-ups too, ahead of my turn, against the support as I last held it: good if nobody has grown it
+                // since (a count of the growths travels with the chain)
+                pre_gm = walk_lookups(r, L, wk.idx, wk.sn, 0, isj, n, row, lane);
+                pre_ok = true;
+            }
+            if (PAIR) {
+                // the chain is mine when the group before has been applied (bounded: a wave that never gets its turn ends
+                // the batch before this row instead of hanging the device)
+                int spins = 0;
+                bool dead = false;
+                while (__hip_atomic_load(&sh->turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != Gc) {
+                    if (__hip_atomic_load(&sh->quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        // the other wave has left - after handing the chain over (it leaves at a LATER group whose rows are
+                        // void, and this group's may not be), or without (everything from its group on is void).  (A wave's
+                        // LDS operations complete in order: `turn` is written before `quit`.)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                        dead = __hip_atomic_load(&sh->turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != Gc;
+                        break;
+                    }
+                    if (++spins > (1 << 22)) { if (lane == 0) atomicMin(&ctl->first_bad, bc_i(j, 0)); dead = true; break; }
+                    __builtin_amdgcn_s_sleep(0);
+                }
+                if (dead) FS_WALK_LEAVE;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+                if (Gc > 0) {
+                    const int gen_now = sh->gen;
+                    pre_ok = pre_ok && gen_now == gen;
+                    gen = gen_now;
+                    wk.val = sh->val[lane]; wk.idx = sh->idx[lane]; wk.sn = sh->sn;
+                }
+                wk.cnt = cntg;
+            }
             for (;;) {
                 // joins s0.. look their dimensions up in the support as it is now
                 FF_T(t_l0);
                 const int SW = wk.sn, SWP = SW | 1;            // odd row stride of the [join][slot] matrix: no bank conflicts
-                if (lane < SW) supl[lane] = wk.idx;
-                __builtin_amdgcn_wave_barrier();
-                bool grow = false;
-                {
-                    // The first four entries of a join's row against the support, which sits in the lanes' registers: one
-                    // readlane per support entry and a compare per row entry, no dependent LDS reads (the binary search
-                    // below cost 74 cycles per join, most of it the latency of its probes); further entries the slow way.
-                    const bool act = isj && lane >= s0;
-                    i32 d4[4];
-                    double v4[4];
-                    int sl[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        d4[e] = -1; v4[e] = 0.0; sl[e] = -1;
-                        if (act && e < n) { d4[e] = rowi[e * 64 + lane]; v4[e] = rowv[e * 64 + lane]; }
-                    }
-                    for (int i = 0; i < SW; i++) {
-                        const i32 si = bc_i(wk.idx, i);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) sl[e] = d4[e] == si ? i : sl[e];
-                    }
-                    if (act) {
-                        for (int i = 0; i < SW; i++) addm[lane * SWP + i] = 0.0;
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            if (e < n) { if (sl[e] >= 0) addm[lane * SWP + sl[e]] = v4[e]; else grow = true; }
-                        for (int e = 4; e < n; e++) {
-                            const i32 d = e < FS_NP ? rowi[e * 64 + lane] : r.idx[(i64)e * r.stride + row];
-                            const double v = e < FS_NP ? rowv[e * 64 + lane] : r.val[(i64)e * r.stride + row];
-                            int lo = 0, hi = SW;
-                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (supl[mid] < d) lo = mid + 1; else hi = mid; }
-                            if (lo < SW && supl[lo] == d) addm[lane * SWP + lo] = v; else grow = true;
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                const u64 gm = __ballot(grow);
+                u64 gm;
+                if (PAIR && pre_ok) { gm = pre_gm; pre_ok = false; }        // looked up ahead of my turn, support unchanged since
+                else gm = walk_lookups(r, L, wk.idx, SW, s0, isj, n, row, lane);
                 const int s1 = gm ? __ffsll((long long)gm) - 1 : Tg;
                 FF_T(t_l1);
                 FF_ACC(2, t_l1 - t_l0);
@@ -1157,15 +1228,25 @@ __device__ __forceinline__ void fs_walk_centre(FSRef s, FSRowsRef r, FSCtl *ctl,
                 {
                     const int jj = bc_i(j, s1);
                     if (!wk.join_general<true>(s, r, ctl, pos + jj, jj, bc_i(n, s1), bc_d(fo, s1), bc_d(fn, s1),
-                                               rowi + s1, rowv + s1, 64)) return;
+                                               rowi + s1, rowv + s1, 64)) FS_WALK_LEAVE;
                     wk.publish(s, jj);
+                    gen++;
                 }
                 FF_ACC(4, clock64() - t_l2);
                 s0 = s1 + 1;
                 if (s0 == Tg) break;
             }
             __builtin_amdgcn_wave_barrier();
+            if (PAIR) {
+                sh->val[lane] = wk.val; sh->idx[lane] = wk.idx;
+                if (lane == 0) { sh->sn = wk.sn; sh->gen = gen; }
+                // (an LDS-only release: a full one waits for the chain's 64 version stores to land in memory - 3 400 cycles a
+                // group, most of what the second wave saved - and the other wave reads none of them)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (lane == 0) __hip_atomic_store(&sh->turn, Gc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
+        G0 += (Ts + 63) >> 6;
         a = b; Pa = Pb;
     }
 #ifdef FF_PROFILE
@@ -1190,8 +1271,41 @@ __global__ __launch_bounds__(64) void k_fs_walk(FSArgsPtr ap, int par)
     if (lane == 0) L.zero = 0.0;
     __builtin_amdgcn_wave_barrier();
     for (int k = blockIdx.x; k < K; k += gridDim.x) {
-        fs_walk_centre(s, r, ctl, L, k, jlim, pos, lane);
+        fs_walk_centre<false>(s, r, ctl, L, nullptr, 0, k, jlim, pos, lane);
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// two waves per centre (unit weights): see WalkShare
+__global__ __launch_bounds__(128) void k_fs_walk_pair(FSArgsPtr ap, int par)
+{
+    FSRef s = ap->s; FSRowsRef r = ap->r;
+    extern __shared__ __attribute__((aligned(16))) char wp_smem[];
+    WalkLds *Lw = (WalkLds *)wp_smem;                             // [2]
+    WalkShare *sh = (WalkShare *)(Lw + 2);
+    FSCtl *ctl = s.ctl + par;
+    if (ctl->halt) return;
+    const int K = ctl->K + ctl->nfound, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int jlim = ctl->nb;
+    { const int fnw = ctl->first_new; if (fnw < jlim) jlim = fnw; }
+    if (jlim <= 0) return;
+    const i64 pos = ctl->pos;
+    if (lane == 0) Lw[w].zero = 0.0;
+#ifdef FF_PROFILE
+    {   // do the two waves sit on different SIMDs?  ff_wmax[3] += workgroups whose waves share one (HW_ID bits 5:4)
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        if (lane == 0) sh->idx[w] = (i32)((hw >> 4) & 3u);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&ff_wmax[3], sh->idx[0] == sh->idx[1] ? 1ull : 0ull);
+        if (threadIdx.x == 0) atomicAdd(&ff_prof[7], 0ull);
+        __syncthreads();
+    }
+#endif
+    for (int k = blockIdx.x; k < K; k += gridDim.x) {
+        if (threadIdx.x == 0) { sh->turn = 0; sh->quit = 0; sh->gen = 0; }
+        __syncthreads();
+        fs_walk_centre<true>(s, r, ctl, Lw[w], sh, w, k, jlim, pos, lane);
+        __syncthreads();
     }
 }
 
@@ -1734,6 +1848,16 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
     const bool wide = width > 6 && (c->W_tight > 8 || (c->W_tight == 0 && width > 12));
     i32 K = 0;
     { int rc = ff_read_K(c, f, &K); if (rc) return rc; }
+    // two waves per centre in the walk (unit weights only: the count before a group is then known without the chain;
+    // SITATOR_WALK_PAIR=0 / 1: never / whenever the weights allow)
+    const size_t walk_pair_lds = 2 * sizeof(WalkLds) + sizeof(WalkShare);
+    // - where the chains are long: a batch of FS_BMAX rows holds FS_BMAX / M rows of an ion, which join one centre in order
+    // (C2, 64 ions: 1 024 joins = 16 groups a centre, walk 21.5 -> 17.1 ms a run).  With a few groups a centre there is
+    // nothing to overlap and the pair's 129 KB of LDS admit one workgroup per CU where the single waves run two (C3, 448
+    // ions: 0.32 -> 0.35 s a run with pairs; C4 / C5, 256 / 160 ions: no difference)
+    bool walk_pair = weights == nullptr && c->M > 0 && c->M <= 128;
+    { const char *wp = getenv("SITATOR_WALK_PAIR"); if (wp) walk_pair = wp[0] != '0' && weights == nullptr; }
+    if (walk_pair) HIP_TRY(c, lds_limit((const void *)k_fs_walk_pair, walk_pair_lds, c->device));
     const char *tp = getenv("SITATOR_FF_TRACE");              // diagnostics: one line per step
     if (tp && !f->d_trace) { HIP_TRY(c, hipMalloc((void **)&f->d_trace, (size_t)FS_TRACE_CAP * 48)); HIP_TRY(c, hipMemset(f->d_trace, 0, (size_t)FS_TRACE_CAP * 48)); }
     i64 base = 0;                                             // rows consumed before the current control chain
@@ -1775,19 +1899,27 @@ int fitfast_stream(sit_ctx *c, const i32 *nnz, const i32 *idx, const double *val
         kern<<<dim3(grid), dim3(block), 0, c->stream>>>(__VA_ARGS__);                                    \
         if (hipGetLastError() != hipSuccess) { c->msg = "fit: launch of " name " failed"; return SIT_ERR_HIP; } \
     } while (0)
+#define FS_WALK()                                                                                       \
+    do {                                                                                                \
+        if (walk_pair) {                                                                                \
+            k_fs_walk_pair<<<dim3(gk), dim3(128), walk_pair_lds, c->stream>>>(ap, par);                 \
+            if (hipGetLastError() != hipSuccess) { c->msg = "fit: launch of walk failed"; return SIT_ERR_HIP; } \
+        } else FS_LAUNCH("walk", k_fs_walk, gk, 64, ap, par);                                           \
+    } while (0)
                 if (wide) {
                     FS_LAUNCH("speculate", (k_fs_speculate<8, 16>), grows, 256, ap, par);
                     FS_LAUNCH("found", (k_fs_found<8, 16>), 1, 1024, ap, par);
-                    FS_LAUNCH("walk", k_fs_walk, gk, 64, ap, par);
+                    FS_WALK();
                     FS_LAUNCH("verify", (k_fs_verify<8, 16>), grows, 256, ap, par);
                     FS_LAUNCH("commit", (k_fs_commit<8, 16>), gk + 1, 64, ap, par);
                 } else {
                     FS_LAUNCH("speculate", (k_fs_speculate<4, 8>), grows, 256, ap, par);
                     FS_LAUNCH("found", (k_fs_found<4, 8>), 1, 1024, ap, par);
-                    FS_LAUNCH("walk", k_fs_walk, gk, 64, ap, par);
+                    FS_WALK();
                     FS_LAUNCH("verify", (k_fs_verify<4, 8>), grows, 256, ap, par);
                     FS_LAUNCH("commit", (k_fs_commit<4, 8>), gk + 1, 64, ap, par);
                 }
+#undef FS_WALK
 #undef FS_LAUNCH
                 par ^= 1;
                 bb = bb * 2 > FS_BMAX ? FS_BMAX : bb * 2;
